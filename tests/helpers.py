@@ -1,0 +1,82 @@
+"""Shared test scaffolding (no reference import, safe on the GPU box)."""
+import importlib.util
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def load_pkg():
+    """The package directory is `multiple-objects-gan_amd/` (not an identifier), so it is
+    loaded under the alias `mogan_amd`."""
+    import mogan_loader
+    return mogan_loader.load()
+
+
+def det_array(name, shape, scale=1.0, shift=0.0):
+    """Deterministic N(0,1)*scale+shift float32 array keyed by `name` (numpy RandomState is
+    stable across numpy versions/machines, unlike torch's init RNG consumption order)."""
+    rng = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return (rng.standard_normal(tuple(shape)) * scale + shift).astype(np.float32)
+
+
+def det_fill_state(module, tag=""):
+    """Overwrite every parameter/buffer of `module` deterministically by key name, so the
+    reference model (golden script), the oracle and the HIP model get identical weights
+    without shipping state_dicts."""
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        name = tag + k
+        if k.endswith("num_batches_tracked"):
+            new[k] = torch.zeros_like(v)
+        elif k.endswith("running_mean"):
+            new[k] = torch.from_numpy(det_array(name, v.shape, 0.1))
+        elif k.endswith("running_var"):
+            new[k] = torch.from_numpy(np.abs(det_array(name, v.shape, 0.1)) + 1.0)
+        elif v.dim() == 1 and k.endswith("weight"):      # BN gamma
+            new[k] = torch.from_numpy(det_array(name, v.shape, 0.1, 1.0))
+        elif v.dim() == 1:                                  # biases
+            new[k] = torch.from_numpy(det_array(name, v.shape, 0.1))
+        else:
+            fan_in = int(np.prod(v.shape[1:]))
+            new[k] = torch.from_numpy(det_array(name, v.shape, 1.0 / np.sqrt(fan_in)))
+    module.load_state_dict(new)
+    return new
+
+
+def probe(t):
+    """Size-independent summary of a tensor: [sum, abs-sum, cos-weighted sum] in f64 +
+    the first 16 and a strided sample of 16 elements."""
+    a = t.detach().cpu().double().reshape(-1).numpy()
+    w = np.cos(np.arange(a.size, dtype=np.float64) * 0.37)
+    idx = np.linspace(0, a.size - 1, 16).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), (a * w).sum()], a[:16] if a.size >= 16
+                           else np.pad(a, (0, 16 - a.size)), a[idx]])
+
+
+def probe_close(got, want, rtol, atol=0.0, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    # checksums (first 3) are compared relative to the abs-sum, samples element-wise
+    scale = abs(want[1]) + 1e-30
+    err_cs = np.abs(got[:3] - want[:3]).max() / scale
+    err_el = np.abs(got[3:] - want[3:]).max() / (np.abs(want[3:]).max() + 1e-30)
+    assert err_cs <= rtol + atol and err_el <= rtol * 16 + atol, \
+        "%s: checksum rel err %.3e, sample rel err %.3e (rtol %.1e)" % (what, err_cs, err_el, rtol)
+
+
+def rel_l2(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_abs(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())

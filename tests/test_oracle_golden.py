@@ -1,0 +1,285 @@
+"""Pins oracle/attngan_oracle.py against the golden vectors captured from the reference's own
+python (tests/golden/make_golden.py). CPU only. Tolerances: the oracle calls the same torch-CPU
+ops as the reference in (nearly) the same order, so fp32 agreement is ~1e-6; the tolerances
+below leave ~10x headroom over what was observed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, det_array, load_pkg, probe, probe_close
+from oracle import attngan_oracle as O
+from standin import StandInEncoder
+
+load_pkg()
+from mogan_amd.attngan import synthetic  # noqa: E402
+
+SMALL = O.Cfg(gf_dim=4, df_dim=4, emb_dim=16, r_num=2, words_num=5)
+
+
+def T(name, shape, scale=1.0, shift=0.0):
+    return torch.from_numpy(det_array(name, shape, scale, shift))
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def det_state(spec, tag):
+    """Same deterministic fill as helpers.det_fill_state, from a key->shape spec."""
+    sd = {}
+    for k, shp in spec.items():
+        name = tag + k
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(det_array(name, shp, 0.1))
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(np.abs(det_array(name, shp, 0.1)) + 1.0)
+        elif len(shp) == 1 and k.endswith("weight"):
+            sd[k] = torch.from_numpy(det_array(name, shp, 0.1, 1.0))
+        elif len(shp) == 1:
+            sd[k] = torch.from_numpy(det_array(name, shp, 0.1))
+        else:
+            sd[k] = torch.from_numpy(det_array(name, shp, 1.0 / np.sqrt(int(np.prod(shp[1:])))))
+    return sd
+
+
+def close(got, want, rtol=2e-5, atol=2e-6, what=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=what)
+
+
+def test_theta():
+    g = golden("theta")
+    tm, tmi = synthetic.bbox_to_theta(g["bbox"])
+    np.testing.assert_array_equal(tm.numpy(), g["tm"])
+    np.testing.assert_array_equal(tmi.numpy(), g["tmi"])
+    # absent object (bbox = -1): theta_inv = [[-1,0,-4],[0,-1,-4]] -> zero output
+    np.testing.assert_array_equal(tmi[3].numpy(), np.array([[-1, 0, -4], [0, -1, -4]], np.float32))
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_stn(ac):
+    g = golden("stn")
+    for tag, insz, outsz in (("paste", (3, 5, 8, 8), (3, 5, 8, 8)), ("crop", (3, 2, 12, 10), (3, 2, 6, 7)),
+                             ("rot", (3, 4, 7, 9), (3, 4, 5, 6))):
+        key = "%s_ac%d_" % (tag, int(ac))
+        x = T("stn.%s.x" % tag, insz).requires_grad_(True)
+        y = O.stn(x, torch.from_numpy(g[key + "theta"]), outsz, align_corners=ac)
+        y.backward(T("stn.%s.g" % tag, outsz))
+        close(y, g[key + "y"], what=key + "y")
+        close(x.grad, g[key + "dx"], what=key + "dx")
+    assert np.all(g["paste_ac0_y"][1] == 0)      # the absent object is gated to exactly 0
+
+
+def _spec_block(kind):
+    s = {}
+    if kind == "up":
+        O._up(s, "", 8, 4)
+        s = {k[1:]: v for k, v in s.items()}
+    elif kind == "res":
+        s["block.0.weight"] = (16, 8, 3, 3)
+        O._bn(s, "block.1", 16)
+        s["block.3.weight"] = (8, 8, 3, 3)
+        O._bn(s, "block.4", 8)
+    elif kind == "lrelu3":
+        O._blk(s, "", 8, 6, 3)
+        s = {k[1:]: v for k, v in s.items()}
+    elif kind == "down":
+        O._blk(s, "", 8, 6, 4)
+        s = {k[1:]: v for k, v in s.items()}
+    return s
+
+
+def test_blocks():
+    g = golden("blocks")
+    x = T("blocks.x", (4, 8, 8, 8)).requires_grad_(True)
+    y = O.glu(x)
+    y.backward(T("blocks.glu.g", y.shape))
+    close(y, g["glu_y"])
+    close(x.grad, g["glu_dx"])
+    for tag, gshape in (("up", (4, 4, 16, 16)), ("res", (4, 8, 8, 8)), ("lrelu3", (4, 6, 8, 8)),
+                        ("down", (4, 6, 4, 4))):
+        net = O.from_state_dict(det_state(_spec_block(tag), "blocks.%s." % tag))
+        net = {"m." + k: v for k, v in net.items()}
+        x = T("blocks.x", (4, 8, 8, 8)).requires_grad_(True)
+        if tag == "up":
+            y = O.up_block(net, "m", x)
+        elif tag == "res":
+            y = O.res_block(net, "m", x)
+        else:
+            y = O.down(net, "m", x)
+        y.backward(T("blocks.%s.g" % tag, gshape))
+        close(y, g[tag + "_y"], what=tag)
+        close(x.grad, g[tag + "_dx"], rtol=1e-4, atol=1e-5, what=tag + " dx")
+        for k, v in net.items():
+            kk = k[2:].replace(".", "__")
+            if v.requires_grad:
+                close(v.grad, g["%s_d_%s" % (tag, kk)], rtol=1e-4, atol=1e-5, what=tag + k)
+            elif "running" in k:
+                close(v, g["%s_s_%s" % (tag, kk)], what=tag + k)
+
+
+def test_attention_mask_indexing_and_func_attention():
+    g = golden("attn")
+    for B in (3, 4):
+        net = O.from_state_dict(det_state({"att.conv_context.weight": (6, 10, 1, 1)}, "attn."))
+        # det_fill_state keyed the reference module's weight as "attn.conv_context.weight"
+        net["att.conv_context.weight"] = T("attn.conv_context.weight", (6, 10, 1, 1),
+                                           1.0 / np.sqrt(10)).requires_grad_(True)
+        h = T("attn.h%d" % B, (B, 6, 4, 4)).requires_grad_(True)
+        ctx = T("attn.ctx%d" % B, (B, 10, 5)).requires_grad_(True)
+        p = "b%d_" % B
+        mask = torch.from_numpy(g[p + "mask"])
+        wc, a = O.global_attention(net, "att", h, ctx, mask)
+        (wc * T("attn.gw%d" % B, wc.shape)).sum().add((a * T("attn.ga%d" % B, a.shape)).sum()).backward()
+        close(wc, g[p + "wc"])
+        close(a, g[p + "attn"])
+        close(h.grad, g[p + "dh"], rtol=1e-4)
+        close(ctx.grad, g[p + "dctx"], rtol=1e-4, atol=1e-5)
+        close(net["att.conv_context.weight"].grad, g[p + "dw"], rtol=1e-4, atol=1e-5)
+    q = T("fattn.q", (2, 8, 4)).requires_grad_(True)
+    c = T("fattn.c", (2, 8, 3, 3)).requires_grad_(True)
+    wc, a = O.func_attention(q, c, 4.0)
+    (wc * T("fattn.gw", wc.shape)).sum().backward()
+    close(wc, g["f_wc"])
+    close(a, g["f_attn"])
+    close(q.grad, g["f_dq"], rtol=1e-4, atol=1e-5)
+    close(c.grad, g["f_dc"], rtol=1e-4, atol=1e-5)
+
+
+def test_g_net_end_to_end():
+    g = golden("gnet")
+    cfg = SMALL
+    bt = synthetic.make_batch(3, words_num=cfg.words_num, nef=cfg.emb_dim, seed=11)
+    net = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."))
+    z = bt["z"].clone().requires_grad_(True)
+    sent = bt["sent_emb"].clone().requires_grad_(True)
+    words = bt["words_embs"].clone().requires_grad_(True)
+    imgs, atts, mu, logvar, hs = O.g_net(net, cfg, z, sent, words, bt["mask"], bt["tmi"],
+                                         bt["label_one_hot"], bt["eps"])
+    loss = sum((im * T("G.gimg%d" % i, im.shape)).sum() for i, im in enumerate(imgs))
+    loss = loss + (mu * T("G.gmu", mu.shape)).sum() + (logvar * T("G.glv", logvar.shape)).sum()
+    loss.backward()
+    close(mu, g["mu"]); close(logvar, g["logvar"])
+    close(imgs[0], g["img64"], rtol=1e-4, atol=1e-5)
+    close(imgs[1][:, :, ::2, ::2], g["img128"], rtol=1e-4, atol=1e-5)
+    close(imgs[2][:, :, ::4, ::4], g["img256"], rtol=1e-4, atol=1e-5)
+    close(atts[0][:, :, ::4, ::4], g["att64"], rtol=1e-4, atol=1e-5)
+    close(atts[1][:, :, ::8, ::8], g["att128"], rtol=1e-4, atol=1e-5)
+    probe_close(probe(hs[0]), g["h_code1"], 1e-5, what="h_code1")
+    probe_close(probe(hs[1]), g["h_code2"], 1e-5, what="h_code2")
+    probe_close(probe(imgs[2]), g["img256_p"], 1e-5, what="img256")
+    close(z.grad, g["dz"], rtol=2e-3, atol=1e-4)
+    close(sent.grad, g["dsent"], rtol=2e-3, atol=1e-4)
+    for k, p in O.parameters(net):
+        probe_close(probe(p.grad), g["g_" + k.replace(".", "__")], 2e-3, what="grad " + k)
+    for k, v in net.items():
+        if "running" in k:
+            probe_close(probe(v), g["s_" + k.replace(".", "__")], 1e-5, what=k)
+
+
+def test_d_nets():
+    g = golden("dnets")
+    cfg = SMALL
+    B = 3
+    bt = synthetic.make_batch(B, words_num=cfg.words_num, nef=cfg.emb_dim, seed=11)
+    for i in range(3):
+        net = O.from_state_dict(det_state(O.d_net_spec(i, cfg), "D%d." % i))
+        x = bt["imgs"][i].clone().requires_grad_(True)
+        f = O.d_features(i, net, x, bt, cfg)
+        c = O.d_logits(net, "COND_DNET", f, bt["sent_emb"])
+        u = O.d_logits(net, "UNCOND_DNET", f)
+        cw = O.d_logits(net, "COND_DNET", f[:B - 1], bt["sent_emb"][1:B])
+        loss = (f * T("D%d.gf" % i, f.shape)).sum() + (c * T("D%d.gc" % i, c.shape)).sum() \
+            + (u * T("D%d.gu" % i, u.shape)).sum() + (cw * T("D%d.gcw" % i, cw.shape)).sum()
+        loss.backward()
+        p = "d%d_" % i
+        close(f, g[p + "feat"], rtol=1e-4, atol=1e-5)
+        close(c, g[p + "cond"], rtol=1e-4); close(u, g[p + "uncond"], rtol=1e-4)
+        close(cw, g[p + "wrong"], rtol=1e-4)
+        probe_close(probe(x.grad), g[p + "dx_p"], 1e-4, what="dx")
+        for k, v in O.parameters(net):
+            probe_close(probe(v.grad), g[p + "g_" + k.replace(".", "__")], 1e-4, what="D%d %s" % (i, k))
+        for k, v in net.items():
+            if "running" in k:
+                probe_close(probe(v), g[p + "s_" + k.replace(".", "__")], 1e-5, what=k)
+
+
+def _build_all(cfg):
+    G = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."))
+    Ds = [O.from_state_dict(det_state(O.d_net_spec(i, cfg), "D%d." % i)) for i in range(3)]
+    enc = StandInEncoder(cfg.emb_dim)
+    sd = {k: torch.from_numpy(det_array("ENC." + k, v.shape,
+                                        0.1 if v.dim() == 1 else 1.0 / np.sqrt(int(np.prod(v.shape[1:])))))
+          for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    for p in enc.parameters():
+        p.requires_grad = False
+    return G, Ds, enc.eval()
+
+
+def test_losses():
+    g = golden("losses")
+    cfg = SMALL
+    B = 4
+    bt = synthetic.make_batch(B, words_num=cfg.words_num, nef=cfg.emb_dim, seed=5)
+    G, Ds, enc = _build_all(cfg)
+    fakes = [T("L.fake%d" % i, im.shape, 0.5).requires_grad_(True) for i, im in enumerate(bt["imgs"])]
+    for i, D in enumerate(Ds):
+        err = O.discriminator_loss(i, D, bt["imgs"][i], fakes[i], bt["sent_emb"], bt, cfg)
+        err.backward()
+        close(err, g["errD%d" % i], rtol=1e-5)
+        for k, v in O.parameters(D):
+            probe_close(probe(v.grad), g["d%d_g_%s" % (i, k.replace(".", "__"))], 1e-4, what=k)
+        O.zero_grad(D)
+    errG, _ = O.generator_loss(Ds, enc, fakes, bt, cfg)
+    errG.backward()
+    close(errG, g["errG"], rtol=1e-5)
+    for i, f in enumerate(fakes):
+        probe_close(probe(f.grad), g["dfake%d_p" % i], 1e-4, what="dfake%d" % i)
+    feat = T("L.feat", (B, cfg.emb_dim, 17, 17)).requires_grad_(True)
+    code = T("L.code", (B, cfg.emb_dim)).requires_grad_(True)
+    w0, w1, att = O.words_loss(feat, bt["words_embs"], bt["cap_lens"], cfg, bt["class_ids"])
+    s0, s1 = O.sent_loss(code, bt["sent_emb"], cfg, bt["class_ids"])
+    (w0 + 2 * w1 + 3 * s0 + 4 * s1).backward()
+    for got, key in ((w0, "w0"), (w1, "w1"), (s0, "s0"), (s1, "s1")):
+        close(got, g[key], rtol=1e-5)
+    close(feat.grad, g["dfeat"], rtol=1e-4, atol=1e-6)
+    close(code.grad, g["dcode"], rtol=1e-4, atol=1e-6)
+    close(att[0], g["watt0"], rtol=1e-4); close(att[3], g["watt3"], rtol=1e-4)
+    mu = T("L.mu", (B, 100), 0.5).requires_grad_(True)
+    lv = T("L.lv", (B, 100), 0.5).requires_grad_(True)
+    kl = O.kl_loss(mu, lv)
+    kl.backward()
+    close(kl, g["kl"], rtol=1e-6); close(mu.grad, g["dmu"]); close(lv.grad, g["dlv"])
+
+
+def test_two_train_steps():
+    """Rows 28 of SURVEY §8(a): op order of the step, Adam, EMA, BN running stats."""
+    g = golden("step")
+    cfg = SMALL
+    G, Ds, enc = _build_all(cfg)
+    st = O.TrainState(G, Ds, cfg)
+    for step in range(2):
+        bt = synthetic.make_batch(4, words_num=cfg.words_num, nef=cfg.emb_dim, seed=100 + step)
+        logs = O.train_step(st, bt, enc)
+        p = "s%d_" % step
+        for k in ("errD0", "errD1", "errD2", "errG", "kl"):
+            np.testing.assert_allclose(logs[k], float(g[p + k]), rtol=2e-5 * (1 + 20 * step), err_msg=k)
+        close(logs["fake64"], g[p + "fake64"], rtol=1e-3 * (1 + 10 * step), atol=1e-4 * (1 + 10 * step))
+        # post-Adam parameters: first Adam step is ~lr*sign(g); judged through
+        # checksums relative to the tensor's abs-sum
+        tol = 2e-5 if step == 0 else 2e-4
+        for k, v in G.items():
+            if v.is_floating_point():
+                probe_close(probe(v), g[p + "G_" + k.replace(".", "__")], tol, what="G " + k)
+        for i, D in enumerate(Ds):
+            for k, v in D.items():
+                if v.is_floating_point():
+                    probe_close(probe(v), g["%sD%d_%s" % (p, i, k.replace(".", "__"))], tol,
+                                what="D%d %s" % (i, k))
+        for (k, _), a in zip(O.parameters(G), st.ema):
+            probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], tol, what="ema " + k)

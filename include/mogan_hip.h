@@ -1,0 +1,184 @@
+/* mogan_hip.h -- C ABI of libmogan_hip.so: the MI355X (gfx950) kernels under the AttnGAN G+D
+ * train step of tohinz/multiple-objects-gan.
+ *
+ * The reference has no FFI: its hot path is stock torch.nn ops composed in python
+ * (code/coco/attngan/model.py, GlobalAttention.py, miscc/losses.py, trainer.py:281-342).  Each
+ * entry point below replaces the torch op(s) at the cited reference lines; the python package
+ * binds them with ctypes (multiple-objects-gan_amd/hip/lib.py) and wraps them in
+ * torch.autograd.Function (hip/ops.py).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - all tensors are dense fp32, NCHW, device pointers, borrowed for the duration of the call
+ *     (the caller -- PyTorch -- owns the memory); uint8 masks / int32 lengths where stated;
+ *   - every call is asynchronous on `stream` (pass torch.cuda.current_stream().cuda_stream),
+ *     allocates nothing and keeps no state: scratch comes from the caller as (ws, ws_bytes);
+ *     a null/short workspace only disables split-K (slower, never wrong) unless stated;
+ *   - return 0 on success, negative MOGAN_ERR_* otherwise (no exceptions cross the boundary);
+ *   - thread-safe and re-entrant.
+ */
+#ifndef MOGAN_HIP_H
+#define MOGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* identical to the typedef in <hip/hip_runtime_api.h>; repeated so plain C / ctypes-side tools can
+ * include this header without the HIP SDK */
+typedef struct ihipStream_t* hipStream_t;
+
+#define MOGAN_ERR_SHAPE (-1)  /* unsupported / inconsistent dimensions */
+#define MOGAN_ERR_LAUNCH (-2) /* hip launch error */
+#define MOGAN_ERR_WS (-3)     /* workspace required but too small */
+
+/* activation codes shared by the norm / elementwise families */
+#define MOGAN_ACT_NONE 0
+#define MOGAN_ACT_RELU 1
+#define MOGAN_ACT_LRELU 2 /* LeakyReLU(slope) */
+#define MOGAN_ACT_GLU 3   /* x[:, :C/2] * sigmoid(x[:, C/2:])   (model.py:24-32) */
+#define MOGAN_ACT_TANH 4
+#define MOGAN_ACT_SIGMOID 5
+
+int mogan_abi_version(void);
+/* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
+int mogan_gemm_debug_force(int cfg, int split);
+
+/* ---------------------------------------------------------------- convolution (fp32 MFMA implicit GEMM)
+ * x (B,Cin,Hs,Ws), w (Cout,Cin,KH,KW), y (B,Cout,OH,OW), no bias.  up=1 fuses nn.Upsample(x2,nearest)
+ * in front of the conv (upBlock, model.py:48-55): the conv then sees H=2Hs, W=2Ws.
+ * OH = (H + 2*ph - KH)/stride + 1.  Replaces nn.Conv2d at model.py:35-44,92-99,587,598-609,626,664-677. */
+int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, int pw, int up, int* OH, int* OW);
+int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                     int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
+/* dx: gradient w.r.t. the conv input in the H x W domain, (B,Cin,H,W); for up=1 follow with mogan_down2_sum */
+int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                       int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
+/* dw (Cout,Cin,KH,KW); accumulate != 0 adds into dw */
+int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                       int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
+                       hipStream_t stream);
+/* backward of nearest x2 upsample: dx[b,c,y,x] = sum of the 2x2 block of du (B*C planes of 2H x 2W) */
+int mogan_down2_sum(const float* du, float* dx, int planes, int H, int W, hipStream_t stream);
+
+/* generic strided batched GEMM: C[z][m][n] (+)= sum_k A[z][m][k] * B[z][k][n]; strides in elements.
+ * Replaces nn.Linear (model.py:324,365,371) and torch.bmm (GlobalAttention.py:46,66,100,118). */
+int mogan_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, long long sAb, long long sAm,
+              long long sAk, long long sBb, long long sBk, long long sBn, long long sCb, long long sCm, long long sCn,
+              int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* ---------------------------------------------------------------- batch norm (+ fused activation)
+ * x (B,C,HW) [HW=1: BatchNorm1d].  Training-mode statistics: mean[C], invstd[C] = 1/sqrt(var_biased+eps);
+ * running_mean/var (nullable) updated with `momentum` (unbiased var), as nn.BatchNorm*d does.
+ * ws: >= mogan_bn_ws_bytes(B,C,HW) bytes, REQUIRED. */
+size_t mogan_bn_ws_bytes(int B, int C, int HW);
+int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float momentum, float* mean, float* invstd,
+                   float* running_mean, float* running_var, void* ws, size_t ws_bytes, hipStream_t stream);
+/* y = act(gamma*(x-mean)*invstd + beta) (+ residual).  GLU: y has C/2 channels. residual nullable, shaped like y.
+ * BN+GLU: model.py:52-54,62-63,72-73,366-367; BN+LeakyReLU: 96-101,579,588-589,602-611; BN+ReLU: 372-373;
+ * BN+residual: 75,80. */
+int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const float* residual, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream);
+/* dy (B,Cy,HW) -> dx (B,C,HW), dgamma[C], dbeta[C] (accumulate != 0 adds into dgamma/dbeta).
+ * The residual branch's gradient is dy itself. ws REQUIRED (mogan_bn_ws_bytes). */
+int mogan_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act,
+                     float slope, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+/* eval-mode BN / per-channel affine fused with an activation: y = act(x*scale[c] + shift[c]);
+ * bwd: dx = dy * act'(.) * scale[c].  (frozen Inception BasicConv2d under CNN_ENCODER, model.py:227-242) */
+int mogan_affine_act_fwd(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                         int act, float slope, hipStream_t stream);
+int mogan_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float* dx, int B,
+                         int C, int HW, int act, float slope, hipStream_t stream);
+
+/* ---------------------------------------------------------------- elementwise
+ * act in {RELU, LRELU, GLU (over channel dim: x (B,C,HW) -> y (B,C/2,HW)), TANH, SIGMOID}.
+ * bwd takes the forward INPUT x (and recomputes).  model.py:93,328,373,470,599,627,659 */
+int mogan_act_fwd(const float* x, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream);
+int mogan_act_bwd(const float* x, const float* dy, float* dx, int B, int C, int HW, int act, float slope,
+                  hipStream_t stream);
+/* y (rows,C,HW) += bias[C];  dbias[c] (+)= sum over rows,HW of dy */
+int mogan_bias_add(float* y, const float* bias, int rows, int C, int HW, hipStream_t stream);
+int mogan_bias_grad(const float* dy, float* dbias, int rows, int C, int HW, int accumulate, hipStream_t stream);
+/* y = a + b (n elements); y = a*alpha */
+int mogan_add(const float* a, const float* b, float* y, long long n, hipStream_t stream);
+int mogan_scale(const float* a, float alpha, float* y, long long n, hipStream_t stream);
+
+/* softmax over L of x viewed as (outer, L, inner), y = softmax(scale*x) restricted to the first
+ * lens[o*inner+i] entries (lens nullable = all L); masked entries get 0.  bwd: dx = scale*y*(dy - sum(y*dy)).
+ * GlobalAttention.py:50,58 (func_attention, DAMSM). */
+int mogan_softmax_fwd(const float* x, float* y, const int32_t* lens, long long outer, int L, long long inner,
+                      float scale, hipStream_t stream);
+int mogan_softmax_bwd(const float* y, const float* dy, float* dx, const int32_t* lens, long long outer, int L,
+                      long long inner, float scale, hipStream_t stream);
+
+/* ---------------------------------------------------------------- spatial transformer (object pathway)
+ * y[b,c] = grid_sample(x[b,c], affine_grid(theta[b])) bilinear, zero padding (model.py:17-21).
+ * align_corners: 0 = torch>=1.3 default, 1 = torch 0.4.1 semantics.
+ * bwd scatters with fp32 atomics into dx, which the callee zero-fills first. */
+int mogan_stn_fwd(const float* x, const float* theta, float* y, int B, int C, int Hin, int Win, int Hout, int Wout,
+                  int align_corners, hipStream_t stream);
+int mogan_stn_bwd(const float* dy, const float* theta, float* dx, int B, int C, int Hin, int Win, int Hout,
+                  int Wout, int align_corners, hipStream_t stream);
+/* bbox (N,4)=(x,y,w,h) -> theta (N,2,3), theta_inv (N,2,3)   (miscc/utils.py:16-49) */
+int mogan_bbox_to_theta(const float* bbox, float* theta, float* theta_inv, int N, hipStream_t stream);
+
+/* ---------------------------------------------------------------- word attention over image regions
+ * GlobalAttentionGeneral.forward core (GlobalAttention.py:96-121) after conv_context:
+ * h (B,idf,Q), src (B,idf,T), mask (B,T) uint8 nullable -> wc (B,idf,Q), attn (B,T,Q).
+ * mask_mode 0 = reference indexing (row b*Q+q is masked with mask[(b*Q+q) mod B]),
+ *           1 = mask[b].   Limits: idf <= 128, T <= 32. */
+int mogan_attn_fwd(const float* h, const float* src, const uint8_t* mask, float* wc, float* attn, int B, int idf,
+                   int Q, int T, int mask_mode, hipStream_t stream);
+/* -> dh (B,idf,Q) and dscore (B,T,Q) (gradient w.r.t. the pre-softmax scores).  dattn nullable.
+ * dsrc is then two mogan_bmm calls: dsrc = h . dscore^T + dwc . attn^T. */
+int mogan_attn_bwd(const float* src, const float* attn, const float* dwc, const float* dattn, float* dh,
+                   float* dscore, int B, int idf, int Q, int T, hipStream_t stream);
+
+/* ---------------------------------------------------------------- losses
+ * BCE (mean) of probabilities p[n] against a constant target (nn.BCELoss with torch's log clamp at -100;
+ * miscc/losses.py:158-168,198-201): loss[0] (+)= weight * mean(...); bwd: dp = gout[0]*weight/n * d/dp */
+int mogan_bce_fwd(const float* p, float target, float weight, float* loss, int n, int accumulate,
+                  hipStream_t stream);
+int mogan_bce_bwd(const float* p, float target, float weight, const float* gout, float* dp, int n,
+                  hipStream_t stream);
+/* KL_loss (miscc/losses.py:230-234): loss = -0.5*mean(1 + logvar - mu^2 - exp(logvar)) */
+int mogan_kl_fwd(const float* mu, const float* logvar, float* loss, int n, hipStream_t stream);
+int mogan_kl_bwd(const float* mu, const float* logvar, const float* gout, float* dmu, float* dlogvar, int n,
+                 hipStream_t stream);
+
+/* CA_NET.reparametrize (model.py:333-340): c = eps*exp(0.5*logvar) + mu; bwd: dmu = dc, dlogvar = dc*eps*0.5*exp(0.5*logvar) */
+int mogan_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* c, int n, hipStream_t stream);
+int mogan_reparam_bwd(const float* logvar, const float* eps, const float* dc, float* dmu, float* dlogvar, int n,
+                      hipStream_t stream);
+
+/* ---------------------------------------------------------------- pooling / resize (CNN_ENCODER trunk)
+ * max_pool2d(k,s, no padding) with argmax-free backward (recomputes the window max; ties -> first),
+ * avg_pool2d(k,s,pad, count_include_pad), bilinear resize (align_corners=0) -- model.py:256,264,271,301 */
+int mogan_maxpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, hipStream_t stream);
+int mogan_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, int s,
+                      hipStream_t stream);
+int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, int pad, hipStream_t stream);
+int mogan_avgpool_bwd(const float* dy, float* dx, int planes, int H, int W, int k, int s, int pad,
+                      hipStream_t stream);
+int mogan_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream);
+int mogan_bilinear_bwd(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, hipStream_t stream);
+
+/* ---------------------------------------------------------------- optimizer
+ * One fused Adam step over a flat fp32 bucket (trainer.py:137-148: lr 2e-4, betas (0.5,0.999), eps 1e-8),
+ * optionally followed by the EMA of trainer.py:341-342: ema = ema_decay*ema + (1-ema_decay)*p (ema nullable).
+ * `step` is the 1-based step count; if dev_state (3 floats on the device, zero-initialised) is given it
+ * replaces `step`: the count lives in dev_state[0] and is incremented on the device, so the call can be
+ * captured in a hipGraph and replayed.  eps_mode 0: denom = sqrt(v)/sqrt(1-b2^t) + eps (torch>=1.x);
+ * 1: denom = sqrt(v) + eps with step size lr*sqrt(1-b2^t)/(1-b1^t) (torch 0.4.1).  grad_scale multiplies g
+ * first (1/world_size after an RCCL sum all-reduce). */
+int mogan_adam_step(float* p, const float* g, float* m, float* v, float* ema, long long n, float lr, float beta1,
+                    float beta2, float eps, int step, float* dev_state, int eps_mode, float grad_scale,
+                    float ema_decay, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOGAN_HIP_H */

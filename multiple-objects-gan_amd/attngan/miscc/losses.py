@@ -1,0 +1,142 @@
+"""Losses of the coco-attngan train step (mirror of code/coco/attngan/miscc/losses.py).
+
+Same function names / arguments / return values as the reference.  Differences underneath:
+  * `nn.parallel.data_parallel(netD, inputs, gpus)` (losses.py:146,152,193) becomes a direct call --
+    data parallelism is one process per GPU with an RCCL gradient all-reduce (trainer.py);
+  * words_loss evaluates all (image, caption) pairs in three batched launches instead of the
+    reference's B-iteration python loop over func_attention (losses.py:72-112).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ...hip import ops
+from .config import cfg
+
+
+def _call_d(netD, img, local_labels, transf_matrices, transf_matrices_inv):
+    if local_labels is not None:
+        return netD(img, local_labels, transf_matrices, transf_matrices_inv)
+    return netD(img)
+
+
+def _class_mask(class_ids, batch_size, device):
+    """losses.py:24-35,69-71,116-121: mis-matched samples of the same class are masked out."""
+    if class_ids is None:
+        return None
+    ids = np.asarray(class_ids).reshape(-1)
+    m = (ids[:, None] == ids[None, :])
+    np.fill_diagonal(m, False)
+    if not m.any():
+        return None            # COCO: class_ids are unique per sample (datasets.py:293-299)
+    return torch.from_numpy(m).to(device)
+
+
+def cosine_similarity(x1, x2, dim=1, eps=1e-8):
+    """losses.py:11-17."""
+    w12 = torch.sum(x1 * x2, dim)
+    return (w12 / (torch.norm(x1, 2, dim) * torch.norm(x2, 2, dim)).clamp(min=eps)).squeeze()
+
+
+def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8):
+    """losses.py:20-59."""
+    n0 = torch.norm(cnn_code, 2, dim=1, keepdim=True)
+    n1 = torch.norm(rnn_code, 2, dim=1, keepdim=True)
+    scores0 = ops.bmm(cnn_code.unsqueeze(0), rnn_code.t().unsqueeze(0)).squeeze(0)
+    scores0 = scores0 / (n0 * n1.t()).clamp(min=eps) * cfg.TRAIN.SMOOTH.GAMMA3
+    masks = _class_mask(class_ids, batch_size, cnn_code.device)
+    if masks is not None:
+        scores0 = scores0.masked_fill(masks, -float('inf'))
+    if labels is None:
+        return None, None
+    return F.cross_entropy(scores0, labels), F.cross_entropy(scores0.t(), labels)
+
+
+def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size):
+    """losses.py:62-132.  words_emb (B,nef,T), img_features (B,nef,17,17).
+    similarities[b, i] = log sum_t exp(gamma2 * cos(word_{i,t}, context_{b,i,t})) * gamma3, where the
+    region context comes from func_attention(word_i, feature_b) (GlobalAttention.py:31-69)."""
+    B = batch_size
+    C, T = words_emb.shape[1], words_emb.shape[2]
+    ih, iw = img_features.shape[2], img_features.shape[3]
+    S = ih * iw
+    dev = img_features.device
+    lens = cap_lens.to(dev).to(torch.int32).reshape(B)
+    ctx = img_features.reshape(B, C, S)
+    wt = words_emb.permute(1, 0, 2).reshape(C, B * T)                     # [c, (i,t)]
+    attn = ops.bmm(ctx.transpose(1, 2), wt.unsqueeze(0).expand(B, C, B * T))        # B,S,(i,t)  Eq. (7)
+    lens1 = lens.view(1, 1, B).expand(B, S, B).contiguous()
+    attn = ops.softmax(attn.view(B, S, B, T), 3, 1.0, lens1)             # over the words of caption i
+    attn = ops.softmax(attn, 1, cfg.TRAIN.SMOOTH.GAMMA1)                 # over the regions, Eq. (9)
+    wc = ops.bmm(ctx, attn.view(B, S, B * T)).view(B, C, B, T)           # weighted context [b,c,i,t]
+    w = wt.view(1, C, B, T)
+    row_sim = (wc * w).sum(1) / (torch.norm(w, 2, 1) * torch.norm(wc, 2, 1)).clamp(min=1e-8)   # B,B,T
+    valid = torch.arange(T, device=dev).view(1, 1, T) < lens.view(1, B, 1)
+    row_sim = (row_sim * cfg.TRAIN.SMOOTH.GAMMA2).exp() * valid           # Eq. (10)
+    similarities = torch.log(row_sim.sum(2)) * cfg.TRAIN.SMOOTH.GAMMA3    # [image b, caption i]
+    masks = _class_mask(class_ids, B, dev)
+    if masks is not None:
+        similarities = similarities.masked_fill(masks, -float('inf'))
+    att_maps = None
+    if labels is None or not torch.is_grad_enabled():
+        lens_h = [int(v) for v in cap_lens.tolist()]
+        att_maps = [attn[i, :, i, :lens_h[i]].t().reshape(1, lens_h[i], ih, iw).contiguous() for i in range(B)]
+    if labels is None:
+        return None, None, att_maps
+    return F.cross_entropy(similarities, labels), F.cross_entropy(similarities.t(), labels), att_maps
+
+
+def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels, gpus=None,
+                       local_labels=None, transf_matrices=None, transf_matrices_inv=None):
+    """losses.py:136-174.  D(real) and D(fake.detach()) are two separate calls (separate BN batch
+    statistics); real_labels/fake_labels are the constant 1/0 vectors of prepare_labels."""
+    real_features = _call_d(netD, real_imgs, local_labels, transf_matrices, transf_matrices_inv)
+    fake_features = _call_d(netD, fake_imgs.detach(), local_labels, transf_matrices, transf_matrices_inv)
+    batch_size = real_features.size(0)
+    cond_real_errD = ops.bce(netD.COND_DNET(real_features, conditions), 1.0)
+    cond_fake_errD = ops.bce(netD.COND_DNET(fake_features, conditions), 0.0)
+    cond_wrong_errD = ops.bce(netD.COND_DNET(real_features[:(batch_size - 1)], conditions[1:batch_size]), 0.0)
+    if netD.UNCOND_DNET is not None:
+        real_errD = ops.bce(netD.UNCOND_DNET(real_features), 1.0)
+        fake_errD = ops.bce(netD.UNCOND_DNET(fake_features), 0.0)
+        return ((real_errD + cond_real_errD) / 2. + (fake_errD + cond_fake_errD + cond_wrong_errD) / 3.)
+    return cond_real_errD + (cond_fake_errD + cond_wrong_errD) / 2.
+
+
+def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,
+                   cap_lens, class_ids, gpus=None, local_labels=None, transf_matrices=None,
+                   transf_matrices_inv=None, return_logs=True):
+    """losses.py:177-226.  Returns (errG_total, logs) like the reference; `return_logs=False` skips the
+    .item() host syncs (needed under hipGraph capture) and returns a dict of 0-dim tensors instead."""
+    numDs = len(netsD)
+    batch_size = real_labels.size(0)
+    errG_total = 0
+    parts = {}
+    for i in range(numDs):
+        if i == 0:
+            features = netsD[i](fake_imgs[i], local_labels, transf_matrices, transf_matrices_inv)
+        else:
+            features = netsD[i](fake_imgs[i])
+        g_loss = ops.bce(netsD[i].COND_DNET(features, sent_emb), 1.0)
+        if netsD[i].UNCOND_DNET is not None:
+            g_loss = ops.bce(netsD[i].UNCOND_DNET(features), 1.0) + g_loss
+        errG_total = errG_total + g_loss
+        parts['g_loss%d' % i] = g_loss
+        if i == (numDs - 1):
+            region_features, cnn_code = image_encoder(fake_imgs[i])
+            w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
+                                             class_ids, batch_size)
+            w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+            s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+            s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+            errG_total = errG_total + w_loss + s_loss
+            parts['w_loss'], parts['s_loss'] = w_loss, s_loss
+    if not return_logs:
+        return errG_total, parts
+    logs = ''.join('%s: %.2f ' % (k, v.item()) for k, v in parts.items())
+    return errG_total, logs
+
+
+def KL_loss(mu, logvar):
+    """losses.py:230-234."""
+    return ops.kl_loss(mu, logvar)

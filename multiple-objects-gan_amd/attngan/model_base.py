@@ -1,0 +1,97 @@
+"""Parameter holders and the fused nn.Sequential used by model.py / inception.py."""
+import torch
+import torch.nn as nn
+
+from ..hip import ops
+
+
+# --------------------------------------------------------------------------- parameter holders
+class HipConv2d(nn.Conv2d):
+    def forward(self, x, up=False):
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding, up)
+
+
+class HipLinear(nn.Linear):
+    def forward(self, x, up=False):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class _HipBNMixin:
+    def fused(self, x, act=ops.ACT_NONE, slope=0.2, residual=None):
+        if self.training:
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked += 1
+            return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
+                              residual, self.eps, self.momentum)
+        # eval mode: running statistics folded into a per-channel affine
+        scale = (self.weight.detach() / torch.sqrt(self.running_var + self.eps)).contiguous()
+        shift = (self.bias.detach() - self.running_mean * scale).contiguous()
+        fusable = act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU)
+        y = ops.affine_act(x, scale, shift, act if fusable else ops.ACT_NONE, slope)
+        if not fusable:
+            y = ops.act(y, act, slope)
+        return y if residual is None else ops.add(y, residual)
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+class HipBatchNorm2d(_HipBNMixin, nn.BatchNorm2d):
+    pass
+
+
+class HipBatchNorm1d(_HipBNMixin, nn.BatchNorm1d):
+    pass
+
+
+class GLU(nn.Module):
+    def forward(self, x):
+        assert x.size(1) % 2 == 0, 'channels dont divide 2!'
+        return ops.glu(x)
+
+
+_ACT_CODE = ((GLU, ops.ACT_GLU), (nn.LeakyReLU, ops.ACT_LRELU), (nn.ReLU, ops.ACT_RELU),
+             (nn.Tanh, ops.ACT_TANH), (nn.Sigmoid, ops.ACT_SIGMOID))
+
+
+def _act_of(m):
+    for cls, code in _ACT_CODE:
+        if isinstance(m, cls):
+            return code, float(getattr(m, "negative_slope", 0.0))
+    return None, 0.0
+
+
+class FusedSeq(nn.Sequential):
+    """nn.Sequential whose forward pattern-matches its children into fused launches:
+    [Upsample] conv|linear [BN [GLU|LeakyReLU|ReLU]] , a trailing BN may take a residual."""
+
+    def forward(self, x, residual=None):
+        mods = list(self)
+        i, n, up = 0, len(mods), False
+        while i < n:
+            m = mods[i]
+            if isinstance(m, nn.Upsample):
+                up, i = True, i + 1
+                continue
+            if isinstance(m, (HipConv2d, HipLinear)):
+                x = m(x, up=up)
+                up, i = False, i + 1
+                if i < n and isinstance(mods[i], _HipBNMixin):
+                    bn = mods[i]
+                    i += 1
+                    code, slope = _act_of(mods[i]) if i < n else (None, 0.0)
+                    if code in (ops.ACT_GLU, ops.ACT_LRELU, ops.ACT_RELU):
+                        i += 1
+                    else:
+                        code = ops.ACT_NONE
+                    x = bn.fused(x, code, slope, residual if i == n else None)
+                continue
+            code, slope = _act_of(m)
+            if code is not None:
+                x = ops.act(x, code, slope)
+            elif isinstance(m, FusedSeq) or not isinstance(m, nn.Sequential):
+                x = m(x)
+            i += 1
+        return x
+
+

@@ -1,0 +1,355 @@
+"""coco-attngan trainer (mirror of code/coco/attngan/trainer.py, train path only).
+
+`condGANTrainer` keeps the reference constructor / build_models / define_optimizers /
+prepare_labels / train / save_model surface.  The body of the reference's minibatch loop
+(trainer.py:269-342) lives in `TrainEngine.step`, which is what bench.py times:
+
+    text-encode -> G forward (once) -> for i in 0..2: zero_grad(D_i), discriminator_loss, backward,
+    Adam(D_i) -> zero_grad(G), generator_loss (through the *updated* Ds, incl. DAMSM) + KL, backward,
+    Adam(G) -> EMA(0.999)
+
+MI355X-first differences (results identical to the reference's single-GPU step on the local batch):
+  * parameters, gradients and Adam moments of each network live in flat fp32 buckets
+    (`FlatAdam`): one fused Adam(+EMA) launch and one RCCL all-reduce per network instead of the
+    reference's per-call replicate/broadcast of nn.parallel.data_parallel (trainer.py:296,
+    miscc/losses.py:146,152,193: ~2.7 GB of parameter broadcast per step);
+  * one process per GPU; D_i's gradient all-reduce runs on a side stream and only D_i's own Adam
+    waits for it, so it overlaps D_{i+1}'s forward/backward (D256, the 643 MB bucket, is needed last);
+  * the G step does not compute weight gradients of the Ds (the reference computes and then discards
+    them at the next zero_grad: trainer.py:304,329-333);
+  * the whole device part of the step can be captured into one hipGraph (`use_graph=True`) -- the
+    step is a few thousand short launches at 4x4..16x16 resolution that are otherwise launch-bound.
+"""
+import glob
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..hip import ops
+from .miscc.config import cfg
+from .miscc.losses import KL_loss, discriminator_loss, generator_loss
+from .miscc.utils import copy_G_params, load_params, mkdir_p, weights_init
+from .model import CNN_ENCODER, D_NET64, D_NET128, D_NET256, G_NET, RNN_ENCODER
+
+
+class FlatAdam:
+    """Flat fp32 parameter / gradient / moment buckets of one network + the fused Adam(+EMA) step
+    (torch.optim.Adam(betas=(0.5,0.999)) of trainer.py:137-148 and the EMA of trainer.py:341-342)."""
+
+    ALIGN = 64   # elements
+
+    def __init__(self, module, lr, with_ema=False):
+        self.module, self.lr = module, float(lr)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.offsets, self.numel = offs, total
+        self.p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            self.p[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + p.numel()].view_as(p)
+            p.grad = self.g[o:o + p.numel()].view_as(p)
+        self.ema = self.p.clone() if with_ema else None
+        self.state = torch.zeros(3, dtype=torch.float32, device=dev)     # device-resident step counter
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def step(self, grad_scale=1.0):
+        ops.adam_step(self.p, self.g, self.m, self.v, self.ema, self.lr, 0.5, 0.999, 1e-8,
+                      dev_state=self.state, eps_mode=int(cfg.ADAM_EPS_MODE), grad_scale=grad_scale)
+
+    def ema_params(self):
+        return [self.ema[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
+
+    def state_dict(self):
+        return {"step": self.state[0].item(), "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.state[0] = float(sd["step"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+
+
+class TrainEngine:
+    """Device-side state of one rank: networks, flat optimizers, DP communicator, optional hipGraph."""
+
+    def __init__(self, text_encoder, image_encoder, netG, netsD, distributed=False, use_graph=False):
+        self.text_encoder, self.image_encoder, self.netG, self.netsD = text_encoder, image_encoder, netG, netsD
+        self.optG = FlatAdam(netG, cfg.TRAIN.GENERATOR_LR, with_ema=True)
+        self.optDs = [FlatAdam(d, cfg.TRAIN.DISCRIMINATOR_LR) for d in netsD]
+        self.distributed = bool(distributed) and dist.is_available() and dist.is_initialized() \
+            and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.comm_stream = torch.cuda.Stream() if self.distributed else None
+        self.use_graph = use_graph
+        self._graph = None
+        self._static = None
+        self.last = {}
+
+    # -- data parallel: sum all-reduce of a flat gradient bucket over RCCL on a side stream ----------
+    def _allreduce_async(self, flat):
+        if not self.distributed:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(flat.g)
+            done = torch.cuda.Event()
+            done.record()
+        return done
+
+    def _opt_step(self, flat, pending):
+        if pending is not None:
+            torch.cuda.current_stream().wait_event(pending)
+        flat.step(grad_scale=1.0 / self.world)
+
+    # -- the reference loop body -------------------------------------------------------------------
+    def device_step(self, b):
+        """trainer.py:291-342 given the text embeddings; `b` holds device tensors:
+        imgs[3], z, eps, words_embs, sent_emb, mask, cap_lens, tm, tmi, label_one_hot."""
+        netG, netsD = self.netG, self.netsD
+        B = b["z"].shape[0]
+        real_labels = b["z"].new_ones(B)
+        fake_labels = b["z"].new_zeros(B)
+        match_labels = b["match_labels"]
+        fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"],
+                                        b["label_one_hot"], b.get("eps"))
+        out = {}
+        pend = []
+        for i in range(len(netsD)):
+            self.optDs[i].zero_grad()
+            kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
+                      transf_matrices_inv=b["tmi"]) if i == 0 else {}
+            errD = discriminator_loss(netsD[i], b["imgs"][i], fake_imgs[i], b["sent_emb"], real_labels,
+                                      fake_labels, None, **kw)
+            errD.backward()
+            pend.append(self._allreduce_async(self.optDs[i]))
+            if i > 0:                                    # D_{i-1}'s all-reduce hid behind D_i's fwd/bwd
+                self._opt_step(self.optDs[i - 1], pend[i - 1])
+            out["errD%d" % i] = errD.detach()
+        self._opt_step(self.optDs[-1], pend[-1])
+        # G update: gradients flow through the (updated) Ds to the fake images only
+        self.optG.zero_grad()
+        for d in netsD:
+            for p in d.parameters():
+                p.requires_grad_(False)
+        errG_total, parts = generator_loss(netsD, self.image_encoder, fake_imgs, real_labels, b["words_embs"],
+                                           b["sent_emb"], match_labels, b["cap_lens"], b.get("class_ids"), None,
+                                           local_labels=b["label_one_hot"], transf_matrices=b["tm"],
+                                           transf_matrices_inv=b["tmi"], return_logs=False)
+        kl_loss = KL_loss(mu, logvar)
+        errG_total = errG_total + kl_loss
+        errG_total.backward()
+        for d in netsD:
+            for p in d.parameters():
+                p.requires_grad_(True)
+        self._opt_step(self.optG, self._allreduce_async(self.optG))       # Adam + EMA in one launch
+        out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach())
+        out.update({k: v.detach() for k, v in parts.items()})
+        return out
+
+    def encode_text(self, captions, cap_lens):
+        """trainer.py:281-289."""
+        with torch.no_grad():
+            hidden = self.text_encoder.init_hidden(captions.shape[0])
+            words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
+        mask = (captions == 0)
+        if mask.size(1) > words_embs.size(2):
+            mask = mask[:, :words_embs.size(2)]
+        return words_embs.detach().contiguous(), sent_emb.detach().contiguous(), mask
+
+    def step(self, batch):
+        """One train iteration on a device batch (see synthetic.make_batch for the fields)."""
+        b = dict(batch)
+        if "words_embs" not in b:
+            b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
+        if "match_labels" not in b:
+            b["match_labels"] = torch.arange(b["z"].shape[0], device=b["z"].device)
+        if not self.use_graph:
+            self.last = self.device_step(b)
+            return self.last
+        return self._graph_step(b)
+
+    def _state_tensors(self):
+        ts = []
+        for o in [self.optG] + self.optDs:
+            ts += [o.p, o.m, o.v, o.state] + ([o.ema] if o.ema is not None else [])
+        for net in [self.netG] + list(self.netsD):
+            ts += list(net.buffers())
+        return ts
+
+    def _snapshot(self):
+        return [t.clone() for t in self._state_tensors()]
+
+    def _restore(self, snap):
+        for t, s in zip(self._state_tensors(), snap):
+            t.copy_(s)
+
+    # -- hipGraph capture of device_step ---------------------------------------------------------------
+    _GRAPH_KEYS = ("z", "eps", "words_embs", "sent_emb", "mask", "cap_lens", "tm", "tmi", "label_one_hot",
+                   "match_labels")
+
+    def _graph_step(self, b):
+        if self.distributed:
+            raise RuntimeError("use_graph with RCCL all-reduce inside the capture is not supported; "
+                               "run the eager step for N>1")
+        if self._graph is None:
+            st = {k: b[k].clone() for k in self._GRAPH_KEYS if k in b}
+            st["imgs"] = [t.clone() for t in b["imgs"]]
+            st["class_ids"] = b.get("class_ids")
+            self._static = st
+            snap = self._snapshot()                       # warm-up steps must not train
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up (allocator, workspaces, lazy init)
+                for _ in range(2):
+                    self.device_step(st)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_out = self.device_step(st)
+            self._restore(snap)
+        st = self._static
+        for k in self._GRAPH_KEYS:
+            if k in st:
+                st[k].copy_(b[k])
+        for dst, src in zip(st["imgs"], b["imgs"]):
+            dst.copy_(src)
+        self._graph.replay()
+        self.last = self._graph_out
+        return self.last
+
+
+def build_networks(n_words=27297, device="cuda", image_encoder=None, seed=None):
+    """Random-init networks as trainer.py:53-128 builds them (weights_init: orthogonal)."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
+    for p in text_encoder.parameters():
+        p.requires_grad = False
+    text_encoder.eval()
+    if image_encoder is None:
+        image_encoder = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM, pretrained=False)
+    for p in image_encoder.parameters():
+        p.requires_grad = False
+    image_encoder.eval()
+    netG = G_NET()
+    netsD = []
+    if cfg.TREE.BRANCH_NUM > 0:
+        netsD.append(D_NET64())
+    if cfg.TREE.BRANCH_NUM > 1:
+        netsD.append(D_NET128())
+    if cfg.TREE.BRANCH_NUM > 2:
+        netsD.append(D_NET256())
+    netG.apply(weights_init)
+    for d in netsD:
+        d.apply(weights_init)
+    text_encoder, image_encoder, netG = text_encoder.to(device), image_encoder.to(device), netG.to(device)
+    netsD = [d.to(device) for d in netsD]
+    return text_encoder, image_encoder, netG, netsD
+
+
+class condGANTrainer(object):
+    """Same constructor and public methods as the reference class (trainer.py:29-366)."""
+
+    def __init__(self, output_dir, data_loader, n_words, ixtoword, resume, distributed=False, use_graph=False):
+        if cfg.TRAIN.FLAG:
+            self.model_dir = os.path.join(output_dir, 'Model')
+            self.image_dir = os.path.join(output_dir, 'Image')
+            mkdir_p(self.model_dir)
+            mkdir_p(self.image_dir)
+        self.batch_size = cfg.TRAIN.BATCH_SIZE
+        self.max_epoch = cfg.TRAIN.MAX_EPOCH
+        self.snapshot_interval = cfg.TRAIN.SNAPSHOT_INTERVAL
+        self.resume = resume
+        self.gpus = [int(ix) for ix in str(cfg.GPU_ID).split(',')]
+        self.n_words, self.ixtoword = n_words, ixtoword
+        self.data_loader = data_loader
+        self.num_batches = len(self.data_loader) if data_loader is not None else 0
+        self.distributed, self.use_graph = distributed, use_graph
+        # one process per GPU: the local device comes from LOCAL_RANK (torchrun), not from GPU_ID
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+        torch.cuda.set_device(self.device)
+
+    def build_models(self):
+        text_encoder, image_encoder, netG, netsD = build_networks(self.n_words, self.device)
+        epoch = 0
+        if cfg.TRAIN.NET_E != '' and os.path.isfile(cfg.TRAIN.NET_E):
+            sd = torch.load(cfg.TRAIN.NET_E, map_location='cpu')
+            text_encoder.load_state_dict(sd)
+            img_path = cfg.TRAIN.NET_E.replace('text_encoder', 'image_encoder')
+            if os.path.isfile(img_path):
+                image_encoder.load_state_dict(torch.load(img_path, map_location='cpu'))
+        if self.resume:
+            ckpts = sorted(glob.glob(self.model_dir + "/" + '*.pth'))
+            if ckpts:
+                sd = torch.load(ckpts[-1], map_location='cpu')
+                netG.load_state_dict(sd["netG"])
+                for i in range(len(netsD)):
+                    netsD[i].load_state_dict(sd["netD"][i])
+                epoch = int(ckpts[-1][-8:-4]) + 1
+        return [text_encoder, image_encoder, netG, netsD, epoch]
+
+    def define_optimizers(self, netG, netsD):
+        return self.engine.optG, self.engine.optDs
+
+    def prepare_labels(self):
+        B = self.batch_size
+        return (torch.ones(B, device=self.device), torch.zeros(B, device=self.device),
+                torch.arange(B, device=self.device))
+
+    def save_model(self, netG, avg_param_G, netsD, optimG, optimsD, epoch, max_to_keep=5):
+        """trainer.py:173-199: netG is saved with the EMA weights swapped in; newest 5 kept."""
+        backup_para = copy_G_params(netG)
+        load_params(netG, avg_param_G)
+        checkpoint = {'epoch': epoch, 'netG': netG.state_dict(), 'optimG': optimG.state_dict(),
+                      'netD': [d.state_dict() for d in netsD], 'optimD': [o.state_dict() for o in optimsD]}
+        torch.save(checkpoint, "{}/checkpoint_{:04}.pth".format(self.model_dir, epoch))
+        load_params(netG, backup_para)
+        if max_to_keep is not None and max_to_keep > 0:
+            ckpts = sorted(glob.glob(self.model_dir + "/" + '*.pth'))
+            while len(ckpts) > max_to_keep:
+                os.remove(ckpts[0])
+                ckpts = ckpts[1:]
+
+    def train(self):
+        from .datasets import prepare_data
+        text_encoder, image_encoder, netG, netsD, start_epoch = self.build_models()
+        self.engine = TrainEngine(text_encoder, image_encoder, netG, netsD, self.distributed, self.use_graph)
+        optimizerG, optimizersD = self.define_optimizers(netG, netsD)
+        nz = cfg.GAN.Z_DIM
+        gen_iterations = 0
+        for epoch in range(start_epoch, self.max_epoch):
+            start_t = time.time()
+            logs = {}
+            for data in self.data_loader:
+                imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data(data, self.device)
+                batch = dict(imgs=imgs, captions=captions, cap_lens=cap_lens, cap_lens_cpu=cap_lens.cpu(),
+                             class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot,
+                             z=torch.randn(captions.shape[0], nz, device=self.device))
+                logs = self.engine.step(batch)
+                gen_iterations += 1
+                if gen_iterations % 1000 == 0:
+                    print(' '.join('%s: %.2f' % (k, float(v)) for k, v in logs.items() if v.dim() == 0))
+            end_t = time.time()
+            if logs:
+                errD_total = sum(float(logs["errD%d" % i]) for i in range(len(netsD)))
+                print('''[%d/%d][%d]
+                  Loss_D: %.2f Loss_G: %.2f Time: %.2fs''' % (epoch, self.max_epoch, self.num_batches,
+                                                            errD_total, float(logs["errG"]), end_t - start_t))
+            if epoch % cfg.TRAIN.SNAPSHOT_INTERVAL == 0 and (not self.distributed or dist.get_rank() == 0):
+                self.save_model(netG, optimizerG.ema_params(), netsD, optimizerG, optimizersD, epoch)
+        if not self.distributed or dist.get_rank() == 0:
+            self.save_model(netG, optimizerG.ema_params(), netsD, optimizerG, optimizersD, self.max_epoch - 1)

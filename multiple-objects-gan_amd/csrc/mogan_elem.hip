@@ -1,0 +1,528 @@
+// mogan_elem.hip -- HBM-bound elementwise / small-reduction kernels of the AttnGAN step:
+// activations (LeakyReLU, GLU, tanh, sigmoid), bias, add/scale, nearest-upsample backward, strided
+// softmax, BCE / KL losses, pooling + bilinear resize (CNN_ENCODER trunk) and the fused Adam(+EMA)
+// step over flat fp32 buckets.  Grid-stride / float4 where the layout allows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mogan_hip.h"
+
+namespace {
+
+static inline int ok_launch() { return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH; }
+static inline unsigned nblk(long long n, int per = 256) {
+    long long b = (n + per - 1) / per;
+    return (unsigned)(b < 1 ? 1 : (b > 262144 ? 262144 : b));     // grid-stride beyond this
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sumd(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// -------------------------------------------------------------------------------- activations
+template <int ACT, bool BWD>
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                  float* __restrict__ out, long long n, float slope) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        float o;
+        if (!BWD) {
+            if (ACT == MOGAN_ACT_RELU) o = v > 0.f ? v : 0.f;
+            else if (ACT == MOGAN_ACT_LRELU) o = v > 0.f ? v : v * slope;
+            else if (ACT == MOGAN_ACT_TANH) o = tanhf(v);
+            else o = sigmoidf_(v);
+        } else {
+            const float d = dy[i];
+            if (ACT == MOGAN_ACT_RELU) o = v > 0.f ? d : 0.f;
+            else if (ACT == MOGAN_ACT_LRELU) o = v > 0.f ? d : d * slope;
+            else if (ACT == MOGAN_ACT_TANH) { const float t = tanhf(v); o = d * (1.f - t * t); }
+            else { const float s = sigmoidf_(v); o = d * s * (1.f - s); }
+        }
+        out[i] = o;
+    }
+}
+
+// GLU over the channel dim: x (B,C,HW) -> y (B,C/2,HW)
+template <bool BWD>
+__global__ __launch_bounds__(256) void glu_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                  float* __restrict__ out, long long total, int Ch, long long HW) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long hw = i % HW, bc = i / HW;
+        const long long c = bc % Ch, b = bc / Ch;
+        const long long ia = (b * 2 * Ch + c) * HW + hw, ig = ia + (long long)Ch * HW;
+        const float a = x[ia], s = sigmoidf_(x[ig]);
+        if (!BWD) out[i] = a * s;
+        else { const float d = dy[i]; out[ia] = d * s; out[ig] = d * a * s * (1.f - s); }
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_add_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                       long long total, int C, long long HW) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        y[i] += bias[(i / HW) % C];
+}
+
+// one block per channel
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int rows,
+                                                        int C, int HW, int accumulate) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double s = 0;
+    const long long per = (long long)rows * HW;
+    for (long long e = threadIdx.x; e < per; e += 256) {
+        const long long r = e / HW, i = e % HW;
+        s += dy[(r * C + c) * HW + i];
+    }
+    s = wave_sumd(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ a, float alpha, float* __restrict__ y,
+                                                    long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = a[i] * alpha;
+}
+
+// dx[p,y,x] = sum of the 2x2 block of du[p, 2y..2y+1, 2x..2x+1]
+__global__ __launch_bounds__(256) void down2_sum_kernel(const float* __restrict__ du, float* __restrict__ dx,
+                                                        long long total, int H, int W) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xw = (int)(i % W);
+        const long long t = i / W;
+        const int y = (int)(t % H);
+        const long long pl = t / H;
+        const float* p = du + (pl * 2 * H + 2 * y) * 2 * W + 2 * xw;
+        const float2 r0 = *(const float2*)p, r1 = *(const float2*)(p + 2 * W);
+        dx[i] = (r0.x + r0.y) + (r1.x + r1.y);
+    }
+}
+
+// -------------------------------------------------------------------------------- strided softmax
+// x viewed (outer, L, inner); one thread per (o, i) column, three passes over L (L <= a few hundred).
+template <bool BWD>
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      float* __restrict__ out, const int32_t* __restrict__ lens,
+                                                      long long cols, int L, long long inner, float scale) {
+    const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const long long o = col / inner, i = col % inner;
+    const long long base = o * L * inner + i;
+    const int n = lens ? min(L, max(0, lens[col])) : L;
+    if (!BWD) {
+        float m = -INFINITY;
+        for (int l = 0; l < n; ++l) m = fmaxf(m, x[base + l * inner] * scale);
+        float s = 0.f;
+        for (int l = 0; l < n; ++l) s += __expf(x[base + l * inner] * scale - m);
+        const float inv = 1.f / s;
+        for (int l = 0; l < n; ++l) out[base + l * inner] = __expf(x[base + l * inner] * scale - m) * inv;
+        for (int l = n; l < L; ++l) out[base + l * inner] = 0.f;
+    } else {   // x = y (softmax output)
+        float dot = 0.f;
+        for (int l = 0; l < n; ++l) dot += x[base + l * inner] * dy[base + l * inner];
+        for (int l = 0; l < n; ++l) {
+            const float yv = x[base + l * inner];
+            out[base + l * inner] = scale * yv * (dy[base + l * inner] - dot);
+        }
+        for (int l = n; l < L; ++l) out[base + l * inner] = 0.f;
+    }
+}
+
+// -------------------------------------------------------------------------------- losses (single block)
+__device__ __forceinline__ float block_sum_f(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, float target, float weight,
+                                                      float* __restrict__ loss, int n, int accumulate) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float lp = fmaxf(logf(p[i]), -100.f), l1p = fmaxf(logf(1.f - p[i]), -100.f);
+        s -= target * lp + (1.f - target) * l1p;
+    }
+    s = block_sum_f(s, sh);
+    if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.f) + weight * s / (float)n;
+}
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ p, float target, float weight,
+                                                      const float* __restrict__ gout, float* __restrict__ dp, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // d/dp of -(t*max(log p,-100) + (1-t)*max(log(1-p),-100)); the clamp zeroes the slope beyond it
+    const float pv = p[i];
+    float g = 0.f;
+    if (logf(pv) > -100.f) g -= target / pv;
+    if (logf(1.f - pv) > -100.f) g += (1.f - target) / (1.f - pv);
+    dp[i] = gout[0] * weight * g / (float)n;
+}
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                     float* __restrict__ loss, int n) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += 1.f + lv[i] - mu[i] * mu[i] - __expf(lv[i]);
+    s = block_sum_f(s, sh);
+    if (threadIdx.x == 0) loss[0] = -0.5f * s / (float)n;
+}
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                     const float* __restrict__ gout, float* __restrict__ dmu,
+                                                     float* __restrict__ dlv, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = gout[0] * (-0.5f) / (float)n;
+    dmu[i] = g * (-2.f * mu[i]);
+    dlv[i] = g * (1.f - __expf(lv[i]));
+}
+
+// -------------------------------------------------------------------------------- pooling / resize
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long long total, int H, int W, int OH, int OW, int k, int s) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+        const float* px = x + pl * H * W;
+        float m = -INFINITY;
+        for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) m = fmaxf(m, px[(oy * s + a) * W + ox * s + b]);
+        y[i] = m;
+    }
+}
+// gather form: dx[p,iy,ix] = sum over windows containing (iy,ix) whose first max is at (iy,ix)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, long long total, int H, int W, int OH,
+                                                          int OW, int k, int s) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
+        const float* px = x + pl * H * W;
+        const float v = px[iy * W + ix];
+        float g = 0.f;
+        const int oy0 = max(0, (iy - k + s) / s), oy1 = min(OH - 1, iy / s);
+        const int ox0 = max(0, (ix - k + s) / s), ox1 = min(OW - 1, ix / s);
+        for (int oy = oy0; oy <= oy1; ++oy)
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                // is (iy,ix) the first maximum of window (oy,ox)?
+                bool first = true;
+                for (int a = 0; a < k && first; ++a)
+                    for (int b = 0; b < k; ++b) {
+                        const int yy = oy * s + a, xx = ox * s + b;
+                        const float w = px[yy * W + xx];
+                        if (w > v || (w == v && (yy < iy || (yy == iy && xx < ix)))) { first = false; break; }
+                    }
+                if (first) g += dy[(pl * OH + oy) * OW + ox];
+            }
+        dx[i] = g;
+    }
+}
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long long total, int H, int W, int OH, int OW, int k, int s,
+                                                          int pad) {
+    const float inv = 1.f / (float)(k * k);                       // count_include_pad=True
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+        const float* px = x + pl * H * W;
+        float sum = 0.f;
+        for (int a = 0; a < k; ++a) {
+            const int yy = oy * s - pad + a; if ((unsigned)yy >= (unsigned)H) continue;
+            for (int b = 0; b < k; ++b) { const int xx = ox * s - pad + b; if ((unsigned)xx < (unsigned)W) sum += px[yy * W + xx]; }
+        }
+        y[i] = sum * inv;
+    }
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                          long long total, int H, int W, int OH, int OW, int k, int s,
+                                                          int pad) {
+    const float inv = 1.f / (float)(k * k);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
+        float g = 0.f;
+        for (int oy = 0; oy < OH; ++oy) {
+            const int a = iy + pad - oy * s; if (a < 0 || a >= k) continue;
+            for (int ox = 0; ox < OW; ++ox) { const int b = ix + pad - ox * s; if (b >= 0 && b < k) g += dy[(pl * OH + oy) * OW + ox]; }
+        }
+        dx[i] = g * inv;
+    }
+}
+// bilinear, align_corners = False (torch area_pixel_compute_source_index)
+__device__ __forceinline__ void bil_src(int o, float scale, int in, int& i0, int& i1, float& l1) {
+    float src = ((float)o + 0.5f) * scale - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src; i1 = i0 + (i0 < in - 1 ? 1 : 0); l1 = src - (float)i0;
+}
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           long long total, int H, int W, int OH, int OW) {
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+        int y0, y1, x0, x1; float ly, lx;
+        bil_src(oy, sh, H, y0, y1, ly); bil_src(ox, sw, W, x0, x1, lx);
+        const float* px = x + pl * H * W;
+        y[i] = (1.f - ly) * ((1.f - lx) * px[y0 * W + x0] + lx * px[y0 * W + x1]) +
+               ly * ((1.f - lx) * px[y1 * W + x0] + lx * px[y1 * W + x1]);
+    }
+}
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                           long long total, int H, int W, int OH, int OW) {
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+        int y0, y1, x0, x1; float ly, lx;
+        bil_src(oy, sh, H, y0, y1, ly); bil_src(ox, sw, W, x0, x1, lx);
+        float* px = dx + pl * H * W;
+        const float g = dy[i];
+        atomicAdd(px + y0 * W + x0, g * (1.f - ly) * (1.f - lx));
+        atomicAdd(px + y0 * W + x1, g * (1.f - ly) * lx);
+        atomicAdd(px + y1 * W + x0, g * ly * (1.f - lx));
+        atomicAdd(px + y1 * W + x1, g * ly * lx);
+    }
+}
+
+// -------------------------------------------------------------------------------- Adam (+EMA)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
+                                                   long long n4, long long n, float beta1, float beta2, float eps,
+                                                   float step_size, float inv_sqrt_bc2, int eps_mode, float gscale,
+                                                   float ema_decay, const float* __restrict__ dev_state) {
+    if (dev_state) { step_size = dev_state[1]; inv_sqrt_bc2 = dev_state[2]; }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const long long e = i * 4;
+        float pv[4], gv[4], mv[4], vv[4], ev[4];
+        const bool full = e + 3 < n;
+        if (full) {
+            *(float4*)pv = *(const float4*)(p + e); *(float4*)gv = *(const float4*)(g + e);
+            *(float4*)mv = *(const float4*)(m + e); *(float4*)vv = *(const float4*)(v + e);
+            if (ema) *(float4*)ev = *(const float4*)(ema + e);
+        } else {
+            for (int k = 0; k < 4; ++k) if (e + k < n) { pv[k] = p[e + k]; gv[k] = g[e + k]; mv[k] = m[e + k]; vv[k] = v[e + k]; if (ema) ev[k] = ema[e + k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = gv[k] * gscale;
+            mv[k] = mv[k] * beta1 + (1.f - beta1) * gg;
+            vv[k] = vv[k] * beta2 + (1.f - beta2) * gg * gg;
+            const float denom = eps_mode == 0 ? (sqrtf(vv[k]) * inv_sqrt_bc2 + eps) : (sqrtf(vv[k]) + eps);
+            pv[k] = pv[k] - step_size * (mv[k] / denom);
+            if (ema) ev[k] = ev[k] * ema_decay + (1.f - ema_decay) * pv[k];
+        }
+        if (full) {
+            *(float4*)(p + e) = *(float4*)pv; *(float4*)(m + e) = *(float4*)mv; *(float4*)(v + e) = *(float4*)vv;
+            if (ema) *(float4*)(ema + e) = *(float4*)ev;
+        } else {
+            for (int k = 0; k < 4; ++k) if (e + k < n) { p[e + k] = pv[k]; m[e + k] = mv[k]; v[e + k] = vv[k]; if (ema) ema[e + k] = ev[k]; }
+        }
+    }
+}
+
+// CA_NET.reparametrize (model.py:333-340): c = eps*exp(0.5*logvar) + mu
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                          const float* __restrict__ eps, float* __restrict__ c, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) c[i] = eps[i] * __expf(0.5f * lv[i]) + mu[i];
+}
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restrict__ lv, const float* __restrict__ eps,
+                                                          const float* __restrict__ dc, float* __restrict__ dmu,
+                                                          float* __restrict__ dlv, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { dmu[i] = dc[i]; dlv[i] = dc[i] * eps[i] * 0.5f * __expf(0.5f * lv[i]); }
+}
+
+// device-resident step counter (hipGraph replays cannot change kernel arguments):
+// state[0] = step count (as float, exact to 2^24), state[1] = step size, state[2] = 1/sqrt(1-b2^t)
+__global__ void adam_prep_kernel(float* __restrict__ state, float lr, float beta1, float beta2, int eps_mode) {
+    const double t = (double)state[0] + 1.0;
+    state[0] = (float)t;
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    state[1] = eps_mode == 0 ? (float)((double)lr / bc1) : (float)((double)lr * sqrt(bc2) / bc1);
+    state[2] = (float)(1.0 / sqrt(bc2));
+}
+
+}  // namespace
+
+extern "C" {
+
+int mogan_abi_version(void) { return 1; }
+
+int mogan_act_fwd(const float* x, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)B * C * HW;
+    switch (act) {
+        case MOGAN_ACT_RELU: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_RELU, false>), dim3(nblk(n)), dim3(256), 0, stream, x, nullptr, y, n, slope); break;
+        case MOGAN_ACT_LRELU: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_LRELU, false>), dim3(nblk(n)), dim3(256), 0, stream, x, nullptr, y, n, slope); break;
+        case MOGAN_ACT_TANH: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_TANH, false>), dim3(nblk(n)), dim3(256), 0, stream, x, nullptr, y, n, slope); break;
+        case MOGAN_ACT_SIGMOID: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_SIGMOID, false>), dim3(nblk(n)), dim3(256), 0, stream, x, nullptr, y, n, slope); break;
+        case MOGAN_ACT_GLU:
+            if (C & 1) return MOGAN_ERR_SHAPE;
+            hipLaunchKernelGGL((glu_kernel<false>), dim3(nblk(n / 2)), dim3(256), 0, stream, x, nullptr, y, n / 2, C / 2, (long long)HW);
+            break;
+        default: return MOGAN_ERR_SHAPE;
+    }
+    return ok_launch();
+}
+
+int mogan_act_bwd(const float* x, const float* dy, float* dx, int B, int C, int HW, int act, float slope,
+                  hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)B * C * HW;
+    switch (act) {
+        case MOGAN_ACT_RELU: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_RELU, true>), dim3(nblk(n)), dim3(256), 0, stream, x, dy, dx, n, slope); break;
+        case MOGAN_ACT_LRELU: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_LRELU, true>), dim3(nblk(n)), dim3(256), 0, stream, x, dy, dx, n, slope); break;
+        case MOGAN_ACT_TANH: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_TANH, true>), dim3(nblk(n)), dim3(256), 0, stream, x, dy, dx, n, slope); break;
+        case MOGAN_ACT_SIGMOID: hipLaunchKernelGGL((act_kernel<MOGAN_ACT_SIGMOID, true>), dim3(nblk(n)), dim3(256), 0, stream, x, dy, dx, n, slope); break;
+        case MOGAN_ACT_GLU:
+            if (C & 1) return MOGAN_ERR_SHAPE;
+            hipLaunchKernelGGL((glu_kernel<true>), dim3(nblk(n / 2)), dim3(256), 0, stream, x, dy, dx, n / 2, C / 2, (long long)HW);
+            break;
+        default: return MOGAN_ERR_SHAPE;
+    }
+    return ok_launch();
+}
+
+int mogan_bias_add(float* y, const float* bias, int rows, int C, int HW, hipStream_t stream) {
+    if (rows <= 0 || C <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)rows * C * HW;
+    hipLaunchKernelGGL(bias_add_kernel, dim3(nblk(n)), dim3(256), 0, stream, y, bias, n, C, (long long)HW);
+    return ok_launch();
+}
+int mogan_bias_grad(const float* dy, float* dbias, int rows, int C, int HW, int accumulate, hipStream_t stream) {
+    if (rows <= 0 || C <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, stream, dy, dbias, rows, C, HW, accumulate);
+    return ok_launch();
+}
+int mogan_add(const float* a, const float* b, float* y, long long n, hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(add_kernel, dim3(nblk(n)), dim3(256), 0, stream, a, b, y, n);
+    return ok_launch();
+}
+int mogan_scale(const float* a, float alpha, float* y, long long n, hipStream_t stream) {
+    if (n <= 0) return n == 0 ? 0 : MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(scale_kernel, dim3(nblk(n)), dim3(256), 0, stream, a, alpha, y, n);
+    return ok_launch();
+}
+int mogan_down2_sum(const float* du, float* dx, int planes, int H, int W, hipStream_t stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)planes * H * W;
+    hipLaunchKernelGGL(down2_sum_kernel, dim3(nblk(n)), dim3(256), 0, stream, du, dx, n, H, W);
+    return ok_launch();
+}
+
+int mogan_softmax_fwd(const float* x, float* y, const int32_t* lens, long long outer, int L, long long inner,
+                      float scale, hipStream_t stream) {
+    if (outer <= 0 || L <= 0 || inner <= 0) return MOGAN_ERR_SHAPE;
+    const long long cols = outer * inner;
+    hipLaunchKernelGGL((softmax_kernel<false>), dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, x, nullptr, y, lens, cols, L, inner, scale);
+    return ok_launch();
+}
+int mogan_softmax_bwd(const float* y, const float* dy, float* dx, const int32_t* lens, long long outer, int L,
+                      long long inner, float scale, hipStream_t stream) {
+    if (outer <= 0 || L <= 0 || inner <= 0) return MOGAN_ERR_SHAPE;
+    const long long cols = outer * inner;
+    hipLaunchKernelGGL((softmax_kernel<true>), dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, y, dy, dx, lens, cols, L, inner, scale);
+    return ok_launch();
+}
+
+int mogan_bce_fwd(const float* p, float target, float weight, float* loss, int n, int accumulate, hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(256), 0, stream, p, target, weight, loss, n, accumulate);
+    return ok_launch();
+}
+int mogan_bce_bwd(const float* p, float target, float weight, const float* gout, float* dp, int n, hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, target, weight, gout, dp, n);
+    return ok_launch();
+}
+int mogan_kl_fwd(const float* mu, const float* logvar, float* loss, int n, hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, stream, mu, logvar, loss, n);
+    return ok_launch();
+}
+int mogan_kl_bwd(const float* mu, const float* logvar, const float* gout, float* dmu, float* dlogvar, int n,
+                 hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, mu, logvar, gout, dmu, dlogvar, n);
+    return ok_launch();
+}
+
+int mogan_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* c, int n, hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, mu, logvar, eps, c, n);
+    return ok_launch();
+}
+int mogan_reparam_bwd(const float* logvar, const float* eps, const float* dc, float* dmu, float* dlogvar, int n,
+                      hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, logvar, eps, dc, dmu, dlogvar, n);
+    return ok_launch();
+}
+
+int mogan_maxpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, hipStream_t stream) {
+    const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
+    if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW, k, s);
+    return ok_launch();
+}
+int mogan_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, int s,
+                      hipStream_t stream) {
+    const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
+    if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)planes * H * W;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, dy, dx, n, H, W, OH, OW, k, s);
+    return ok_launch();
+}
+int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, int pad, hipStream_t stream) {
+    const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
+    if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW, k, s, pad);
+    return ok_launch();
+}
+int mogan_avgpool_bwd(const float* dy, float* dx, int planes, int H, int W, int k, int s, int pad,
+                      hipStream_t stream) {
+    const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
+    if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)planes * H * W;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW, k, s, pad);
+    return ok_launch();
+}
+int mogan_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream) {
+    if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW);
+    return ok_launch();
+}
+int mogan_bilinear_bwd(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, hipStream_t stream) {
+    if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    if (hipMemsetAsync(dx, 0, (size_t)planes * H * W * sizeof(float), stream) != hipSuccess) return MOGAN_ERR_LAUNCH;
+    const long long n = (long long)planes * OH * OW;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW);
+    return ok_launch();
+}
+
+int mogan_adam_step(float* p, const float* g, float* m, float* v, float* ema, long long n, float lr, float beta1,
+                    float beta2, float eps, int step, float* dev_state, int eps_mode, float grad_scale,
+                    float ema_decay, hipStream_t stream) {
+    if (n <= 0 || (!dev_state && step < 1)) return MOGAN_ERR_SHAPE;
+    if (dev_state) { hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, stream, dev_state, lr, beta1, beta2, eps_mode); step = 1; }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = eps_mode == 0 ? (float)(lr / bc1) : (float)(lr * sqrt(bc2) / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const long long n4 = (n + 3) / 4;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) != 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk(n4)), dim3(256), 0, stream, p, g, m, v, ema, n4, n, beta1, beta2, eps,
+                       step_size, inv_sqrt_bc2, eps_mode, grad_scale, ema_decay, (const float*)dev_state);
+    return ok_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,493 @@
+// mogan_gemm.hip -- fp32 MFMA implicit-GEMM for gfx950 (CDNA4).
+//
+// One LDS-tiled kernel, four operand "gather modes":
+//   CONV_FWD    Y[n,co,oy,ox]  = sum_{ci,kh,kw} W[co,ci,kh,kw] * X[n,ci,oy*s-p+kh,ox*s-p+kw]
+//               GEMM: M=Cout, N=B*OH*OW, K=Cin*KH*KW   (optional fused nearest-x2 upsample of X)
+//   CONV_DGRAD  dX[n,ci,y,x]   = sum_{co,kh,kw} W[co,ci,kh,kw] * dY[n,co,(y+p-kh)/s,(x+p-kw)/s]
+//               one GEMM per stride-parity class (blockIdx.z): M=Cin, N=B*Hc*Wc, K=Cout*ceil(KH/s)*ceil(KW/s)
+//   CONV_WGRAD  dW[co,ci,kh,kw] = sum_{n,oy,ox} dY[n,co,oy,ox] * X[n,ci,oy*s-p+kh,ox*s-p+kw]
+//               GEMM: M=Cout, N=Cin*KH*KW, K=B*OH*OW
+//   BMM         generic strided batched GEMM (Linear fwd/dgrad/wgrad, attention / DAMSM products)
+//
+// Math is exact fp32: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, 157.3 TF peak on MI355X;
+// there is no TF32/xf32 on gfx950).  Block = 256 threads = 4 wave64; each wave owns TMxTN tiles of
+// 32x32; BK = 32.  A is staged as As[m][k] (row stride 33), B as Bs[k][n] (row stride BN+1): both
+// MFMA operand reads (`ds_read_b32`, 32-lane groups) are bank-conflict free.  Global->register
+// prefetch of K-tile t+1 is issued before the MFMAs of tile t (one LDS buffer, two barriers per
+// tile): with a 64-cycle MFMA the kernel is matrix-pipe bound, not load bound.
+// Split-K writes per-split slabs into the caller's workspace; a second kernel reduces them in a
+// fixed order (deterministic, no atomics).
+//
+// Replaces (reference = stock torch ops): nn.Conv2d / nn.Upsample+conv3x3 / nn.Linear / torch.bmm
+// call sites of code/coco/attngan/model.py:35-55,364-380,598-611,664-680 and
+// GlobalAttention.py:46,66,100,118.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <algorithm>
+#include "../../include/mogan_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FastDiv { uint32_t d, mul, shr; };
+
+static FastDiv make_fd(uint32_t d) {
+    FastDiv f; f.d = d ? d : 1; f.mul = 0; f.shr = 0;
+    if (f.d > 1) {
+        uint32_t l = 0; while ((1u << l) < f.d) ++l;          // ceil(log2 d)
+        uint32_t p = 31 + l;
+        f.mul = (uint32_t)(((1ull << p) + f.d - 1) / f.d);
+        f.shr = p - 32;
+    }
+    return f;
+}
+// exact for 0 <= n < 2^31
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+}
+
+enum { CONV_FWD = 0, CONV_DGRAD = 1, CONV_WGRAD = 2, BMM = 3 };
+
+struct GemmP {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    int kchunk, nsplit;
+    long long slab;         // elements per split slab (workspace) when nsplit > 1
+    float* ws;
+    int accumulate;         // direct (nsplit==1) store adds to C
+    // conv geometry: H,W = conv-input dims (after the optional fused upsample), Hs,Ws = stored dims
+    int Bn, Cin, Cout, H, W, Hs, Ws, OH, OW, KH, KW, s, ph, pw, up;
+    FastDiv fd_ohw, fd_ow, fd_khw, fd_kw, fd_nk, fd_nkw;
+    int nkh, nkw;           // dgrad taps per parity class (max over classes)
+    // bmm strides (elements)
+    long long sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn;
+    int a_lane_k, b_lane_n;
+};
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32;
+    constexpr int LDA = BK + 1, LDB = BN + 1;
+    constexpr int NA = BM * BK / 256, NB = BK * BN / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    __shared__ float As[BM * LDA];
+    __shared__ float Bs[BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int zb = blockIdx.z / p.nsplit, sp = blockIdx.z % p.nsplit;
+    const int kbeg = sp * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    const float* __restrict__ Ag = p.A;
+    const float* __restrict__ Bg = p.B;
+    const int OHW = p.OH * p.OW, HsWs = p.Hs * p.Ws, KHW = p.KH * p.KW;
+
+    // ---- per-thread, tile-invariant decode of the column/row this thread stages -------------
+    // FWD/DGRAD: the thread stages one fixed n (lanes run along n); WGRAD/BMM see below.
+    int Ncls = p.N;                 // DGRAD: columns of this parity class
+    int py = 0, px = 0, Hc = 0, Wc = 0, kh0 = 0, kw0 = 0;
+    bool nvalid = false; int nb_base = 0, niy0 = 0, nix0 = 0;   // FWD
+    int dg_img = 0, dg_oyb = 0, dg_oxb = 0;                      // DGRAD
+    if constexpr (MODE == CONV_DGRAD) {
+        py = zb / p.s; px = zb % p.s;
+        Hc = (p.H - py + p.s - 1) / p.s; Wc = (p.W - px + p.s - 1) / p.s;
+        Ncls = p.Bn * Hc * Wc;
+        if (n0 >= Ncls) return;     // block-uniform
+        kh0 = (py + p.ph) % p.s; kw0 = (px + p.pw) % p.s;
+    }
+    if constexpr (MODE == CONV_FWD) {
+        const int n = n0 + (tid % BN);
+        nvalid = n < p.N;
+        const int nn = nvalid ? n : 0;
+        const int img = nn / OHW, pix = nn - img * OHW;
+        const int oy = pix / p.OW, ox = pix - oy * p.OW;
+        niy0 = oy * p.s - p.ph; nix0 = ox * p.s - p.pw;
+        nb_base = img * p.Cin * HsWs;
+    }
+    if constexpr (MODE == CONV_DGRAD) {
+        const int n = n0 + (tid % BN);
+        nvalid = n < Ncls;
+        const int nn = nvalid ? n : 0;
+        const int hw = Hc * Wc;
+        const int img = nn / hw, rem = nn - img * hw;
+        const int yc = rem / Wc, xc = rem - yc * Wc;
+        dg_img = img;
+        dg_oyb = (yc * p.s + py + p.ph - kh0) / p.s;      // exact
+        dg_oxb = (xc * p.s + px + p.pw - kw0) / p.s;
+    }
+
+    float ra[NA], rb[NB];
+
+    auto load_tile = [&](int kt) {
+        // ------------------------------------------------ A tile -> ra
+        if constexpr (MODE == CONV_FWD) {
+            const int k = kt + (tid & 31);
+            const bool kok = k < kend;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = m0 + (tid >> 5) + 8 * i;
+                ra[i] = (kok && m < p.M) ? Ag[(size_t)m * p.K + k] : 0.f;
+            }
+        } else if constexpr (MODE == CONV_DGRAD) {
+            // A[m=ci][k=(co,khp,kwp)] = W[co][ci][kh0+khp*s][kw0+kwp*s]; lanes run along ci
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e = tid + 256 * i;
+                const int m = m0 + (e % BM);
+                const bool mok = m < p.M;
+                const int k = kt + e / BM;
+                const uint32_t co = fdiv(k, p.fd_nk);
+                const uint32_t r = k - co * (p.nkh * p.nkw);
+                const uint32_t khp = fdiv(r, p.fd_nkw), kwp = r - khp * p.nkw;
+                const int kh = kh0 + khp * p.s, kw = kw0 + kwp * p.s;
+                const bool ok = mok && k < kend && kh < p.KH && kw < p.KW;
+                ra[i] = ok ? Ag[((size_t)co * p.Cin + m) * KHW + kh * p.KW + kw] : 0.f;
+            }
+        } else if constexpr (MODE == CONV_WGRAD) {
+            const int k = kt + (tid & 31);
+            const bool kok = k < kend;
+            const uint32_t kk = kok ? k : 0;
+            const uint32_t img = fdiv(kk, p.fd_ohw), pix = kk - img * OHW;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = m0 + (tid >> 5) + 8 * i;
+                ra[i] = (kok && m < p.M) ? Ag[((size_t)img * p.Cout + m) * OHW + pix] : 0.f;
+            }
+        } else {
+            const float* Ab = Ag + (size_t)zb * p.sAb;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e = tid + 256 * i;
+                const int ml = p.a_lane_k ? (e >> 5) : (e % BM);
+                const int kl = p.a_lane_k ? (e & 31) : (e / BM);
+                const int m = m0 + ml, k = kt + kl;
+                ra[i] = (m < p.M && k < kend) ? Ab[(size_t)m * p.sAm + (size_t)k * p.sAk] : 0.f;
+            }
+        }
+        // ------------------------------------------------ B tile -> rb
+        if constexpr (MODE == CONV_FWD) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = kt + tid / BN + (256 / BN) * i;
+                const uint32_t ci = fdiv(k, p.fd_khw);
+                const uint32_t r = k - ci * KHW;
+                const uint32_t kh = fdiv(r, p.fd_kw), kw = r - kh * p.KW;
+                const int iy = niy0 + (int)kh, ix = nix0 + (int)kw;
+                const bool ok = nvalid && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[i] = ok ? Bg[(size_t)nb_base + (size_t)ci * HsWs + (iy >> p.up) * p.Ws + (ix >> p.up)] : 0.f;
+            }
+        } else if constexpr (MODE == CONV_DGRAD) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = kt + tid / BN + (256 / BN) * i;
+                const uint32_t co = fdiv(k, p.fd_nk);
+                const uint32_t r = k - co * (p.nkh * p.nkw);
+                const uint32_t khp = fdiv(r, p.fd_nkw), kwp = r - khp * p.nkw;
+                const int kh = kh0 + khp * p.s, kw = kw0 + kwp * p.s;
+                const int oy = dg_oyb - (int)khp, ox = dg_oxb - (int)kwp;
+                const bool ok = nvalid && k < kend && kh < p.KH && kw < p.KW &&
+                                (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
+                rb[i] = ok ? Bg[(((size_t)dg_img * p.Cout + co) * p.OH + oy) * p.OW + ox] : 0.f;
+            }
+        } else if constexpr (MODE == CONV_WGRAD) {
+            // B[k=(img,oy,ox)][n=(ci,kh,kw)]; lanes run along k (pixels)
+            const int k = kt + (tid & 31);
+            const bool kok = k < kend;
+            const uint32_t kk = kok ? k : 0;
+            const uint32_t img = fdiv(kk, p.fd_ohw), pix = kk - img * OHW;
+            const uint32_t oy = fdiv(pix, p.fd_ow), ox = pix - oy * p.OW;
+            const int iy0 = (int)oy * p.s - p.ph, ix0 = (int)ox * p.s - p.pw;
+            const size_t xb = (size_t)img * p.Cin * HsWs;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + (tid >> 5) + 8 * i;
+                const uint32_t ci = fdiv(n, p.fd_khw);
+                const uint32_t r = n - ci * KHW;
+                const uint32_t kh = fdiv(r, p.fd_kw), kw = r - kh * p.KW;
+                const int iy = iy0 + (int)kh, ix = ix0 + (int)kw;
+                const bool ok = kok && n < p.N && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[i] = ok ? Bg[xb + (size_t)ci * HsWs + (iy >> p.up) * p.Ws + (ix >> p.up)] : 0.f;
+            }
+        } else {
+            const float* Bb = Bg + (size_t)zb * p.sBb;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = tid + 256 * i;
+                const int nl = p.b_lane_n ? (e % BN) : (e >> 5);
+                const int kl = p.b_lane_n ? (e / BN) : (e & 31);
+                const int n = n0 + nl, k = kt + kl;
+                rb[i] = (n < p.N && k < kend) ? Bb[(size_t)k * p.sBk + (size_t)n * p.sBn] : 0.f;
+            }
+        }
+    };
+
+    auto store_tile = [&]() {
+        if constexpr (MODE == CONV_FWD || MODE == CONV_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) As[((tid >> 5) + 8 * i) * LDA + (tid & 31)] = ra[i];
+        } else if constexpr (MODE == CONV_DGRAD) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { const int e = tid + 256 * i; As[(e % BM) * LDA + e / BM] = ra[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e = tid + 256 * i;
+                const int ml = p.a_lane_k ? (e >> 5) : (e % BM);
+                const int kl = p.a_lane_k ? (e & 31) : (e / BM);
+                As[ml * LDA + kl] = ra[i];
+            }
+        }
+        if constexpr (MODE == CONV_FWD || MODE == CONV_DGRAD) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) Bs[(tid / BN + (256 / BN) * i) * LDB + (tid % BN)] = rb[i];
+        } else if constexpr (MODE == CONV_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) Bs[(tid & 31) * LDB + (tid >> 5) + 8 * i] = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = tid + 256 * i;
+                const int nl = p.b_lane_n ? (e % BN) : (e >> 5);
+                const int kl = p.b_lane_n ? (e / BN) : (e & 31);
+                Bs[kl * LDB + nl] = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int arow = (wm * TM * 32 + (lane & 31)) * LDA + (lane >> 5);
+    const int bcol = (lane >> 5) * LDB + wn * TN * 32 + (lane & 31);
+
+    if (kbeg < kend) {
+        load_tile(kbeg);
+        store_tile();
+        __syncthreads();
+        for (int kt = kbeg; kt < kend; kt += BK) {
+            const bool more = kt + BK < kend;
+            if (more) load_tile(kt + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) a[t] = As[arow + t * 32 * LDA + kk * 2];
+#pragma unroll
+                for (int t = 0; t < TN; ++t) b[t] = Bs[bcol + kk * 2 * LDB + t * 32];
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TN; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) { store_tile(); __syncthreads(); }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    float* __restrict__ Cg = (p.nsplit > 1) ? (p.ws + (size_t)sp * p.slab) : p.C;
+    const bool addc = (p.nsplit == 1) && p.accumulate;
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int n = n0 + wn * TN * 32 + tb * 32 + (lane & 31);
+        size_t cbase = 0, cms = 0; bool nok;
+        if constexpr (MODE == CONV_FWD) {
+            nok = n < p.N;
+            const int nn = nok ? n : 0;
+            const int img = nn / OHW, pix = nn - img * OHW;
+            cbase = (size_t)img * p.M * OHW + pix; cms = OHW;
+        } else if constexpr (MODE == CONV_DGRAD) {
+            nok = n < Ncls;
+            const int nn = nok ? n : 0;
+            const int hw = Hc * Wc;
+            const int img = nn / hw, rem = nn - img * hw;
+            const int yc = rem / Wc, xc = rem - yc * Wc;
+            cms = (size_t)p.H * p.W;
+            cbase = (size_t)img * p.M * cms + (size_t)(yc * p.s + py) * p.W + (xc * p.s + px);
+        } else if constexpr (MODE == CONV_WGRAD) {
+            nok = n < p.N; cbase = n; cms = p.N;
+        } else {
+            nok = n < p.N; cbase = (size_t)zb * p.sCb + (size_t)n * p.sCn; cms = p.sCm;
+        }
+#pragma unroll
+        for (int ta = 0; ta < TM; ++ta) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (nok && m < p.M) {
+                    float* dst = Cg + cbase + (size_t)m * cms;
+                    float v = acc[ta][tb][r];
+                    if (addc) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// out[i] = (acc ? out[i] : 0) + sum_s ws[s*slab + i], fixed order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                            long long n, long long slab, int nsplit, int acc) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 3 < n && (slab & 3) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)ws) & 15) == 0) {
+        float4 s = acc ? *(const float4*)(out + i4) : make_float4(0, 0, 0, 0);
+        for (int k = 0; k < nsplit; ++k) {
+            const float4 v = *(const float4*)(ws + (size_t)k * slab + i4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *(float4*)(out + i4) = s;
+    } else {
+        for (long long i = i4; i < n && i < i4 + 4; ++i) {
+            float s = acc ? out[i] : 0.f;
+            for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * slab + i];
+            out[i] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host dispatch
+struct Cfg { int wm, wn, tm, tn; };
+static const Cfg kCfgs[] = {{2, 2, 2, 2}, {1, 4, 3, 1}, {4, 1, 1, 1}, {1, 4, 1, 1}, {2, 2, 1, 1}};
+enum { NCFG = 5 };
+
+template <int MODE>
+static void launch_cfg(int c, dim3 grid, hipStream_t st, const GemmP& p) {
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 2, 2>), grid, dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 3, 1>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<MODE, 4, 1, 1, 1>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 1, 1>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 1, 1>), grid, dim3(256), 0, st, p); break;
+    }
+}
+
+static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+static int g_force_cfg = -1, g_force_split = 0;
+
+// Tile config: least padded MFMA work; ties -> larger tile.  Split-K: fill >= 2 waves of 256 CUs
+// when the tile grid alone cannot, keeping >= 128 of K per split.
+static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0) return 0;
+    int best = 0; double bestw = 1e300;
+    for (int c = 0; c < NCFG; ++c) {
+        const int bm = kCfgs[c].wm * kCfgs[c].tm * 32, bn = kCfgs[c].wn * kCfgs[c].tn * 32;
+        double w = (double)cdiv(p.M, bm) * bm * (double)cdiv(p.N, bn) * bn;
+        w *= (bm * bn >= 96 * 128) ? 1.0 : (bm * bn >= 64 * 64 ? 1.08 : 1.15);   // small tiles: less reuse
+        if (w < bestw * 0.999) { bestw = w; best = c; }
+    }
+    if (g_force_cfg >= 0) best = g_force_cfg;
+    const int bm = kCfgs[best].wm * kCfgs[best].tm * 32, bn = kCfgs[best].wn * kCfgs[best].tn * 32;
+    const long long tiles = cdiv(p.M, bm) * cdiv(p.N, bn) * nz;
+    int nsplit = 1;
+    const int ktiles = (int)cdiv(p.K, 32);
+    if (tiles < 512 && ktiles >= 8) {
+        nsplit = (int)cdiv(768, tiles);
+        nsplit = (int)std::min<long long>(nsplit, ktiles / 4);
+        if (nsplit < 1) nsplit = 1;
+    }
+    if (g_force_split > 0) nsplit = std::min(g_force_split, ktiles);
+    if (nsplit > 1) {
+        const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)c_numel)) : 0;
+        if (fit < 2) nsplit = 1; else nsplit = (int)std::min<long long>(nsplit, fit);
+    }
+    int kt_per = (int)cdiv(ktiles, nsplit);
+    nsplit = (int)cdiv(ktiles, kt_per);
+    p.kchunk = kt_per * 32; p.nsplit = nsplit; p.slab = c_numel; p.ws = (float*)ws;
+    if (p.K <= 0) { p.kchunk = 32; p.nsplit = 1; }
+    dim3 grid((unsigned)cdiv(p.N, bn), (unsigned)cdiv(p.M, bm), (unsigned)(nz * p.nsplit));
+    if (grid.y > 65535 || grid.z > 65535) return MOGAN_ERR_SHAPE;
+    switch (mode) {
+        case CONV_FWD: launch_cfg<CONV_FWD>(best, grid, st, p); break;
+        case CONV_DGRAD: launch_cfg<CONV_DGRAD>(best, grid, st, p); break;
+        case CONV_WGRAD: launch_cfg<CONV_WGRAD>(best, grid, st, p); break;
+        default: launch_cfg<BMM>(best, grid, st, p); break;
+    }
+    if (p.nsplit > 1) {
+        const long long nblk = cdiv(cdiv(c_numel, 4), 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)ws, p.C,
+                           c_numel, c_numel, p.nsplit, p.accumulate);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+static int conv_geom(GemmP& p, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int s, int ph, int pw, int up) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Hs <= 0 || Ws <= 0 || KH <= 0 || KW <= 0 || s <= 0 || up < 0 || up > 1)
+        return MOGAN_ERR_SHAPE;
+    p.Bn = B; p.Cin = Cin; p.Cout = Cout; p.Hs = Hs; p.Ws = Ws; p.up = up;
+    p.H = Hs << up; p.W = Ws << up; p.KH = KH; p.KW = KW; p.s = s; p.ph = ph; p.pw = pw;
+    p.OH = (p.H + 2 * ph - KH) / s + 1; p.OW = (p.W + 2 * pw - KW) / s + 1;
+    if (p.OH <= 0 || p.OW <= 0) return MOGAN_ERR_SHAPE;
+    p.fd_ohw = make_fd(p.OH * p.OW); p.fd_ow = make_fd(p.OW);
+    p.fd_khw = make_fd(KH * KW); p.fd_kw = make_fd(KW);
+    p.nkh = (KH + s - 1) / s; p.nkw = (KW + s - 1) / s;
+    p.fd_nk = make_fd(p.nkh * p.nkw); p.fd_nkw = make_fd(p.nkw);
+    if ((long long)B * Cin * p.H * p.W >= (1ll << 31) || (long long)B * Cout * p.OH * p.OW >= (1ll << 31))
+        return MOGAN_ERR_SHAPE;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mogan_gemm_debug_force(int cfg, int split) { g_force_cfg = cfg; g_force_split = split; return 0; }
+
+int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, int pw, int up, int* OH, int* OW) {
+    if (stride <= 0) return MOGAN_ERR_SHAPE;
+    *OH = ((Hs << up) + 2 * ph - KH) / stride + 1;
+    *OW = ((Ws << up) + 2 * pw - KW) / stride + 1;
+    return 0;
+}
+
+int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                     int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
+    GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
+    return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
+}
+
+int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                       int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
+    GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    // dx is the gradient w.r.t. the conv input in the (upsampled) H x W domain: (B,Cin,H,W)
+    p.A = w; p.B = dy; p.C = dx; p.M = Cin; p.K = Cout * p.nkh * p.nkw; p.accumulate = 0;
+    const int Hc = (p.H + stride - 1) / stride, Wc = (p.W + stride - 1) / stride;
+    p.N = B * Hc * Wc;   // class (0,0) has the most columns
+    return run_gemm(CONV_DGRAD, p, stride * stride, (long long)B * Cin * p.H * p.W, ws, ws_bytes, stream);
+}
+
+int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                       int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
+                       hipStream_t stream) {
+    GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    p.A = dy; p.B = x; p.C = dw; p.M = Cout; p.N = Cin * KH * KW; p.K = B * p.OH * p.OW; p.accumulate = accumulate;
+    return run_gemm(CONV_WGRAD, p, 1, (long long)Cout * Cin * KH * KW, ws, ws_bytes, stream);
+}
+
+int mogan_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, long long sAb, long long sAm,
+              long long sAk, long long sBb, long long sBk, long long sBn, long long sCb, long long sCm, long long sCn,
+              int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (batch <= 0 || M < 0 || N < 0 || K < 0) return MOGAN_ERR_SHAPE;
+    GemmP p{};
+    p.A = a; p.B = b; p.C = c; p.M = M; p.N = N; p.K = K; p.accumulate = accumulate;
+    p.sAb = sAb; p.sAm = sAm; p.sAk = sAk; p.sBb = sBb; p.sBk = sBk; p.sBn = sBn; p.sCb = sCb; p.sCm = sCm; p.sCn = sCn;
+    p.a_lane_k = (sAk <= sAm); p.b_lane_n = (sBn <= sBk);
+    p.OH = p.OW = p.Hs = p.Ws = p.KH = p.KW = p.s = 1;
+    // split-K slabs are addressed like C: only allowed when C is dense (batch,M,N) row-major
+    const bool dense = (sCn == 1 && sCm == N && (batch == 1 || sCb == (long long)M * N));
+    return run_gemm(BMM, p, batch, (long long)batch * M * N, dense ? ws : nullptr, dense ? ws_bytes : 0, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,438 @@
+// mogan_norm.hip -- BatchNorm (training statistics) fused with GLU / LeakyReLU / ReLU / residual-add,
+// forward and backward, plus the eval-mode per-channel affine used by the frozen Inception trunk.
+//
+// All of it is HBM-bound.  Layout x (B,C,HW), NCHW.  Kernels:
+//   bn_partial   grid (C, YS): one block reduces a (batch-range x HW-range) slab of one channel with
+//                float4 loads and fp64 accumulators (E[x^2]-mean^2 is then safe), wave64 shuffle
+//                reduction, one (sum,sumsq) pair per block into the workspace;
+//   bn_finalize  one wave per channel: fixed-order sum of the partials -> mean, invstd, running stats;
+//   bn_act_fwd   y = act(gamma*xhat+beta) (+res): one pass, float4;  GLU reads channel c and c+C/2;
+//   bn_bwd_partial / bn_bwd_finalize / bn_bwd_apply: the two-reduction BN backward with the activation
+//                backward recomputed from x (nothing but x, mean, invstd is saved by the forward).
+// Replaces nn.BatchNorm1d/2d + GLU / nn.LeakyReLU / nn.ReLU at code/coco/attngan/model.py:48-81,
+// 96-101,364-373,575-611,667-680.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mogan_hip.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block (256 threads) reduction of NV doubles; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sh /* [4*NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sh[wave * NV + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = sh[i] + sh[NV + i] + sh[2 * NV + i] + sh[3 * NV + i];
+}
+
+struct Split { int bs, hs, bper, hper; };   // YS = bs*hs blocks per channel
+
+static Split make_split(int B, int C, int HW) {
+    Split s;
+    long long want = (1536 + C - 1) / C;                     // ~6 blocks per CU overall
+    if (want < 1) want = 1;
+    s.bs = (int)(want < B ? want : B);
+    long long rest = (want + s.bs - 1) / s.bs;
+    long long hmax = (HW + 2047) / 2048; if (hmax < 1) hmax = 1;
+    s.hs = (int)(rest < hmax ? rest : hmax);
+    s.bper = (B + s.bs - 1) / s.bs; s.bs = (B + s.bper - 1) / s.bper;
+    s.hper = (((HW + s.hs - 1) / s.hs) + 3) & ~3; s.hs = (HW + s.hper - 1) / s.hper;
+    return s;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// -------------------------------------------------------------------------------- forward stats
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int B, int C, int HW,
+                                                         Split sp, double* __restrict__ part) {
+    __shared__ double sh[8];
+    const int c = blockIdx.x, ys = blockIdx.y;
+    const int bi = ys / sp.hs, hi = ys % sp.hs;
+    const int b0 = bi * sp.bper, b1 = min(B, b0 + sp.bper);
+    const int h0 = hi * sp.hper, h1 = min(HW, h0 + sp.hper);
+    double acc[2] = {0.0, 0.0};
+    const bool vec = ((HW & 3) == 0);
+    for (int b = b0; b < b1; ++b) {
+        const float* px = x + ((size_t)b * C + c) * HW;
+        if (vec) {
+            for (int i = h0 + threadIdx.x * 4; i < h1; i += 1024) {
+                const float4 v = *(const float4*)(px + i);
+                acc[0] += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                acc[1] += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            }
+        } else {
+            for (int i = h0 + threadIdx.x; i < h1; i += 256) {
+                const double v = px[i];
+                acc[0] += v; acc[1] += v * v;
+            }
+        }
+    }
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) {
+        part[((size_t)c * gridDim.y + ys) * 2 + 0] = acc[0];
+        part[((size_t)c * gridDim.y + ys) * 2 + 1] = acc[1];
+    }
+}
+
+// HW == 1 (BatchNorm1d on (B,C)): one thread per channel, coalesced across channels
+__global__ __launch_bounds__(256) void bn1d_partial_kernel(const float* __restrict__ x, int B, int C,
+                                                           double* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int b = 0; b < B; ++b) { const double v = x[(size_t)b * C + c]; s += v; q += v * v; }
+    part[(size_t)c * 2] = s; part[(size_t)c * 2 + 1] = q;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int C, int YS, double n,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ invstd, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int y = 0; y < YS; ++y) { s += part[((size_t)c * YS + y) * 2]; q += part[((size_t)c * YS + y) * 2 + 1]; }
+    const double m = s / n;
+    double var = q / n - m * m; if (var < 0) var = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unb = n > 1 ? var * n / (n - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// -------------------------------------------------------------------------------- forward apply
+template <int ACT, bool VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ res, float* __restrict__ y, int C,
+                                                         int HW, float slope) {
+    constexpr int W = VEC ? 4 : 1;
+    constexpr int WA = 4;
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.y % Cy, b = blockIdx.y / Cy;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * W;
+    if (i >= HW) return;
+    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    const float* px = x + ((size_t)b * C + c) * HW + i;
+    float v[WA], o[WA];
+    if (VEC) { const float4 t = *(const float4*)px; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else v[0] = *px;
+    if (ACT == MOGAN_ACT_GLU) {
+        const int cg = c + Cy;
+        const float sc2 = gamma[cg] * invstd[cg], sh2 = beta[cg] - mean[cg] * sc2;
+        float g[WA];
+        if (VEC) { const float4 t = *(const float4*)(px + (size_t)Cy * HW); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
+        else g[0] = px[(size_t)Cy * HW];
+#pragma unroll
+        for (int k = 0; k < W; ++k) o[k] = (v[k] * sc + sh) * sigmoidf_(g[k] * sc2 + sh2);
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            float t = v[k] * sc + sh;
+            if (ACT == MOGAN_ACT_RELU) t = t > 0.f ? t : 0.f;
+            if (ACT == MOGAN_ACT_LRELU) t = t > 0.f ? t : t * slope;
+            o[k] = t;
+        }
+    }
+    float* py = y + ((size_t)b * Cy + c) * HW + i;
+    if (res) {
+        const float* pr = res + ((size_t)b * Cy + c) * HW + i;
+        if (VEC) { const float4 t = *(const float4*)pr; o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
+        else o[0] += *pr;
+    }
+    if (VEC) *(float4*)py = make_float4(o[0], o[1], o[2], o[3]); else *py = o[0];
+}
+
+// -------------------------------------------------------------------------------- backward
+// dy_bn (gradient at the BN output) from dy (gradient at the activation output), recomputing the BN output.
+// Non-GLU: channel c.  GLU: pair (c, c+Cy): a = bn_c, g = bn_{c+Cy}; y = a*sig(g).
+template <int ACT>
+__device__ __forceinline__ void act_bwd(float xa, float xg, float dyv, float sc, float sh, float sc2, float sh2,
+                                        float slope, float& da, float& dg, float& xha_scaled_dummy) {
+    (void)xha_scaled_dummy;
+    if (ACT == MOGAN_ACT_GLU) {
+        const float a = xa * sc + sh, s = sigmoidf_(xg * sc2 + sh2);
+        da = dyv * s; dg = dyv * a * s * (1.f - s);
+    } else {
+        const float t = xa * sc + sh;
+        if (ACT == MOGAN_ACT_RELU) da = t > 0.f ? dyv : 0.f;
+        else if (ACT == MOGAN_ACT_LRELU) da = t > 0.f ? dyv : dyv * slope;
+        else da = dyv;
+        dg = 0.f;
+    }
+}
+
+// partial sums per (channel, ys): [sum dy_a, sum dy_a*xhat_a, sum dy_g, sum dy_g*xhat_g]
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int B, int C, int HW,
+                                                             Split sp, float slope, double* __restrict__ part) {
+    __shared__ double sh_[16];
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.x, ys = blockIdx.y;          // c in [0, Cy)
+    const int bi = ys / sp.hs, hi = ys % sp.hs;
+    const int b0 = bi * sp.bper, b1 = min(B, b0 + sp.bper);
+    const int h0 = hi * sp.hper, h1 = min(HW, h0 + sp.hper);
+    const float mu = mean[c], is = invstd[c];
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+    float mu2 = 0, is2 = 0, sc2 = 0, sh2 = 0;
+    if (ACT == MOGAN_ACT_GLU) { mu2 = mean[c + Cy]; is2 = invstd[c + Cy]; sc2 = gamma[c + Cy] * is2; sh2 = beta[c + Cy] - mu2 * sc2; }
+    double acc[4] = {0, 0, 0, 0};
+    float dummy = 0;
+    for (int b = b0; b < b1; ++b) {
+        const float* pxa = x + ((size_t)b * C + c) * HW;
+        const float* pxg = pxa + (size_t)Cy * HW;
+        const float* pdy = dy + ((size_t)b * Cy + c) * HW;
+        for (int i = h0 + threadIdx.x; i < h1; i += 256) {
+            const float xa = pxa[i], xg = (ACT == MOGAN_ACT_GLU) ? pxg[i] : 0.f;
+            float da, dg;
+            act_bwd<ACT>(xa, xg, pdy[i], sc, sh, sc2, sh2, slope, da, dg, dummy);
+            acc[0] += da; acc[1] += (double)da * ((xa - mu) * is);
+            if (ACT == MOGAN_ACT_GLU) { acc[2] += dg; acc[3] += (double)dg * ((xg - mu2) * is2); }
+        }
+    }
+    block_sum<4>(acc, sh_);
+    if (threadIdx.x == 0) {
+        double* o = part + ((size_t)c * gridDim.y + ys) * 4;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+}
+
+// -> sums[C][2] = (sum dy_bn, sum dy_bn*xhat) as float, dgamma/dbeta
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int YS,
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cy) return;
+    double a[4] = {0, 0, 0, 0};
+    for (int y = 0; y < YS; ++y)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += part[((size_t)c * YS + y) * 4 + k];
+    sums[c * 2] = (float)a[0]; sums[c * 2 + 1] = (float)a[1];
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a[0];
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a[1];
+    if (ACT == MOGAN_ACT_GLU) {
+        const int cg = c + Cy;
+        sums[cg * 2] = (float)a[2]; sums[cg * 2 + 1] = (float)a[3];
+        if (dbeta) dbeta[cg] = (accumulate ? dbeta[cg] : 0.f) + (float)a[2];
+        if (dgamma) dgamma[cg] = (accumulate ? dgamma[cg] : 0.f) + (float)a[3];
+    }
+}
+
+// dx = gamma*invstd * (dy_bn - sum_dy/n - xhat * sum_dyxhat/n)
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ sums, float* __restrict__ dx, int C,
+                                                           int HW, float slope, float inv_n) {
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.y % Cy, b = blockIdx.y / Cy;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float mu = mean[c], is = invstd[c];
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+    float mu2 = 0, is2 = 0, sc2 = 0, sh2 = 0;
+    if (ACT == MOGAN_ACT_GLU) { mu2 = mean[c + Cy]; is2 = invstd[c + Cy]; sc2 = gamma[c + Cy] * is2; sh2 = beta[c + Cy] - mu2 * sc2; }
+    const size_t ia = ((size_t)b * C + c) * HW + i, ig = ia + (size_t)Cy * HW;
+    const float xa = x[ia], xg = (ACT == MOGAN_ACT_GLU) ? x[ig] : 0.f;
+    float da, dg, dummy = 0;
+    act_bwd<ACT>(xa, xg, dy[((size_t)b * Cy + c) * HW + i], sc, sh, sc2, sh2, slope, da, dg, dummy);
+    dx[ia] = sc * (da - sums[c * 2] * inv_n - (xa - mu) * is * sums[c * 2 + 1] * inv_n);
+    if (ACT == MOGAN_ACT_GLU) {
+        const int cg = c + Cy;
+        dx[ig] = sc2 * (dg - sums[cg * 2] * inv_n - (xg - mu2) * is2 * sums[cg * 2 + 1] * inv_n);
+    }
+}
+
+// -------------------------------------------------------------------------------- eval affine
+template <int ACT, bool BWD>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ out, int C,
+                                                         int HW, float slope) {
+    const int c = blockIdx.y % C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const size_t idx = (size_t)blockIdx.y * HW + i;
+    const float sc = scale[c], t = x[idx] * sc + shift[c];
+    if (!BWD) {
+        float o = t;
+        if (ACT == MOGAN_ACT_RELU) o = t > 0.f ? t : 0.f;
+        if (ACT == MOGAN_ACT_LRELU) o = t > 0.f ? t : t * slope;
+        out[idx] = o;
+    } else {
+        float d = dy[idx];
+        if (ACT == MOGAN_ACT_RELU) d = t > 0.f ? d : 0.f;
+        if (ACT == MOGAN_ACT_LRELU) d = t > 0.f ? d : d * slope;
+        out[idx] = d * sc;
+    }
+}
+
+static inline int ok_launch() { return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH; }
+
+template <int ACT>
+static int bn_bwd_impl(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, float slope,
+                       int accumulate, void* ws, hipStream_t stream) {
+    const int Cy = ACT == MOGAN_ACT_GLU ? C / 2 : C;
+    Split s = make_split(B, C, HW);
+    const int YS = s.bs * s.hs;
+    double* part = (double*)ws;
+    float* sums = (float*)((char*)ws + (size_t)C * YS * 4 * sizeof(double));
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<ACT>), dim3(Cy, YS), dim3(256), 0, stream, x, dy, mean, invstd, gamma,
+                       beta, B, C, HW, s, slope, part);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<ACT>), dim3((Cy + 255) / 256), dim3(256), 0, stream,
+                       (const double*)part, C, YS, sums, dgamma, dbeta, accumulate);
+    const float inv_n = 1.f / ((float)B * (float)HW);
+    const int bchunk = 65535 / Cy;
+    if (bchunk < 1) return MOGAN_ERR_SHAPE;
+    for (int b0 = 0; b0 < B; b0 += bchunk) {
+        const int nb = B - b0 < bchunk ? B - b0 : bchunk;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT>), dim3((HW + 255) / 256, nb * Cy), dim3(256), 0, stream,
+                           x + (size_t)b0 * C * HW, dy + (size_t)b0 * Cy * HW, mean, invstd, gamma, beta,
+                           (const float*)sums, dx + (size_t)b0 * C * HW, C, HW, slope, inv_n);
+    }
+    return ok_launch();
+}
+
+template <bool BWD>
+static int affine_impl(const float* x, const float* dy, const float* scale, const float* shift, float* out, int B,
+                       int C, int HW, int act, float slope, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    const int bchunk = 65535 / C;
+    if (bchunk < 1) return MOGAN_ERR_SHAPE;
+    for (int b0 = 0; b0 < B; b0 += bchunk) {
+        const int nb = B - b0 < bchunk ? B - b0 : bchunk;
+        dim3 grid((HW + 255) / 256, nb * C);
+        const size_t off = (size_t)b0 * C * HW;
+        const float* pdy = dy ? dy + off : nullptr;
+        switch (act) {
+            case MOGAN_ACT_NONE: hipLaunchKernelGGL((affine_act_kernel<MOGAN_ACT_NONE, BWD>), grid, dim3(256), 0, stream, x + off, pdy, scale, shift, out + off, C, HW, slope); break;
+            case MOGAN_ACT_RELU: hipLaunchKernelGGL((affine_act_kernel<MOGAN_ACT_RELU, BWD>), grid, dim3(256), 0, stream, x + off, pdy, scale, shift, out + off, C, HW, slope); break;
+            case MOGAN_ACT_LRELU: hipLaunchKernelGGL((affine_act_kernel<MOGAN_ACT_LRELU, BWD>), grid, dim3(256), 0, stream, x + off, pdy, scale, shift, out + off, C, HW, slope); break;
+            default: return MOGAN_ERR_SHAPE;
+        }
+    }
+    return ok_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mogan_bn_ws_bytes(int B, int C, int HW) {
+    if (B <= 0 || C <= 0 || HW <= 0) return 0;
+    const Split s = make_split(B, C, HW);
+    return (size_t)C * s.bs * s.hs * 4 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 64;
+}
+
+int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float momentum, float* mean, float* invstd,
+                   float* running_mean, float* running_var, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    if (!ws || ws_bytes < mogan_bn_ws_bytes(B, C, HW)) return MOGAN_ERR_WS;
+    double* part = (double*)ws;
+    int YS = 1;
+    if (HW == 1) {
+        hipLaunchKernelGGL(bn1d_partial_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, x, B, C, part);
+    } else {
+        const Split s = make_split(B, C, HW);
+        YS = s.bs * s.hs;
+        if (YS > 65535) return MOGAN_ERR_SHAPE;
+        hipLaunchKernelGGL(bn_partial_kernel, dim3(C, YS), dim3(256), 0, stream, x, B, C, HW, s, part);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)part, C, YS,
+                       (double)B * HW, eps, momentum, mean, invstd, running_mean, running_var);
+    return ok_launch();
+}
+
+#define MOGAN_FWD_CASE(A)                                                                                           \
+    case A:                                                                                                         \
+        if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<A, true>), grid, dim3(256), 0, stream, x, mean, invstd,      \
+                                    gamma, beta, residual, y, C, HW, slope);                                        \
+        else hipLaunchKernelGGL((bn_act_fwd_kernel<A, false>), grid, dim3(256), 0, stream, x, mean, invstd, gamma,  \
+                                beta, residual, y, C, HW, slope);                                                   \
+        break;
+
+int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const float* residual, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0 || (act == MOGAN_ACT_GLU && (C & 1))) return MOGAN_ERR_SHAPE;
+    const int Cy = act == MOGAN_ACT_GLU ? C / 2 : C;
+    const bool vec = (HW & 3) == 0;
+    if ((long long)B * Cy > 65535) {
+        // fold: gridDim.y limit -- loop over batch chunks
+        const int bchunk = 65535 / Cy;
+        if (bchunk < 1) return MOGAN_ERR_SHAPE;
+        for (int b0 = 0; b0 < B; b0 += bchunk) {
+            const int nb = B - b0 < bchunk ? B - b0 : bchunk;
+            int rc = mogan_bn_act_fwd(x + (size_t)b0 * C * HW, mean, invstd, gamma, beta,
+                                      residual ? residual + (size_t)b0 * Cy * HW : nullptr, y + (size_t)b0 * Cy * HW, nb,
+                                      C, HW, act, slope, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    const int per = vec ? 1024 : 256;
+    dim3 grid((HW + per - 1) / per, B * Cy);
+    switch (act) {
+        MOGAN_FWD_CASE(MOGAN_ACT_NONE)
+        MOGAN_FWD_CASE(MOGAN_ACT_RELU)
+        MOGAN_FWD_CASE(MOGAN_ACT_LRELU)
+        MOGAN_FWD_CASE(MOGAN_ACT_GLU)
+        default: return MOGAN_ERR_SHAPE;
+    }
+    return ok_launch();
+}
+
+int mogan_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, int act,
+                     float slope, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0 || (act == MOGAN_ACT_GLU && (C & 1))) return MOGAN_ERR_SHAPE;
+    if (!ws || ws_bytes < mogan_bn_ws_bytes(B, C, HW)) return MOGAN_ERR_WS;
+    {
+        const Split s = make_split(B, C, HW);
+        if (s.bs * s.hs > 65535) return MOGAN_ERR_SHAPE;
+    }
+    switch (act) {
+        case MOGAN_ACT_NONE: return bn_bwd_impl<MOGAN_ACT_NONE>(x, dy, mean, invstd, gamma, beta, dx, dgamma, dbeta, B, C, HW, slope, accumulate, ws, stream);
+        case MOGAN_ACT_RELU: return bn_bwd_impl<MOGAN_ACT_RELU>(x, dy, mean, invstd, gamma, beta, dx, dgamma, dbeta, B, C, HW, slope, accumulate, ws, stream);
+        case MOGAN_ACT_LRELU: return bn_bwd_impl<MOGAN_ACT_LRELU>(x, dy, mean, invstd, gamma, beta, dx, dgamma, dbeta, B, C, HW, slope, accumulate, ws, stream);
+        case MOGAN_ACT_GLU: return bn_bwd_impl<MOGAN_ACT_GLU>(x, dy, mean, invstd, gamma, beta, dx, dgamma, dbeta, B, C, HW, slope, accumulate, ws, stream);
+        default: return MOGAN_ERR_SHAPE;
+    }
+}
+
+int mogan_affine_act_fwd(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                         int act, float slope, hipStream_t stream) {
+    return affine_impl<false>(x, nullptr, scale, shift, y, B, C, HW, act, slope, stream);
+}
+int mogan_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float* dx, int B,
+                         int C, int HW, int act, float slope, hipStream_t stream) {
+    return affine_impl<true>(x, dy, scale, shift, dx, B, C, HW, act, slope, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""ctypes binding of libmogan_hip.so (include/mogan_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a call is made without a
+GPU tensor, this raises.  Importing the module is harmless on a CPU-only box (so that
+`__graft_entry__.build()` and the CPU test-suite can import the package); the library is opened
+on first use.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "libmogan_hip.so")
+
+P, I, F, L, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
+
+# name -> argtypes (all return int unless listed in _RESTYPE); mirrors include/mogan_hip.h
+SIGNATURES = {
+    "mogan_abi_version": [],
+    "mogan_gemm_debug_force": [I, I],
+    "mogan_conv2d_out_dims": [I, I, I, I, I, I, I, I, P, P],
+    "mogan_conv2d_fwd": [P, P, P] + [I] * 11 + [P, Z, P],
+    "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],
+    "mogan_conv2d_wgrad": [P, P, P] + [I] * 12 + [P, Z, P],
+    "mogan_down2_sum": [P, P, I, I, I, P],
+    "mogan_bmm": [P, P, P, I, I, I, I] + [L] * 9 + [I, P, Z, P],
+    "mogan_bn_ws_bytes": [I, I, I],
+    "mogan_bn_stats": [P, I, I, I, F, F, P, P, P, P, P, Z, P],
+    "mogan_bn_act_fwd": [P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "mogan_bn_act_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P, Z, P],
+    "mogan_affine_act_fwd": [P, P, P, P, I, I, I, I, F, P],
+    "mogan_affine_act_bwd": [P, P, P, P, P, I, I, I, I, F, P],
+    "mogan_act_fwd": [P, P, I, I, I, I, F, P],
+    "mogan_act_bwd": [P, P, P, I, I, I, I, F, P],
+    "mogan_bias_add": [P, P, I, I, I, P],
+    "mogan_bias_grad": [P, P, I, I, I, I, P],
+    "mogan_add": [P, P, P, L, P],
+    "mogan_scale": [P, F, P, L, P],
+    "mogan_softmax_fwd": [P, P, P, L, I, L, F, P],
+    "mogan_softmax_bwd": [P, P, P, P, L, I, L, F, P],
+    "mogan_stn_fwd": [P, P, P, I, I, I, I, I, I, I, P],
+    "mogan_stn_bwd": [P, P, P, I, I, I, I, I, I, I, P],
+    "mogan_bbox_to_theta": [P, P, P, I, P],
+    "mogan_attn_fwd": [P, P, P, P, P, I, I, I, I, I, P],
+    "mogan_attn_bwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "mogan_bce_fwd": [P, F, F, P, I, I, P],
+    "mogan_bce_bwd": [P, F, F, P, P, I, P],
+    "mogan_kl_fwd": [P, P, P, I, P],
+    "mogan_kl_bwd": [P, P, P, P, P, I, P],
+    "mogan_reparam_fwd": [P, P, P, P, I, P],
+    "mogan_reparam_bwd": [P, P, P, P, P, I, P],
+    "mogan_maxpool_fwd": [P, P, I, I, I, I, I, P],
+    "mogan_maxpool_bwd": [P, P, P, I, I, I, I, I, P],
+    "mogan_avgpool_fwd": [P, P, I, I, I, I, I, I, P],
+    "mogan_avgpool_bwd": [P, P, I, I, I, I, I, I, P],
+    "mogan_bilinear_fwd": [P, P, I, I, I, I, I, P],
+    "mogan_bilinear_bwd": [P, P, I, I, I, I, I, P],
+    "mogan_adam_step": [P, P, P, P, P, L, F, F, F, F, I, P, I, F, F, P],
+}
+_RESTYPE = {"mogan_bn_ws_bytes": Z}
+_ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
+
+_lib = None
+_ws = {}
+WORKSPACE_BYTES = int(os.environ.get("MOGAN_WS_MB", "256")) << 20
+
+
+class MoganHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Open libmogan_hip.so and type every entry point. Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise MoganHipError(
+                "libmogan_hip.so is not built (%s). Run `python __graft_entry__.py` / "
+                "`python multiple-objects-gan_amd/build.py`; there is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, I)
+        _lib = lib
+    return _lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(device):
+    """Persistent split-K / reduction scratch per (device, stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws.get(key)
+    if buf is None:
+        buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf.data_ptr(), buf.numel()
+
+
+def ptr(t):
+    """Device pointer of a dense fp32/uint8/int32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MoganHipError("mogan_hip ops need tensors on the GPU (got a %s tensor): "
+                            "there is no CPU path in the product" % t.device)
+    return t.data_ptr()
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise MoganHipError("%s failed: %s" % (name, _ERRORS.get(rc, rc)))
+
+
+def bn_ws_bytes(B, C, HW):
+    return int(load().mogan_bn_ws_bytes(B, C, HW))

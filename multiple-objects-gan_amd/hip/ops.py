@@ -1,0 +1,543 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mogan_hip.h).
+
+These are the ONLY callers of libmogan_hip.so.  PyTorch supplies device memory, streams and the
+autograd tape; all arithmetic on tensors happens inside the HIP kernels.  Every function raises
+(MoganHipError) if the library is missing or an input is not on the GPU -- there is no fallback.
+"""
+import torch
+
+from . import lib
+from .lib import call, ptr, stream_ptr, workspace
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GLU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+
+
+def _c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------- convolution
+def conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, up):
+    H, W = Hs << up, Ws << up
+    return (H + 2 * ph - KH) // stride + 1, (W + 2 * pw - KW) // stride + 1
+
+
+def conv2d_forward(x, w, stride, ph, pw, up):
+    B, Cin, Hs, Ws = x.shape
+    Cout, _, KH, KW = w.shape
+    OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, up)
+    y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    wsp, wsn = workspace(x.device)
+    call("mogan_conv2d_fwd", ptr(x), ptr(w), ptr(y), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
+         wsp, wsn, stream_ptr())
+    return y
+
+
+def conv2d_dgrad(dy, w, x_shape, stride, ph, pw, up):
+    B, Cin, Hs, Ws = x_shape
+    Cout, _, KH, KW = w.shape
+    wsp, wsn = workspace(dy.device)
+    du = torch.empty((B, Cin, Hs << up, Ws << up), dtype=torch.float32, device=dy.device)
+    call("mogan_conv2d_dgrad", ptr(dy), ptr(w), ptr(du), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
+         wsp, wsn, stream_ptr())
+    if not up:
+        return du
+    dx = torch.empty((B, Cin, Hs, Ws), dtype=torch.float32, device=dy.device)
+    call("mogan_down2_sum", ptr(du), ptr(dx), B * Cin, Hs, Ws, stream_ptr())
+    return dx
+
+
+def conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=None, accumulate=False):
+    B, Cin, Hs, Ws = x.shape
+    Cout, _, KH, KW = w_shape
+    wsp, wsn = workspace(dy.device)
+    dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=dy.device)
+    call("mogan_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
+         1 if accumulate else 0, wsp, wsn, stream_ptr())
+    return dw
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = conv2d(upsample2x?(x), w) (+ bias).  model.py:35-55,587,598-609,626,664-677."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, ph, pw, up):
+        x, w = _c(x), _c(w)
+        y = conv2d_forward(x, w, stride, ph, pw, up)
+        if bias is not None:
+            call("mogan_bias_add", ptr(y), ptr(_c(bias)), y.shape[0], y.shape[1], y.shape[2] * y.shape[3],
+                 stream_ptr())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, ph, pw, up, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, ph, pw, up, has_bias = ctx.geom
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(dy, w, x.shape, stride, ph, pw, up)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+            call("mogan_bias_grad", ptr(dy), ptr(db), dy.shape[0], dy.shape[1], dy.shape[2] * dy.shape[3], 0,
+                 stream_ptr())
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, padding=0, up=False):
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    return Conv2dFn.apply(x, w, bias, int(stride), int(ph), int(pw), 1 if up else 0)
+
+
+# ------------------------------------------------------------------------------- strided bmm / linear
+def bmm_raw(a, b, out, accumulate=False):
+    """out[z] (+)= a[z] @ b[z] for 3-D strided views (no copies)."""
+    Z_, M, K = a.shape
+    N = b.shape[2]
+    wsp, wsn = workspace(a.device)
+    call("mogan_bmm", ptr(a), ptr(b), ptr(out), Z_, M, N, K,
+         a.stride(0), a.stride(1), a.stride(2), b.stride(0), b.stride(1), b.stride(2),
+         out.stride(0), out.stride(1), out.stride(2), 1 if accumulate else 0, wsp, wsn, stream_ptr())
+    return out
+
+
+class BmmFn(torch.autograd.Function):
+    """(Z,M,K) x (Z,K,N) -> (Z,M,N); inputs may be arbitrary strided views (torch.bmm call sites of
+    GlobalAttention.py:46,66)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.float(), b.float()
+        out = torch.empty((a.shape[0], a.shape[1], b.shape[2]), dtype=torch.float32, device=a.device)
+        bmm_raw(a, b, out)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        dout = _c(dout)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+            bmm_raw(dout, b.transpose(1, 2), da)
+        if ctx.needs_input_grad[1]:
+            db = torch.empty(b.shape, dtype=torch.float32, device=a.device)
+            bmm_raw(a.transpose(1, 2), dout, db)
+        return da, db
+
+
+def bmm(a, b):
+    return BmmFn.apply(a, b)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ w.T (+ bias); nn.Linear at model.py:324,365,371."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w = _c(x), _c(w)
+        y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+        bmm_raw(x.unsqueeze(0), w.t().unsqueeze(0), y.unsqueeze(0))
+        if bias is not None:
+            call("mogan_bias_add", ptr(y), ptr(_c(bias)), y.shape[0], y.shape[1], 1, stream_ptr())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            bmm_raw(dy.unsqueeze(0), w.unsqueeze(0), dx.unsqueeze(0))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(w.shape, dtype=torch.float32, device=x.device)
+            bmm_raw(dy.t().unsqueeze(0), x.unsqueeze(0), dw.unsqueeze(0))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+            call("mogan_bias_grad", ptr(dy), ptr(db), dy.shape[0], dy.shape[1], 1, 0, stream_ptr())
+        return dx, dw, db
+
+
+def linear(x, w, bias=None):
+    return LinearFn.apply(x, w, bias)
+
+
+# ------------------------------------------------------------------------------- batch norm (+act)
+def _bchw(x):
+    if x.dim() == 2:
+        return x.shape[0], x.shape[1], 1
+    return x.shape[0], x.shape[1], x[0, 0].numel()
+
+
+class BNActFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d/2d fused with GLU / LeakyReLU / ReLU and an optional residual add
+    (model.py:52-54,72-80,96-101,366-373,577-611).  Updates the running statistics in place like
+    nn.BatchNorm does (momentum 0.1, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, act, slope, eps, momentum):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        B, C, HW = _bchw(x)
+        dev = x.device
+        stats = torch.empty((2, C), dtype=torch.float32, device=dev)
+        need = lib.bn_ws_bytes(B, C, HW)
+        wsp, wsn = workspace(dev)
+        if need > wsn:
+            raise lib.MoganHipError("workspace too small for bn (%d > %d)" % (need, wsn))
+        call("mogan_bn_stats", ptr(x), B, C, HW, eps, momentum, ptr(stats[0]), ptr(stats[1]),
+             ptr(running_mean), ptr(running_var), wsp, wsn, stream_ptr())
+        Cy = C // 2 if act == ACT_GLU else C
+        y = torch.empty((B, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
+        res = _c(residual) if residual is not None else None
+        call("mogan_bn_act_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(res), ptr(y),
+             B, C, HW, act, slope, stream_ptr())
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (act, slope, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        dy = _c(dy)
+        B, C, HW = _bchw(x)
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        wsp, wsn = workspace(x.device)
+        call("mogan_bn_act_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(dx),
+             ptr(dgb[0]), ptr(dgb[1]), B, C, HW, act, slope, 0, wsp, wsn, stream_ptr())
+        return dx, dgb[0], dgb[1], (dy if has_res else None), None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5,
+           momentum=0.1):
+    return BNActFn.apply(x, gamma, beta, residual, running_mean, running_var, act, float(slope), float(eps),
+                         float(momentum))
+
+
+class AffineActFn(torch.autograd.Function):
+    """Eval-mode BN (running statistics folded into scale/shift) + activation; only dx is produced
+    (frozen Inception trunk of CNN_ENCODER, model.py:218-219,227-242)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, act, slope):
+        x = _c(x)
+        B, C, HW = _bchw(x)
+        y = torch.empty_like(x)
+        call("mogan_affine_act_fwd", ptr(x), ptr(scale), ptr(shift), ptr(y), B, C, HW, act, slope, stream_ptr())
+        ctx.save_for_backward(x, scale, shift)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift = ctx.saved_tensors
+        act, slope = ctx.cfg
+        B, C, HW = _bchw(x)
+        dx = torch.empty_like(x)
+        call("mogan_affine_act_bwd", ptr(x), ptr(_c(dy)), ptr(scale), ptr(shift), ptr(dx), B, C, HW, act, slope,
+             stream_ptr())
+        return dx, None, None, None, None
+
+
+def affine_act(x, scale, shift, act=ACT_RELU, slope=0.0):
+    return AffineActFn.apply(x, scale, shift, act, float(slope))
+
+
+# ------------------------------------------------------------------------------- activations
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = _c(x)
+        B, C, HW = _bchw(x)
+        Cy = C // 2 if act == ACT_GLU else C
+        y = torch.empty((B, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        call("mogan_act_fwd", ptr(x), ptr(y), B, C, HW, act, slope, stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        B, C, HW = _bchw(x)
+        dx = torch.empty_like(x)
+        call("mogan_act_bwd", ptr(x), ptr(_c(dy)), ptr(dx), B, C, HW, act, slope, stream_ptr())
+        return dx, None, None
+
+
+def act(x, kind, slope=0.2):
+    return ActFn.apply(x, kind, float(slope))
+
+
+def glu(x):
+    return ActFn.apply(x, ACT_GLU, 0.0)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        call("mogan_add", ptr(a), ptr(b), ptr(y), a.numel(), stream_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+# ------------------------------------------------------------------------------- softmax
+class SoftmaxFn(torch.autograd.Function):
+    """softmax(scale * x) over `dim`, optionally restricted to the first lens[...] entries of each
+    column (DAMSM: captions of different lengths).  GlobalAttention.py:50,58."""
+
+    @staticmethod
+    def forward(ctx, x, dim, scale, lens):
+        x = _c(x)
+        dim = dim % x.dim()
+        outer = 1
+        for s in x.shape[:dim]:
+            outer *= s
+        inner = 1
+        for s in x.shape[dim + 1:]:
+            inner *= s
+        L = x.shape[dim]
+        y = torch.empty_like(x)
+        call("mogan_softmax_fwd", ptr(x), ptr(y), ptr(lens), outer, L, inner, scale, stream_ptr())
+        ctx.save_for_backward(y)
+        ctx.lens = lens
+        ctx.cfg = (outer, L, inner, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        outer, L, inner, scale = ctx.cfg
+        dx = torch.empty_like(y)
+        call("mogan_softmax_bwd", ptr(y), ptr(_c(dy)), ptr(dx), ptr(ctx.lens), outer, L, inner, scale, stream_ptr())
+        return dx, None, None, None
+
+
+def softmax(x, dim, scale=1.0, lens=None):
+    return SoftmaxFn.apply(x, dim, float(scale), lens)
+
+
+# ------------------------------------------------------------------------------- spatial transformer
+class STNFn(torch.autograd.Function):
+    """model.py:17-21 (affine_grid + grid_sample, bilinear, zeros)."""
+
+    @staticmethod
+    def forward(ctx, x, theta, Hout, Wout, align_corners):
+        x, theta = _c(x), _c(theta)
+        B, C, Hin, Win = x.shape
+        y = torch.empty((B, C, Hout, Wout), dtype=torch.float32, device=x.device)
+        call("mogan_stn_fwd", ptr(x), ptr(theta), ptr(y), B, C, Hin, Win, Hout, Wout, align_corners, stream_ptr())
+        ctx.save_for_backward(theta)
+        ctx.cfg = (B, C, Hin, Win, Hout, Wout, align_corners)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (theta,) = ctx.saved_tensors
+        B, C, Hin, Win, Hout, Wout, ac = ctx.cfg
+        dx = torch.empty((B, C, Hin, Win), dtype=torch.float32, device=dy.device)
+        call("mogan_stn_bwd", ptr(_c(dy)), ptr(theta), ptr(dx), B, C, Hin, Win, Hout, Wout, ac, stream_ptr())
+        return dx, None, None, None, None
+
+
+def stn(x, theta, size, align_corners=False):
+    return STNFn.apply(x, theta, int(size[2]), int(size[3]), 1 if align_corners else 0)
+
+
+def bbox_to_theta(bbox):
+    bbox = _c(bbox).view(-1, 4)
+    n = bbox.shape[0]
+    th = torch.empty((n, 2, 3), dtype=torch.float32, device=bbox.device)
+    thi = torch.empty((n, 2, 3), dtype=torch.float32, device=bbox.device)
+    call("mogan_bbox_to_theta", ptr(bbox), ptr(th), ptr(thi), n, stream_ptr())
+    return th, thi
+
+
+# ------------------------------------------------------------------------------- word attention
+class AttnFn(torch.autograd.Function):
+    """GlobalAttention.py:96-121 after conv_context. h (B,idf,Q), src (B,idf,T), mask (B,T) uint8."""
+
+    @staticmethod
+    def forward(ctx, h, src, mask, mask_mode):
+        h, src = _c(h), _c(src)
+        B, idf, Q = h.shape
+        T = src.shape[2]
+        wc = torch.empty((B, idf, Q), dtype=torch.float32, device=h.device)
+        attn = torch.empty((B, T, Q), dtype=torch.float32, device=h.device)
+        call("mogan_attn_fwd", ptr(h), ptr(src), ptr(mask), ptr(wc), ptr(attn), B, idf, Q, T, mask_mode,
+             stream_ptr())
+        ctx.save_for_backward(h, src, attn)
+        return wc, attn
+
+    @staticmethod
+    def backward(ctx, dwc, dattn):
+        h, src, attn = ctx.saved_tensors
+        B, idf, Q = h.shape
+        T = src.shape[2]
+        dwc = _c(dwc)
+        dattn = _c(dattn) if dattn is not None else None
+        dh = torch.empty_like(h)
+        dscore = torch.empty_like(attn)
+        call("mogan_attn_bwd", ptr(src), ptr(attn), ptr(dwc), ptr(dattn), ptr(dh), ptr(dscore), B, idf, Q, T,
+             stream_ptr())
+        dsrc = None
+        if ctx.needs_input_grad[1]:
+            dsrc = torch.empty_like(src)
+            bmm_raw(h, dscore.transpose(1, 2), dsrc)                    # (B,idf,Q) x (B,Q,T)
+            bmm_raw(dwc, attn.transpose(1, 2), dsrc, accumulate=True)
+        return dh, dsrc, None, None
+
+
+def attention(h, src, mask=None, mask_mode=0):
+    if mask is not None:
+        mask = mask.to(torch.uint8).contiguous()
+    return AttnFn.apply(h, src, mask, mask_mode)
+
+
+# ------------------------------------------------------------------------------- losses
+class BCEFn(torch.autograd.Function):
+    """nn.BCELoss()(p, const target) (miscc/losses.py:158-168,198-201)."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        p = _c(p).view(-1)
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        call("mogan_bce_fwd", ptr(p), target, 1.0, ptr(loss), p.numel(), 0, stream_ptr())
+        ctx.save_for_backward(p)
+        ctx.target = target
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        call("mogan_bce_bwd", ptr(p), ctx.target, 1.0, ptr(_c(g).view(1)), ptr(dp), p.numel(), stream_ptr())
+        return dp, None
+
+
+def bce(p, target):
+    return BCEFn.apply(p, float(target))
+
+
+class KLFn(torch.autograd.Function):
+    """KL_loss (miscc/losses.py:230-234)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _c(mu), _c(logvar)
+        loss = torch.empty(1, dtype=torch.float32, device=mu.device)
+        call("mogan_kl_fwd", ptr(mu), ptr(logvar), ptr(loss), mu.numel(), stream_ptr())
+        ctx.save_for_backward(mu, logvar)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        call("mogan_kl_bwd", ptr(mu), ptr(logvar), ptr(_c(g).view(1)), ptr(dmu), ptr(dlv), mu.numel(), stream_ptr())
+        return dmu, dlv
+
+
+def kl_loss(mu, logvar):
+    return KLFn.apply(mu, logvar)
+
+
+class ReparamFn(torch.autograd.Function):
+    """CA_NET.reparametrize (model.py:333-340)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _c(mu), _c(logvar), _c(eps)
+        c = torch.empty_like(mu)
+        call("mogan_reparam_fwd", ptr(mu), ptr(logvar), ptr(eps), ptr(c), mu.numel(), stream_ptr())
+        ctx.save_for_backward(logvar, eps)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        logvar, eps = ctx.saved_tensors
+        dmu, dlv = torch.empty_like(logvar), torch.empty_like(logvar)
+        call("mogan_reparam_bwd", ptr(logvar), ptr(eps), ptr(_c(dc)), ptr(dmu), ptr(dlv), logvar.numel(), stream_ptr())
+        return dmu, dlv, None
+
+
+def reparam(mu, logvar, eps):
+    return ReparamFn.apply(mu, logvar, eps)
+
+
+# ------------------------------------------------------------------------------- pooling / resize
+class PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind, k, s, pad, OH, OW):
+        x = _c(x)
+        B, C, H, W = x.shape
+        if kind == "max":
+            oh, ow = (H - k) // s + 1, (W - k) // s + 1
+            y = torch.empty((B, C, oh, ow), dtype=torch.float32, device=x.device)
+            call("mogan_maxpool_fwd", ptr(x), ptr(y), B * C, H, W, k, s, stream_ptr())
+            ctx.save_for_backward(x)
+        elif kind == "avg":
+            oh, ow = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+            y = torch.empty((B, C, oh, ow), dtype=torch.float32, device=x.device)
+            call("mogan_avgpool_fwd", ptr(x), ptr(y), B * C, H, W, k, s, pad, stream_ptr())
+        else:
+            y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+            call("mogan_bilinear_fwd", ptr(x), ptr(y), B * C, H, W, OH, OW, stream_ptr())
+        ctx.cfg = (kind, k, s, pad, OH, OW, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        kind, k, s, pad, OH, OW, shp = ctx.cfg
+        B, C, H, W = shp
+        dy = _c(dy)
+        dx = torch.empty(shp, dtype=torch.float32, device=dy.device)
+        if kind == "max":
+            (x,) = ctx.saved_tensors
+            call("mogan_maxpool_bwd", ptr(x), ptr(dy), ptr(dx), B * C, H, W, k, s, stream_ptr())
+        elif kind == "avg":
+            call("mogan_avgpool_bwd", ptr(dy), ptr(dx), B * C, H, W, k, s, pad, stream_ptr())
+        else:
+            call("mogan_bilinear_bwd", ptr(dy), ptr(dx), B * C, H, W, OH, OW, stream_ptr())
+        return dx, None, None, None, None, None, None
+
+
+def max_pool2d(x, k, s):
+    return PoolFn.apply(x, "max", k, s, 0, 0, 0)
+
+
+def avg_pool2d(x, k, s=None, pad=0):
+    return PoolFn.apply(x, "avg", k, s or k, pad, 0, 0)
+
+
+def bilinear_resize(x, OH, OW):
+    return PoolFn.apply(x, "bilinear", 0, 0, 0, OH, OW)
+
+
+# ------------------------------------------------------------------------------- optimizer
+def adam_step(p, g, m, v, ema, lr, beta1, beta2, eps, step=0, dev_state=None, eps_mode=0, grad_scale=1.0,
+              ema_decay=0.999):
+    """In-place fused Adam (+EMA) over flat fp32 buckets (trainer.py:137-148,341-342)."""
+    call("mogan_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), lr, beta1, beta2, eps, step,
+         ptr(dev_state), eps_mode, grad_scale, ema_decay, stream_ptr())

@@ -1,0 +1,312 @@
+"""-m gpu: every HIP entry point (through the C ABI, via hip/ops.py) against the CPU oracle's
+primitives (oracle/attngan_oracle.py, i.e. the torch-CPU ops the reference composes), evaluated in
+fp64 so that a kernel more accurate than torch-fp32 is not penalised.
+
+Stated tolerances (fp32 kernels, k-ordered fmaf accumulation):
+  conv / bmm outputs      rel-L2 <= 2e-6,  max-abs <= 1e-5 * max|ref|*sqrt(K)/16 (see _check)
+  BN / activations / STN / attention / softmax / pooling   max-abs <= 2e-5 (values are O(1))
+  Adam                    max-abs <= 1e-6 on O(1) parameters after three steps
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import det_array, load_pkg
+from oracle import attngan_oracle as O
+
+load_pkg()
+from mogan_amd.hip import lib, ops  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(name, shape, scale=1.0, shift=0.0):
+    return torch.from_numpy(det_array(name, shape, scale, shift))
+
+
+def _check(got, ref, rtol=2e-6, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    denom = ref.norm().item() + 1e-30
+    rel = (got - ref).norm().item() / denom
+    mx = (got - ref).abs().max().item()
+    assert rel <= rtol, "%s: rel-L2 %.3e > %.1e (max-abs %.3e)" % (what, rel, rtol, mx)
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k (kh,kw), stride, pad (ph,pw), up
+    (2, 8, 8, 8, 16, (3, 3), 1, (1, 1), 0),
+    (2, 8, 8, 8, 16, (3, 3), 1, (1, 1), 1),        # upBlock: fused nearest x2
+    (3, 5, 9, 7, 7, (3, 3), 1, (1, 1), 1),         # ragged everything
+    (2, 6, 16, 16, 12, (4, 4), 2, (1, 1), 0),      # D down conv
+    (2, 84, 16, 16, 24, (4, 4), 1, (1, 1), 0),     # D_NET64 local conv -> 15x15
+    (3, 100, 16, 16, 50, (3, 3), 2, (1, 1), 0),    # BBOX_NET (3x3 s2)
+    (2, 12, 4, 4, 1, (4, 4), 4, (0, 0), 0),        # logits conv 4x4 s4
+    (4, 20, 5, 1, 6, (1, 1), 1, (0, 0), 0),        # conv_context (1x1 on (B,cdf,T,1))
+    (2, 3, 32, 32, 96, (4, 4), 2, (1, 1), 0),      # first D conv (Cin=3)
+    (2, 48, 16, 16, 3, (3, 3), 1, (1, 1), 0),      # img head (Cout=3)
+    (2, 10, 17, 17, 12, (1, 7), 1, (0, 3), 0),     # Inception 1x7
+    (2, 10, 17, 17, 12, (7, 1), 1, (3, 0), 0),     # Inception 7x1
+    (2, 6, 35, 35, 8, (3, 3), 2, (0, 0), 0),       # Inception 3x3 s2 valid (odd size)
+    (2, 6, 12, 12, 8, (5, 5), 1, (2, 2), 0),       # Inception 5x5
+    (1, 96, 32, 32, 96, (3, 3), 1, (1, 1), 0),     # 96-wide tile config
+    (2, 160, 8, 8, 130, (3, 3), 1, (1, 1), 0),     # 128x128 tiles with ragged edges + long K
+]
+
+
+def _conv_ref(x, w, stride, pad, up):
+    x = x.double()
+    if up:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    return F.conv2d(x, w.double(), None, stride, pad)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("force", [(-1, 0), (0, 3), (1, 1), (2, 2), (3, 1), (4, 5)])
+def test_conv2d_fwd_dgrad_wgrad(case, force):
+    B, Cin, H, W, Cout, k, s, pad, up = case
+    lib.load().mogan_gemm_debug_force(*force)
+    try:
+        x = T("cx%s" % (case,), (B, Cin, H, W)).requires_grad_(True)
+        w = T("cw%s" % (case,), (Cout, Cin) + k, 0.2).requires_grad_(True)
+        ref = _conv_ref(x, w, s, pad, up)
+        g = T("cg%s" % (case,), ref.shape)
+        ref.backward(g.double())
+        xd = x.detach().to(DEV).requires_grad_(True)
+        wd = w.detach().to(DEV).requires_grad_(True)
+        y = ops.conv2d(xd, wd, None, s, pad, bool(up))
+        y.backward(g.to(DEV))
+        torch.cuda.synchronize()
+        _check(y, ref, what="fwd")
+        _check(xd.grad, x.grad, what="dgrad")
+        _check(wd.grad, w.grad, what="wgrad")
+    finally:
+        lib.load().mogan_gemm_debug_force(-1, 0)
+
+
+def test_conv_bias_and_wgrad_accumulate():
+    x = T("cbx", (3, 12, 4, 4)).requires_grad_(True)
+    w = T("cbw", (1, 12, 4, 4), 0.2).requires_grad_(True)
+    b = T("cbb", (1,)).requires_grad_(True)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 4)
+    ref.sum().backward()
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xd, wd, bd, 4, 0)
+    y.sum().backward()
+    _check(y, ref); _check(bd.grad, b.grad); _check(wd.grad, w.grad)
+    acc = wd.grad.clone()
+    ops.conv2d_wgrad(torch.ones_like(y), xd.detach(), tuple(w.shape), 4, 0, 0, 0, out=acc, accumulate=True)
+    _check(acc, 2 * w.grad, what="accumulate")
+
+
+@pytest.mark.parametrize("shape", [(16, 248, 1024), (3, 181, 100), (4, 256, 400), (130, 70, 33)])
+def test_linear(shape):
+    rows, fin, fout = shape
+    x = T("lx%s" % (shape,), (rows, fin)).requires_grad_(True)
+    w = T("lw%s" % (shape,), (fout, fin), 0.1).requires_grad_(True)
+    b = T("lb%s" % (shape,), (fout,)).requires_grad_(True)
+    ref = F.linear(x.double(), w.double(), b.double())
+    g = T("lg%s" % (shape,), ref.shape)
+    ref.backward(g.double())
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd)
+    y.backward(g.to(DEV))
+    _check(y, ref); _check(xd.grad, x.grad); _check(wd.grad, w.grad); _check(bd.grad, b.grad)
+
+
+def test_bmm_strided_views():
+    a = T("ba", (3, 40, 50)).requires_grad_(True)
+    b = T("bb", (3, 17, 50)).requires_grad_(True)       # used transposed
+    ref = torch.bmm(a.double(), b.double().transpose(1, 2))
+    g = T("bg", ref.shape)
+    ref.backward(g.double())
+    ad, bd = (t.detach().to(DEV).requires_grad_(True) for t in (a, b))
+    y = ops.bmm(ad, bd.transpose(1, 2))
+    y.backward(g.to(DEV))
+    _check(y, ref); _check(ad.grad, a.grad); _check(bd.grad, b.grad)
+
+
+ACTS = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "glu": ops.ACT_GLU}
+
+
+def _act_ref(y, act):
+    if act == "relu":
+        return F.relu(y)
+    if act == "lrelu":
+        return F.leaky_relu(y, 0.2)
+    if act == "glu":
+        return O.glu(y)
+    return y
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 8, 8), (3, 6, 15, 15), (16, 24), (2, 10, 64, 64), (5, 4, 3, 3)])
+@pytest.mark.parametrize("act", ["none", "relu", "lrelu", "glu"])
+@pytest.mark.parametrize("res", [False, True])
+def test_bn_act(shape, act, res):
+    if res and act != "none":
+        pytest.skip("residual only follows a plain BN in the reference (ResBlock)")
+    C = shape[1]
+    x = T("bnx%s" % (shape,), shape, 1.5, 0.3).requires_grad_(True)
+    gm = T("bng%d" % C, (C,), 0.2, 1.0).requires_grad_(True)
+    bt = T("bnb%d" % C, (C,), 0.2).requires_grad_(True)
+    rm, rv = T("bnrm%d" % C, (C,), 0.1), T("bnrv%d" % C, (C,), 0.1).abs() + 1
+    r = T("bnres%s" % (shape,), shape).requires_grad_(True) if res else None
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    yb = F.batch_norm(x.double(), rm_ref, rv_ref, gm.double(), bt.double(), True, 0.1, 1e-5)
+    ref = _act_ref(yb, act) + (r.double() if res else 0)
+    g = T("bngo%s%s" % (shape, act), ref.shape)
+    ref.backward(g.double())
+    xd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, gm, bt))
+    rd = r.detach().to(DEV).requires_grad_(True) if res else None
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    y = ops.bn_act(xd, gd, bd, rmd, rvd, ACTS[act], 0.2, rd)
+    y.backward(g.to(DEV))
+    _check(y, ref, 5e-6, "y")
+    _check(rmd, rm_ref, 1e-6, "running_mean"); _check(rvd, rv_ref, 1e-6, "running_var")
+    _check(xd.grad, x.grad, 2e-5, "dx"); _check(gd.grad, gm.grad, 2e-5, "dgamma"); _check(bd.grad, bt.grad, 2e-5, "dbeta")
+    if res:
+        _check(rd.grad, r.grad, 1e-7, "dres")
+
+
+@pytest.mark.parametrize("act", ["relu", "lrelu", "tanh", "sigmoid", "glu"])
+def test_act(act):
+    x = T("ax" + act, (3, 8, 5, 7)).requires_grad_(True)
+    code = dict(ACTS, tanh=ops.ACT_TANH, sigmoid=ops.ACT_SIGMOID)[act]
+    ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid}.get(act, lambda v: _act_ref(v, act))(x.double())
+    g = T("ag" + act, ref.shape)
+    ref.backward(g.double())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.act(xd, code, 0.2)
+    y.backward(g.to(DEV))
+    _check(y, ref, 2e-6); _check(xd.grad, x.grad, 2e-6)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_stn(ac):
+    bbox = torch.tensor([[0.1, 0.2, 0.3, 0.4], [-1, -1, -1, -1], [0.4, 0.1, 0.55, 0.8], [0.0, 0.0, 1.0, 1.0]])
+    th, thi = ops.bbox_to_theta(bbox.to(DEV))
+    from mogan_amd.attngan import synthetic
+    th_ref, thi_ref = synthetic.bbox_to_theta(bbox)
+    assert torch.equal(th.cpu(), th_ref) and torch.equal(thi.cpu(), thi_ref)
+    rot = T("stn.rot", (4, 2, 3), 0.5) + torch.tensor([[1., 0, 0], [0, 1., 0]])
+    for theta, insz, outsz in ((thi_ref, (4, 5, 8, 8), (4, 5, 8, 8)), (th_ref, (4, 3, 64, 64), (4, 3, 16, 16)),
+                               (thi_ref, (4, 7, 15, 15), (4, 7, 16, 16)), (rot, (4, 4, 7, 9), (4, 4, 5, 6))):
+        x = T("stnx%s" % (insz,), insz).requires_grad_(True)
+        ref = O.stn(x.double(), theta.double(), outsz, align_corners=ac)
+        g = T("stng%s" % (outsz,), outsz)
+        ref.backward(g.double())
+        xd = x.detach().to(DEV).requires_grad_(True)
+        y = ops.stn(xd, theta.to(DEV), outsz, ac)
+        y.backward(g.to(DEV))
+        _check(y, ref, 1e-5, "stn y"); _check(xd.grad, x.grad, 1e-5, "stn dx")
+        assert float(y[1].detach().abs().max()) == 0.0 or theta is rot    # absent object -> exactly 0
+
+
+@pytest.mark.parametrize("B,idf,Q,T_", [(3, 6, 16, 5), (4, 48, 4096, 12), (2, 96, 300, 20)])
+def test_attention(B, idf, Q, T_):
+    h = T("ath%d" % B, (B, idf, Q)).requires_grad_(True)
+    src = T("ats%d" % B, (B, idf, T_), 0.3).requires_grad_(True)
+    mask = torch.zeros(B, T_, dtype=torch.bool)
+    for b in range(B):
+        mask[b, max(1, T_ - 1 - b):] = True
+    for mode in (0, 1):
+        for t in (h, src):
+            t.grad = None
+        sc = torch.bmm(h.double().transpose(1, 2), src.double()).reshape(B * Q, T_)
+        rows = (torch.arange(B * Q) % B) if mode == 0 else (torch.arange(B * Q) // Q)
+        att = torch.softmax(sc.masked_fill(mask[rows], -float("inf")), 1).reshape(B, Q, T_).transpose(1, 2)
+        wc = torch.bmm(src.double(), att)
+        gw, ga = T("atgw%d" % B, wc.shape), T("atga%d" % B, att.shape)
+        ((wc * gw.double()).sum() + (att * ga.double()).sum()).backward()
+        hd, sd = (t.detach().to(DEV).requires_grad_(True) for t in (h, src))
+        wcd, attd = ops.attention(hd, sd, mask.to(DEV), mode)
+        ((wcd * gw.to(DEV)).sum() + (attd * ga.to(DEV)).sum()).backward()
+        _check(wcd, wc, 5e-6, "wc"); _check(attd, att, 5e-6, "attn")
+        _check(hd.grad, h.grad, 2e-5, "dh"); _check(sd.grad, src.grad, 2e-5, "dsrc")
+
+
+def test_softmax_masked_and_scaled():
+    x = T("smx", (3, 7, 5, 4)).requires_grad_(True)
+    lens = torch.tensor([[5, 3, 1, 4]] * 21, dtype=torch.int32).reshape(3, 7, 4)
+    ref = torch.zeros_like(x, dtype=torch.float64)
+    xd64 = x.double()
+    for k in range(4):
+        n = int(lens[0, 0, k])
+        ref = ref.clone()
+        ref[:, :, :n, k] = torch.softmax(4.0 * xd64[:, :, :n, k], 2)
+    g = T("smg", x.shape)
+    ref.backward(g.double())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.softmax(xd, 2, 4.0, lens.to(DEV).contiguous())
+    y.backward(g.to(DEV))
+    _check(y, ref, 2e-6); _check(xd.grad, x.grad, 1e-5)
+    y2 = ops.softmax(xd.detach(), 3)
+    _check(y2, torch.softmax(x.detach().double(), 3), 2e-6)
+
+
+def test_losses_bce_kl():
+    p = torch.sigmoid(T("bcep", (16,), 2.0)).requires_grad_(True)
+    for tgt in (0.0, 1.0):
+        p.grad = None
+        ref = O.bce(p.double(), torch.full((16,), tgt, dtype=torch.float64))
+        (ref * 1.7).backward()
+        pd = p.detach().to(DEV).requires_grad_(True)
+        l = ops.bce(pd, tgt)
+        (l * 1.7).backward()
+        _check(l, ref, 1e-6); _check(pd.grad, p.grad, 1e-6)
+    # torch's clamp of log at -100
+    pd = torch.tensor([0.0, 1.0, 0.5], device=DEV)
+    assert abs(float(ops.bce(pd, 1.0)) - (100 + 0 + np.log(2)) / 3) < 1e-4
+    mu = T("klm", (16, 100), 0.5).requires_grad_(True)
+    lv = T("kll", (16, 100), 0.5).requires_grad_(True)
+    ref = O.kl_loss(mu.double(), lv.double())
+    ref.backward()
+    md, ld = (t.detach().to(DEV).requires_grad_(True) for t in (mu, lv))
+    l = ops.kl_loss(md, ld)
+    l.backward()
+    _check(l, ref, 1e-6); _check(md.grad, mu.grad, 1e-6); _check(ld.grad, lv.grad, 1e-6)
+
+
+def test_pooling_and_resize():
+    x = T("plx", (2, 5, 35, 35)).requires_grad_(True)
+    for name, fn_ref, fn in (
+            ("max", lambda v: F.max_pool2d(v, 3, 2), lambda v: ops.max_pool2d(v, 3, 2)),
+            ("avg", lambda v: F.avg_pool2d(v, 3, 1, 1), lambda v: ops.avg_pool2d(v, 3, 1, 1)),
+            ("avg8", lambda v: F.avg_pool2d(v[:, :, :8, :8], 8), lambda v: ops.avg_pool2d(v[:, :, :8, :8], 8)),
+            ("bil", lambda v: F.interpolate(v, size=(61, 61), mode="bilinear", align_corners=False),
+             lambda v: ops.bilinear_resize(v, 61, 61))):
+        x.grad = None
+        ref = fn_ref(x.double())
+        g = T("plg" + name, ref.shape)
+        ref.backward(g.double())
+        xd = x.detach().to(DEV).requires_grad_(True)
+        y = fn(xd)
+        y.backward(g.to(DEV))
+        _check(y, ref, 5e-6, name); _check(xd.grad, x.grad, 5e-6, name + " dx")
+
+
+@pytest.mark.parametrize("eps_mode", [0, 1])
+def test_adam_ema(eps_mode):
+    n = 10007
+    p, g = T("adp", (n,)), T("adg", (n,), 0.01)
+    net = {"w": p.clone().double().requires_grad_(True)}
+    st = O.adam_state(net)
+    ema = p.clone().double()
+    pd, gd = p.to(DEV), g.to(DEV)
+    pad = (-n) % 4
+    m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV); emad = p.to(DEV).clone()
+    state = torch.zeros(3, device=DEV)
+    for step in range(1, 4):
+        net["w"].grad = (g.double() * step)
+        O.adam_step(net, st, 2e-4, eps_mode="torch2" if eps_mode == 0 else "torch041")
+        ema.mul_(0.999).add_(net["w"].detach(), alpha=0.001)
+        if step < 3:
+            ops.adam_step(pd, gd * step, m, v, emad, 2e-4, 0.5, 0.999, 1e-8, step=step, eps_mode=eps_mode)
+            state[0] = step
+        else:   # device-resident step counter (hipGraph-friendly)
+            ops.adam_step(pd, gd * step, m, v, emad, 2e-4, 0.5, 0.999, 1e-8, dev_state=state, eps_mode=eps_mode)
+    assert float((pd.cpu().double() - net["w"].detach()).abs().max()) < 1e-6   # |p|~3: 2-3 ulp
+    assert float((emad.cpu().double() - ema).abs().max()) < 1e-6

@@ -1,0 +1,245 @@
+"""-m gpu: the product networks / losses / train step (HIP kernels through the C ABI) against the
+golden vectors captured from the reference's python (tests/golden/*.npz), on the same
+deterministic weights and inputs.
+
+Stated fp32 tolerances (SURVEY.md §8(c) measured envelope of the reference itself):
+  generated tensors, attention maps, D features     max-abs <= 1e-4 (values O(1))
+  scalar losses                                     rel <= 1e-5 (DAMSM-weighted G loss: 1e-4)
+  D weight gradients                                checksum rel <= 1e-4
+  G weight gradients                                checksum rel <= 1e-2 (ill-conditioned through the
+                                                    stacked BN+GLU generator even for torch-fp32 itself)
+  post-Adam parameters / EMA / BN running stats     checksum rel <= 1e-4 of the tensor's abs-sum
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, det_array, det_fill_state, load_pkg, probe, probe_close
+from standin import StandInEncoder
+
+load_pkg()
+from mogan_amd.attngan import synthetic  # noqa: E402
+from mogan_amd.attngan.miscc.config import cfg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(name, shape, scale=1.0, shift=0.0):
+    return torch.from_numpy(det_array(name, shape, scale, shift))
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def close(got, want, atol=1e-4, rtol=1e-4, what=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.fixture(autouse=True)
+def small_cfg():
+    cfg.GAN.GF_DIM, cfg.GAN.DF_DIM, cfg.GAN.R_NUM, cfg.GAN.Z_DIM = 4, 4, 2, 100
+    cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.WORDS_NUM = 16, 5
+    cfg.TREE.BRANCH_NUM = 3
+    cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.GAMMA2 = 4.0, 5.0
+    cfg.TRAIN.SMOOTH.GAMMA3, cfg.TRAIN.SMOOTH.LAMBDA = 10.0, 50.0
+    cfg.TRAIN.GENERATOR_LR = cfg.TRAIN.DISCRIMINATOR_LR = 2e-4
+    cfg.STN_ALIGN_CORNERS, cfg.ATT_MASK_MODE, cfg.ADAM_EPS_MODE = False, 0, 0
+    yield
+
+
+def test_blocks():
+    from mogan_amd.attngan import model
+    g = golden("blocks")
+    cfg.GAN.R_NUM = 2
+    for tag, make, gshape in (("up", lambda: model.upBlock(8, 4), (4, 4, 16, 16)),
+                              ("res", lambda: model.ResBlock(8), (4, 8, 8, 8)),
+                              ("lrelu3", lambda: model.Block3x3_leakRelu(8, 6), (4, 6, 8, 8)),
+                              ("down", lambda: model.downBlock(8, 6), (4, 6, 4, 4))):
+        mod = make()
+        det_fill_state(mod, "blocks.%s." % tag)
+        mod = mod.to(DEV).train()
+        x = T("blocks.x", (4, 8, 8, 8)).to(DEV).requires_grad_(True)
+        y = mod(x)
+        y.backward(T("blocks.%s.g" % tag, gshape).to(DEV))
+        close(y, g[tag + "_y"], 2e-5, what=tag)
+        close(x.grad, g[tag + "_dx"], 5e-5, 1e-3, what=tag + " dx")
+        for k, p in mod.named_parameters():
+            close(p.grad, g["%s_d_%s" % (tag, k.replace(".", "__"))], 1e-4, 1e-3, what=tag + k)
+        for k, v in mod.state_dict().items():
+            if "running" in k:
+                close(v, g["%s_s_%s" % (tag, k.replace(".", "__"))], 1e-5, what=tag + k)
+
+
+def test_global_attention_reference_mask_indexing():
+    from mogan_amd.attngan.GlobalAttention import GlobalAttentionGeneral, func_attention
+    g = golden("attn")
+    for B in (3, 4):
+        att = GlobalAttentionGeneral(6, 10)
+        det_fill_state(att, "attn.")
+        att = att.to(DEV)
+        h = T("attn.h%d" % B, (B, 6, 4, 4)).to(DEV).requires_grad_(True)
+        ctx = T("attn.ctx%d" % B, (B, 10, 5)).to(DEV).requires_grad_(True)
+        p = "b%d_" % B
+        att.applyMask(torch.from_numpy(g[p + "mask"]).to(DEV))
+        wc, a = att(h, ctx)
+        ((wc * T("attn.gw%d" % B, wc.shape).to(DEV)).sum() + (a * T("attn.ga%d" % B, a.shape).to(DEV)).sum()).backward()
+        close(wc, g[p + "wc"], 2e-5); close(a, g[p + "attn"], 2e-5)
+        close(h.grad, g[p + "dh"], 5e-5, 1e-3); close(ctx.grad, g[p + "dctx"], 5e-5, 1e-3)
+        close(att.conv_context.weight.grad, g[p + "dw"], 5e-5, 1e-3)
+    q = T("fattn.q", (2, 8, 4)).to(DEV).requires_grad_(True)
+    c = T("fattn.c", (2, 8, 3, 3)).to(DEV).requires_grad_(True)
+    wc, a = func_attention(q, c, 4.0)
+    (wc * T("fattn.gw", wc.shape).to(DEV)).sum().backward()
+    close(wc, g["f_wc"], 2e-5); close(a, g["f_attn"], 2e-5)
+    close(q.grad, g["f_dq"], 5e-5, 1e-3); close(c.grad, g["f_dc"], 5e-5, 1e-3)
+
+
+def test_g_net_end_to_end():
+    from mogan_amd.attngan import model
+    g = golden("gnet")
+    bt = synthetic.to_device(synthetic.make_batch(3, words_num=5, nef=16, seed=11), DEV)
+    G = model.G_NET()
+    det_fill_state(G, "G.")
+    G = G.to(DEV).train()
+    z = bt["z"].clone().requires_grad_(True)
+    sent = bt["sent_emb"].clone().requires_grad_(True)
+    words = bt["words_embs"].clone().requires_grad_(True)
+    imgs, atts, mu, logvar = G(z, sent, words, bt["mask"], bt["tmi"], bt["label_one_hot"], eps=bt["eps"])
+    loss = sum((im * T("G.gimg%d" % i, im.shape).to(DEV)).sum() for i, im in enumerate(imgs))
+    loss = loss + (mu * T("G.gmu", mu.shape).to(DEV)).sum() + (logvar * T("G.glv", logvar.shape).to(DEV)).sum()
+    loss.backward()
+    close(mu, g["mu"], 1e-5); close(logvar, g["logvar"], 1e-5)
+    close(imgs[0], g["img64"]); close(imgs[1][:, :, ::2, ::2], g["img128"]); close(imgs[2][:, :, ::4, ::4], g["img256"])
+    close(atts[0][:, :, ::4, ::4], g["att64"]); close(atts[1][:, :, ::8, ::8], g["att128"])
+    probe_close(probe(imgs[2]), g["img256_p"], 1e-4, what="img256")
+    probe_close(probe(atts[1]), g["att128_p"], 1e-4, what="att128")
+    close(z.grad, g["dz"], 1e-3, 1e-2); close(sent.grad, g["dsent"], 1e-3, 1e-2)
+    for k, p in G.named_parameters():
+        probe_close(probe(p.grad), g["g_" + k.replace(".", "__")], 1e-2, what="grad " + k)
+    for k, v in G.state_dict().items():
+        if "running" in k:
+            probe_close(probe(v), g["s_" + k.replace(".", "__")], 1e-4, what=k)
+
+
+def test_d_nets():
+    from mogan_amd.attngan import model
+    g = golden("dnets")
+    B = 3
+    bt = synthetic.to_device(synthetic.make_batch(B, words_num=5, nef=16, seed=11), DEV)
+    for i, cls in enumerate((model.D_NET64, model.D_NET128, model.D_NET256)):
+        D = cls()
+        det_fill_state(D, "D%d." % i)
+        D = D.to(DEV).train()
+        x = bt["imgs"][i].clone().requires_grad_(True)
+        f = D(x, bt["label_one_hot"], bt["tm"], bt["tmi"]) if i == 0 else D(x)
+        c = D.COND_DNET(f, bt["sent_emb"])
+        u = D.UNCOND_DNET(f)
+        cw = D.COND_DNET(f[:B - 1], bt["sent_emb"][1:B])
+        dev = lambda n, s: T(n, s).to(DEV)
+        loss = (f * dev("D%d.gf" % i, f.shape)).sum() + (c * dev("D%d.gc" % i, c.shape)).sum() \
+            + (u * dev("D%d.gu" % i, u.shape)).sum() + (cw * dev("D%d.gcw" % i, cw.shape)).sum()
+        loss.backward()
+        p = "d%d_" % i
+        close(f, g[p + "feat"]); close(c, g[p + "cond"], 1e-5); close(u, g[p + "uncond"], 1e-5)
+        close(cw, g[p + "wrong"], 1e-5)
+        probe_close(probe(x.grad), g[p + "dx_p"], 1e-3, what="dx")
+        for k, v in D.named_parameters():
+            probe_close(probe(v.grad), g[p + "g_" + k.replace(".", "__")], 1e-3, what="D%d %s" % (i, k))
+        for k, v in D.state_dict().items():
+            if "running" in k:
+                probe_close(probe(v), g[p + "s_" + k.replace(".", "__")], 1e-4, what=k)
+
+
+def _build_all():
+    from mogan_amd.attngan import model
+    G = model.G_NET()
+    det_fill_state(G, "G.")
+    Ds = []
+    for i, cls in enumerate((model.D_NET64, model.D_NET128, model.D_NET256)):
+        D = cls()
+        det_fill_state(D, "D%d." % i)
+        Ds.append(D.to(DEV).train())
+    enc = StandInEncoder(16)
+    det_fill_state(enc, "ENC.")
+    for p in enc.parameters():
+        p.requires_grad = False
+    return G.to(DEV).train(), Ds, enc.to(DEV).eval()
+
+
+def test_losses():
+    from mogan_amd.attngan.miscc import losses as L
+    g = golden("losses")
+    B = 4
+    bt = synthetic.to_device(synthetic.make_batch(B, words_num=5, nef=16, seed=5), DEV)
+    G, Ds, enc = _build_all()
+    ones, zeros, match = torch.ones(B, device=DEV), torch.zeros(B, device=DEV), torch.arange(B, device=DEV)
+    fakes = [T("L.fake%d" % i, im.shape, 0.5).to(DEV).requires_grad_(True) for i, im in enumerate(bt["imgs"])]
+    for i, D in enumerate(Ds):
+        kw = dict(local_labels=bt["label_one_hot"], transf_matrices=bt["tm"],
+                  transf_matrices_inv=bt["tmi"]) if i == 0 else {}
+        errD = L.discriminator_loss(D, bt["imgs"][i], fakes[i], bt["sent_emb"], ones, zeros, None, **kw)
+        errD.backward()
+        np.testing.assert_allclose(float(errD), float(g["errD%d" % i]), rtol=1e-5)
+        for k, v in D.named_parameters():
+            probe_close(probe(v.grad), g["d%d_g_%s" % (i, k.replace(".", "__"))], 1e-3, what=k)
+        D.zero_grad()
+    errG, logs = L.generator_loss(Ds, enc, fakes, ones, bt["words_embs"], bt["sent_emb"], match, bt["cap_lens"],
+                                  bt["class_ids"], None, local_labels=bt["label_one_hot"],
+                                  transf_matrices=bt["tm"], transf_matrices_inv=bt["tmi"])
+    errG.backward()
+    np.testing.assert_allclose(float(errG), float(g["errG"]), rtol=1e-4)
+    assert "w_loss" in logs and "g_loss2" in logs
+    for i, f in enumerate(fakes):
+        probe_close(probe(f.grad), g["dfake%d_p" % i], 1e-3, what="dfake%d" % i)
+    feat = T("L.feat", (B, 16, 17, 17)).to(DEV).requires_grad_(True)
+    code = T("L.code", (B, 16)).to(DEV).requires_grad_(True)
+    w0, w1, _ = L.words_loss(feat, bt["words_embs"], match, bt["cap_lens"], bt["class_ids"], B)
+    s0, s1 = L.sent_loss(code, bt["sent_emb"], match, bt["class_ids"], B)
+    (w0 + 2 * w1 + 3 * s0 + 4 * s1).backward()
+    for got, key in ((w0, "w0"), (w1, "w1"), (s0, "s0"), (s1, "s1")):
+        np.testing.assert_allclose(float(got), float(g[key]), rtol=2e-5, err_msg=key)
+    close(feat.grad, g["dfeat"], 1e-5, 1e-3); close(code.grad, g["dcode"], 1e-5, 1e-3)
+    with torch.no_grad():
+        _, _, att = L.words_loss(feat, bt["words_embs"], None, bt["cap_lens"], bt["class_ids"], B)
+    close(att[0], g["watt0"], 1e-5); close(att[3], g["watt3"], 1e-5)
+    mu = T("L.mu", (B, 100), 0.5).to(DEV).requires_grad_(True)
+    lv = T("L.lv", (B, 100), 0.5).to(DEV).requires_grad_(True)
+    kl = L.KL_loss(mu, lv)
+    kl.backward()
+    np.testing.assert_allclose(float(kl), float(g["kl"]), rtol=1e-5)
+    close(mu.grad, g["dmu"], 1e-7, 1e-4); close(lv.grad, g["dlv"], 1e-7, 1e-4)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_train_steps(use_graph):
+    """the op order of the step (fake images generated once, each D updated
+    before generator_loss forwards through it), Adam, EMA, BN running statistics -- eager and as one
+    replayed hipGraph."""
+    from mogan_amd.attngan.trainer import TrainEngine
+    g = golden("step")
+    G, Ds, enc = _build_all()
+    eng = TrainEngine(None, enc, G, Ds, use_graph=use_graph)
+    for step in range(2):
+        bt = synthetic.to_device(synthetic.make_batch(4, words_num=5, nef=16, seed=100 + step), DEV)
+        logs = eng.step(bt)
+        torch.cuda.synchronize()
+        p = "s%d_" % step
+        for k in ("errD0", "errD1", "errD2", "kl"):
+            np.testing.assert_allclose(float(logs[k]), float(g[p + k]), rtol=1e-4 * (1 + 9 * step), err_msg=k)
+        np.testing.assert_allclose(float(logs["errG"]), float(g[p + "errG"]), rtol=2e-4 * (1 + 9 * step))
+        close(logs["fake64"], g[p + "fake64"], 2e-4 * (1 + 9 * step), 1e-3)
+        tol = 1e-4 if step == 0 else 1e-3
+        for k, v in G.state_dict().items():
+            if v.is_floating_point():
+                probe_close(probe(v), g[p + "G_" + k.replace(".", "__")], tol, what="G " + k)
+        for i, D in enumerate(Ds):
+            for k, v in D.state_dict().items():
+                if v.is_floating_point():
+                    probe_close(probe(v), g["%sD%d_%s" % (p, i, k.replace(".", "__"))], tol, what="D%d %s" % (i, k))
+        for (k, _), a in zip(G.named_parameters(), eng.optG.ema_params()):
+            probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], tol, what="ema " + k)

@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of one coco-attngan G+D train step (256x256) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (code/coco/attngan/trainer.py:281-342) over one synthetic
+minibatch of B=16 per GPU: text-encode, G forward, 3 x (D zero_grad, discriminator_loss, backward,
+Adam), generator_loss incl. Inception + DAMSM words/sentence losses + KL, backward, Adam, EMA.
+fp32 everywhere, random-init networks of the full coco_train.yml widths, inputs resident in HBM.
+W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize();
+elapsed = MAX over ranks; rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      dominant kernel = the fp32-MFMA implicit-GEMM (gemm_kernel<...>): algorithmic flops
+                per launch (2*M*N*K of the true GEMM dims) / average launch duration measured live
+                with HIP events on the launch stream (mogan_prof_*), vs the 157.3 TFLOP/s fp32 MFMA peak
+  cpu_baseline  the CPU oracle (oracle/attngan_oracle.py, a torch-CPU port of the reference step)
+                timed on this host's cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import mogan_loader  # noqa: E402
+
+mogan_loader.load()
+from mogan_amd.attngan import synthetic  # noqa: E402
+from mogan_amd.attngan.miscc.config import cfg, set_coco_train_defaults  # noqa: E402
+from mogan_amd.attngan.trainer import TrainEngine, build_networks  # noqa: E402
+from mogan_amd.hip import lib  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+MODES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bmm")
+TILES = ("128x128", "96x128", "128x32", "32x128", "64x64")
+
+
+def make_device_batch(B, seed, device):
+    bt = synthetic.make_batch(B, words_num=cfg.TEXT.WORDS_NUM, nef=cfg.TEXT.EMBEDDING_DIM, seed=seed,
+                              text="tokens")
+    cap_lens_cpu = bt["cap_lens"].clone()
+    b = synthetic.to_device(bt, device)
+    b["cap_lens_cpu"] = cap_lens_cpu
+    b["cap_lens"] = b["cap_lens"].to(torch.int32)
+    return b, bt
+
+
+def roofline_leg(engine, run_step, steps=2):
+    """Eager steps with every gemm_kernel launch bracketed by HIP events on its stream."""
+    import ctypes
+    g = engine.use_graph
+    engine.use_graph = False
+    run_step()                                        # eager warm-up (allocator)
+    torch.cuda.synchronize()
+    lib.call("mogan_prof_enable", 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / steps
+    buf = (ctypes.c_double * (5 * 32))()
+    n = lib.load().mogan_prof_collect(ctypes.cast(buf, ctypes.c_void_p), 32)
+    lib.call("mogan_prof_enable", 0)
+    engine.use_graph = g
+    rows = []
+    for i in range(n):
+        m, c, launches, flops, ms = buf[5 * i:5 * i + 5]
+        rows.append(dict(kernel="gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)]),
+                         launches_per_step=launches / steps, gflop_per_step=flops / steps / 1e9,
+                         ms_per_step=ms / steps, tflops=(flops / 1e12) / (ms / 1e3) if ms > 0 else 0.0))
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows, wall_ms
+
+
+def cpu_baseline_leg(engine, bt_cpu, dev_batch, B):
+    """The oracle (torch-CPU port of the reference step) on this host, same workload."""
+    from oracle import attngan_oracle as O
+    from oracle import inception_oracle as IO
+    ocfg = O.Cfg(gf_dim=cfg.GAN.GF_DIM, df_dim=cfg.GAN.DF_DIM, emb_dim=cfg.TEXT.EMBEDDING_DIM,
+                 r_num=cfg.GAN.R_NUM, words_num=cfg.TEXT.WORDS_NUM)
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
+    st = O.TrainState(O.from_state_dict(cpu(engine.netG.state_dict())),
+                      [O.from_state_dict(cpu(d.state_dict())) for d in engine.netsD], ocfg)
+    enc_sd = cpu(engine.image_encoder.state_dict())
+    batch = dict(bt_cpu)
+    batch["words_embs"] = dev_batch["words_embs"].cpu()
+    batch["sent_emb"] = dev_batch["sent_emb"].cpu()
+    batch["mask"] = dev_batch["mask"].cpu()
+    enc = lambda x: IO.cnn_encoder(enc_sd, x)
+    times = []
+    t_all = time.perf_counter()
+    for i in range(3):
+        batch["z"] = torch.randn(B, cfg.GAN.Z_DIM)
+        t0 = time.perf_counter()
+        O.train_step(st, batch, enc)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 25.0:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    sec = sum(timed) / len(timed)
+    return dict(value=B / sec, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d timed step(s) of the same B=%d workload after %d warm-up step(s) "
+                       "(oracle/attngan_oracle.py + inception_oracle.py, torch-CPU fp32, %.2f s/step)"
+                       % (len(timed), B, len(times) - len(timed), sec))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="minibatch per GPU (BASELINE config: 16)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--debug-losses", action="store_true", help="print the losses of every step (adds a host sync)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    set_coco_train_defaults()
+    B = args.batch
+    cfg.TRAIN.BATCH_SIZE = B
+    text_encoder, image_encoder, netG, netsD = build_networks(device=device, seed=1234)   # identical replicas
+    use_graph = (world == 1) and not args.no_graph
+    engine = TrainEngine(text_encoder, image_encoder, netG, netsD, distributed=world > 1, use_graph=use_graph)
+    batch, bt_cpu = make_device_batch(B, seed=rank, device=device)
+    gen = torch.Generator(device=device).manual_seed(1000 + rank)
+
+    def run_step():
+        b = dict(batch)
+        b["z"] = torch.randn(B, cfg.GAN.Z_DIM, device=device, generator=gen)         # trainer.py:294
+        b["eps"] = torch.randn(B, cfg.GAN.CONDITION_DIM, device=device, generator=gen)  # model.py:336
+        return engine.step(b)
+
+    for _ in range(args.warmup):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logs = run_step()
+        if args.debug_losses:
+            print("step", {k: round(float(v), 4) for k, v in logs.items() if v.dim() == 0}, file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms = elapsed / args.steps * 1e3
+    out = {
+        "metric": "images/sec per G+D train step, 256x256 coco-attngan",
+        "value": world * B * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MS-COCO AttnGAN 256x256 G+D train step: G_NET + D_NET64/128/256 + "
+                               "GlobalAttentionGeneral + Inception/DAMSM losses (random-init), coco_train.yml "
+                               "widths (GF 48, DF 96, T 12), fp32", "batch_per_gpu": B, "global_batch": world * B,
+                   "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager"},
+        "losses": {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.dim() == 0},
+    }
+    if rank == 0 and not args.no_roofline:
+        rows, eager_ms = roofline_leg(engine, run_step)
+        dom = rows[0]
+        tot_ms = sum(r["ms_per_step"] for r in rows)
+        tot_gf = sum(r["gflop_per_step"] for r in rows)
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": dom["launches_per_step"],
+            "avg_launch_ms": dom["ms_per_step"] / dom["launches_per_step"],
+            "gflop_per_launch": dom["gflop_per_step"] / dom["launches_per_step"],
+            "all_gemm": {"gflop_per_step": tot_gf, "gflop_per_image": tot_gf / B, "ms_per_step": tot_ms,
+                         "achieved": tot_gf / tot_ms if tot_ms else 0.0,
+                         "frac": (tot_gf / tot_ms) / PEAK_F32_MFMA_TFLOPS if tot_ms else 0.0,
+                         "share_of_step_ms": tot_ms / ms},
+            "eager_ms_per_step": eager_ms,
+            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]],
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_leg(engine, bt_cpu, engine.encode_batch_for_cpu(batch), B)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

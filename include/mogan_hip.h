@@ -46,6 +46,13 @@ int mogan_abi_version(void);
 /* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
 int mogan_gemm_debug_force(int cfg, int split);
 
+/* measurement hook (bench.py roofline leg): with profiling enabled every gemm_kernel launch is bracketed by
+ * HIP events on its own stream; collect() returns rows of 5 doubles {mode (0 fwd,1 dgrad,2 wgrad,3 bmm),
+ * tile config, launches, algorithmic flops = sum 2*M*N*K of the true GEMM dims, milliseconds} and the row count.
+ * Not for use under hipGraph capture. */
+int mogan_prof_enable(int on);
+int mogan_prof_collect(double* out, int max_rows);
+
 /* ---------------------------------------------------------------- convolution (fp32 MFMA implicit GEMM)
  * x (B,Cin,Hs,Ws), w (Cout,Cin,KH,KW), y (B,Cout,OH,OW), no bias.  up=1 fuses nn.Upsample(x2,nearest)
  * in front of the conv (upBlock, model.py:48-55): the conv then sees H=2Hs, W=2Ws.

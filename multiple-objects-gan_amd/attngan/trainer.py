@@ -169,6 +169,10 @@ class TrainEngine:
             mask = mask[:, :words_embs.size(2)]
         return words_embs.detach().contiguous(), sent_emb.detach().contiguous(), mask
 
+    def encode_batch_for_cpu(self, b):
+        w, s, m = self.encode_text(b["captions"], b["cap_lens_cpu"])
+        return {"words_embs": w, "sent_emb": s, "mask": m}
+
     def step(self, batch):
         """One train iteration on a device batch (see synthetic.make_batch for the fields)."""
         b = dict(batch)
@@ -228,6 +232,14 @@ class TrainEngine:
         for dst, src in zip(st["imgs"], b["imgs"]):
             dst.copy_(src)
         self._graph.replay()
+        if os.environ.get("MOGAN_GRAPH_SYNC"):
+            torch.cuda.synchronize()
+        if os.environ.get("MOGAN_GRAPH_NANCHECK"):
+            flags = [torch.isnan(o.p).any() for o in [self.optG] + self.optDs]
+            flags += [torch.isnan(o.g).any() for o in [self.optG] + self.optDs]
+            flags += [torch.isnan(st[k]).any() for k in ("z", "eps", "words_embs", "sent_emb", "tm", "tmi")]
+            flags += [torch.isnan(self._graph_out[k]).any() for k in ("fake64", "errD0", "g_loss0", "kl")]
+            self._nan_log = getattr(self, "_nan_log", []) + [torch.stack(flags)]
         self.last = self._graph_out
         return self.last
 
@@ -253,11 +265,11 @@ def build_networks(n_words=27297, device="cuda", image_encoder=None, seed=None):
         netsD.append(D_NET128())
     if cfg.TREE.BRANCH_NUM > 2:
         netsD.append(D_NET256())
-    netG.apply(weights_init)
-    for d in netsD:
-        d.apply(weights_init)
     text_encoder, image_encoder, netG = text_encoder.to(device), image_encoder.to(device), netG.to(device)
     netsD = [d.to(device) for d in netsD]
+    netG.apply(weights_init)              # on the device: orthogonal init of the 160M-parameter D256
+    for d in netsD:
+        d.apply(weights_init)
     return text_encoder, image_encoder, netG, netsD
 
 

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmogan_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-variable"]
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 
 
 def sources():

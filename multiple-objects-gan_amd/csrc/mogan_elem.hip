@@ -9,6 +9,16 @@
 namespace {
 
 static inline int ok_launch() { return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH; }
+
+// zero-fill as a kernel node (not hipMemsetAsync): memset nodes captured into a hipGraph were observed
+// to race with the atomics kernel that follows them on this ROCm (rare NaN gradients under replay)
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+static inline void zero_fill(float* p, size_t n, hipStream_t st) {
+    size_t b = (n + 255) / 256; if (b > 65536) b = 65536; if (b < 1) b = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)b), dim3(256), 0, st, p, n);
+}
 static inline unsigned nblk(long long n, int per = 256) {
     long long b = (n + per - 1) / per;
     return (unsigned)(b < 1 ? 1 : (b > 262144 ? 262144 : b));     // grid-stride beyond this
@@ -504,7 +514,7 @@ int mogan_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int O
 }
 int mogan_bilinear_bwd(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, hipStream_t stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
-    if (hipMemsetAsync(dx, 0, (size_t)planes * H * W * sizeof(float), stream) != hipSuccess) return MOGAN_ERR_LAUNCH;
+    zero_fill(dx, (size_t)planes * H * W, stream);
     const long long n = (long long)planes * OH * OW;
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW);
     return ok_launch();

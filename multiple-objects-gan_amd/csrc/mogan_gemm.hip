@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
+#include <mutex>
+#include <vector>
 #include "../../include/mogan_hip.h"
 
 namespace {
@@ -376,6 +378,13 @@ static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b;
 
 static int g_force_cfg = -1, g_force_split = 0;
 
+// Opt-in per-launch timing (bench.py roofline leg): HIP events on the launch stream around every
+// gemm_kernel launch + its algorithmic flops (2*M*N*K of the true, unpadded GEMM, all z-batches).
+struct ProfRec { int mode, cfg; double flops; hipEvent_t e0, e1; };
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+
 // Tile config: least padded MFMA work; ties -> larger tile.  Split-K: fill >= 2 waves of 256 CUs
 // when the tile grid alone cannot, keeping >= 128 of K per split.
 static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -408,11 +417,25 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     if (p.K <= 0) { p.kchunk = 32; p.nsplit = 1; }
     dim3 grid((unsigned)cdiv(p.N, bn), (unsigned)cdiv(p.M, bm), (unsigned)(nz * p.nsplit));
     if (grid.y > 65535 || grid.z > 65535) return MOGAN_ERR_SHAPE;
+    ProfRec rec{}; const bool prof = g_prof_on;
+    if (prof) {
+        rec.mode = mode; rec.cfg = best;
+        // DGRAD: p.N is the column count of parity class (0,0); all classes together cover B*H*W columns
+        const double ncols = mode == CONV_DGRAD ? (double)p.Bn * p.H * p.W : (double)p.N * nz;
+        rec.flops = 2.0 * (double)p.M * ncols * (double)p.K;
+        hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
+        hipEventRecord(rec.e0, st);
+    }
     switch (mode) {
         case CONV_FWD: launch_cfg<CONV_FWD>(best, grid, st, p); break;
         case CONV_DGRAD: launch_cfg<CONV_DGRAD>(best, grid, st, p); break;
         case CONV_WGRAD: launch_cfg<CONV_WGRAD>(best, grid, st, p); break;
         default: launch_cfg<BMM>(best, grid, st, p); break;
+    }
+    if (prof) {
+        hipEventRecord(rec.e1, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
     }
     if (p.nsplit > 1) {
         const long long nblk = cdiv(cdiv(c_numel, 4), 256);
@@ -443,6 +466,36 @@ static int conv_geom(GemmP& p, int B, int Cin, int Hs, int Ws, int Cout, int KH,
 extern "C" {
 
 int mogan_gemm_debug_force(int cfg, int split) { g_force_cfg = cfg; g_force_split = split; return 0; }
+
+int mogan_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+
+// out: rows of 5 doubles {mode, cfg, launches, algorithmic flops, milliseconds}, one per (mode,cfg) seen
+int mogan_prof_collect(double* out, int max_rows) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double acc[4][NCFG][3] = {};
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        acc[r.mode][r.cfg][0] += 1; acc[r.mode][r.cfg][1] += r.flops; acc[r.mode][r.cfg][2] += ms;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    int n = 0;
+    for (int m = 0; m < 4; ++m)
+        for (int c = 0; c < NCFG; ++c)
+            if (acc[m][c][0] > 0 && n < max_rows) {
+                double* o = out + 5 * n++;
+                o[0] = m; o[1] = c; o[2] = acc[m][c][0]; o[3] = acc[m][c][1]; o[4] = acc[m][c][2];
+            }
+    return n;
+}
 
 int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, int pw, int up, int* OH, int* OW) {
     if (stride <= 0) return MOGAN_ERR_SHAPE;

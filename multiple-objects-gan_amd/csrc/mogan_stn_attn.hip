@@ -17,6 +17,16 @@ namespace {
 
 static inline int ok_launch() { return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH; }
 
+// zero-fill as a kernel node (not hipMemsetAsync): memset nodes captured into a hipGraph were observed
+// to race with the atomics kernel that follows them on this ROCm (rare NaN gradients under replay)
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+static inline void zero_fill(float* p, size_t n, hipStream_t st) {
+    size_t b = (n + 255) / 256; if (b > 65536) b = 65536; if (b < 1) b = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)b), dim3(256), 0, st, p, n);
+}
+
 struct Taps { int x0, y0; float wx1, wy1; bool vx0, vx1, vy0, vy1; };
 
 __device__ __forceinline__ Taps stn_taps(const float* __restrict__ th, int oy, int ox, int Hin, int Win, int Hout,
@@ -206,7 +216,7 @@ int mogan_stn_fwd(const float* x, const float* theta, float* y, int B, int C, in
 int mogan_stn_bwd(const float* dy, const float* theta, float* dx, int B, int C, int Hin, int Win, int Hout,
                   int Wout, int align_corners, hipStream_t stream) {
     if (B <= 0 || C <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || B > 65535) return MOGAN_ERR_SHAPE;
-    if (hipMemsetAsync(dx, 0, (size_t)B * C * Hin * Win * sizeof(float), stream) != hipSuccess) return MOGAN_ERR_LAUNCH;
+    zero_fill(dx, (size_t)B * C * Hin * Win, stream);
     const int pb = (Hout * Wout + 255) / 256;
     int csplit = (1024 + pb * B - 1) / (pb * B); if (csplit > C) csplit = C; if (csplit < 1) csplit = 1;
     const int cchunk = (C + csplit - 1) / csplit; csplit = (C + cchunk - 1) / cchunk;

@@ -19,6 +19,8 @@ P, I, F, L, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 SIGNATURES = {
     "mogan_abi_version": [],
     "mogan_gemm_debug_force": [I, I],
+    "mogan_prof_enable": [I],
+    "mogan_prof_collect": [P, I],
     "mogan_conv2d_out_dims": [I, I, I, I, I, I, I, I, P, P],
     "mogan_conv2d_fwd": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],

@@ -233,13 +233,19 @@ def test_two_train_steps(use_graph):
             np.testing.assert_allclose(float(logs[k]), float(g[p + k]), rtol=1e-4 * (1 + 9 * step), err_msg=k)
         np.testing.assert_allclose(float(logs["errG"]), float(g[p + "errG"]), rtol=2e-4 * (1 + 9 * step))
         close(logs["fake64"], g[p + "fake64"], 2e-4 * (1 + 9 * step), 1e-3)
-        tol = 1e-4 if step == 0 else 1e-3
+        # Adam's first steps move every element by ~lr*sign(g): where |g| is at the fp32 noise floor the
+        # sign is not reproducible, which shows on the tiny 1-D tensors (a 12-element BN
+        # bias of magnitude 0.1 moves by up to 2*lr per step) -> looser checksum tolerance for those
+        def tol_of(v):
+            big = v.dim() > 1
+            return (1e-4 if big else 1e-3) if step == 0 else (1e-3 if big else 5e-3)
         for k, v in G.state_dict().items():
             if v.is_floating_point():
-                probe_close(probe(v), g[p + "G_" + k.replace(".", "__")], tol, what="G " + k)
+                probe_close(probe(v), g[p + "G_" + k.replace(".", "__")], tol_of(v), what="G " + k)
         for i, D in enumerate(Ds):
             for k, v in D.state_dict().items():
                 if v.is_floating_point():
-                    probe_close(probe(v), g["%sD%d_%s" % (p, i, k.replace(".", "__"))], tol, what="D%d %s" % (i, k))
+                    probe_close(probe(v), g["%sD%d_%s" % (p, i, k.replace(".", "__"))], tol_of(v),
+                                what="D%d %s" % (i, k))
         for (k, _), a in zip(G.named_parameters(), eng.optG.ema_params()):
-            probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], tol, what="ema " + k)
+            probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], 1e-4, what="ema " + k)

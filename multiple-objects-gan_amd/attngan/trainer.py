@@ -80,6 +80,23 @@ class FlatAdam:
         self.v.copy_(sd["exp_avg_sq"])
 
 
+def allreduce_flat(flat_g, comm_stream=None):
+    """Sum all-reduce of one flat gradient bucket over the default process group (RCCL on GPUs, gloo in
+    the CPU tests).  With a side stream the collective is ordered after the work already queued on the
+    current stream and an event is returned for the consumer (the bucket's Adam) to wait on."""
+    if comm_stream is None:
+        dist.all_reduce(flat_g)
+        return None
+    ev = torch.cuda.Event()
+    ev.record()
+    comm_stream.wait_event(ev)
+    with torch.cuda.stream(comm_stream):
+        dist.all_reduce(flat_g)
+        done = torch.cuda.Event()
+        done.record()
+    return done
+
+
 class TrainEngine:
     """Device-side state of one rank: networks, flat optimizers, DP communicator, optional hipGraph."""
 
@@ -100,14 +117,7 @@ class TrainEngine:
     def _allreduce_async(self, flat):
         if not self.distributed:
             return None
-        ev = torch.cuda.Event()
-        ev.record()
-        self.comm_stream.wait_event(ev)
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(flat.g)
-            done = torch.cuda.Event()
-            done.record()
-        return done
+        return allreduce_flat(flat.g, self.comm_stream)
 
     def _opt_step(self, flat, pending):
         if pending is not None:

@@ -95,6 +95,9 @@ def stream_ptr():
 
 def workspace(device):
     """Persistent split-K / reduction scratch per (device, stream)."""
+    if device.type != "cuda":
+        raise MoganHipError("mogan_hip ops need tensors on the GPU (got device %s): there is no CPU "
+                            "path in the product" % device)
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)

@@ -52,6 +52,8 @@ int mogan_gemm_debug_force(int cfg, int split);
  * Not for use under hipGraph capture. */
 int mogan_prof_enable(int on);
 int mogan_prof_collect(double* out, int max_rows);
+/* same records as one CSV row per launch (geometry, algorithmic GFLOP, ms); consumes them */
+int mogan_prof_dump(const char* path);
 
 /* ---------------------------------------------------------------- convolution (fp32 MFMA implicit GEMM)
  * x (B,Cin,Hs,Ws), w (Cout,Cin,KH,KW), y (B,Cout,OH,OW), no bias.  up=1 fuses nn.Upsample(x2,nearest)

@@ -66,7 +66,16 @@ struct GemmP {
     // bmm strides (elements)
     long long sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn;
     int a_lane_k, b_lane_n;
+    unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (< 4 GiB)
 };
+
+// branch-free guarded load: out-of-range byte offsets return 0 from the buffer unit (no exec-mask branches)
+__device__ __forceinline__ float ldg(__amdgpu_buffer_rsrc_t r, unsigned idx, bool ok) {
+    const unsigned off = ok ? idx * 4u : 0xFFFFFFFCu;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+#define KH_BAD (0x4000 << 16)   // decode entry whose tap index is far out of range -> the bounds test fails
 
 template <int MODE, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
@@ -74,8 +83,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     constexpr int LDA = BK + 1, LDB = BN + 1;
     constexpr int NA = BM * BK / 256, NB = BK * BN / 256;
     static_assert(WM * WN == 4, "4 waves per block");
-    __shared__ float As[BM * LDA];
-    __shared__ float Bs[BK * LDB];
+    __shared__ float As[2][BM * LDA];
+    __shared__ float Bs[2][BK * LDB];
+    __shared__ int Kt[2][3][BK];     // per-K-tile decode of k (conv fwd / dgrad), double buffered
+    __shared__ int Nt[2][BN];        // per-block decode of the column n (conv wgrad)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -84,16 +95,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int kbeg = sp * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
-    const float* __restrict__ Ag = p.A;
-    const float* __restrict__ Bg = p.B;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)p.b_bytes, 0x00020000);
     const int OHW = p.OH * p.OW, HsWs = p.Hs * p.Ws, KHW = p.KH * p.KW;
 
-    // ---- per-thread, tile-invariant decode of the column/row this thread stages -------------
-    // FWD/DGRAD: the thread stages one fixed n (lanes run along n); WGRAD/BMM see below.
-    int Ncls = p.N;                 // DGRAD: columns of this parity class
+    // ---- per-thread, tile-invariant decode -------------------------------------------------
+    int Ncls = p.N;
     int py = 0, px = 0, Hc = 0, Wc = 0, kh0 = 0, kw0 = 0;
-    bool nvalid = false; int nb_base = 0, niy0 = 0, nix0 = 0;   // FWD
-    int dg_img = 0, dg_oyb = 0, dg_oxb = 0;                      // DGRAD
+    bool nvalid = false; unsigned nb_base = 0; int niy0 = 0, nix0 = 0;
+    unsigned dg_base = 0; int dg_oyb = 0, dg_oxb = 0;
     if constexpr (MODE == CONV_DGRAD) {
         py = zb / p.s; px = zb % p.s;
         Hc = (p.H - py + p.s - 1) / p.s; Wc = (p.W - px + p.s - 1) / p.s;
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         const int img = nn / OHW, pix = nn - img * OHW;
         const int oy = pix / p.OW, ox = pix - oy * p.OW;
         niy0 = oy * p.s - p.ph; nix0 = ox * p.s - p.pw;
-        nb_base = img * p.Cin * HsWs;
+        nb_base = (unsigned)img * p.Cin * HsWs;
     }
     if constexpr (MODE == CONV_DGRAD) {
         const int n = n0 + (tid % BN);
@@ -117,14 +127,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         const int hw = Hc * Wc;
         const int img = nn / hw, rem = nn - img * hw;
         const int yc = rem / Wc, xc = rem - yc * Wc;
-        dg_img = img;
+        dg_base = (unsigned)img * p.Cout * OHW;
         dg_oyb = (yc * p.s + py + p.ph - kh0) / p.s;      // exact
         dg_oxb = (xc * p.s + px + p.pw - kw0) / p.s;
     }
+    if constexpr (MODE == CONV_WGRAD) {
+        for (int j = tid; j < BN; j += 256) {
+            const int n = n0 + j;
+            const uint32_t ci = fdiv(n, p.fd_khw);
+            const uint32_t r = n - ci * KHW;
+            const uint32_t kh = fdiv(r, p.fd_kw), kw = r - kh * p.KW;
+            Nt[0][j] = ci * HsWs;
+            Nt[1][j] = n < p.N ? (int)((kh << 16) | kw) : KH_BAD;
+        }
+    }
+
+    // decode of one k of a K-tile into the LDS table (all 8 lane-groups write identical values)
+    auto decode_k = [&](int kt, int buf) {
+        if constexpr (MODE == CONV_FWD) {
+            const int j = tid & 31, k = kt + j;
+            const uint32_t ci = fdiv(k, p.fd_khw);
+            const uint32_t r = k - ci * KHW;
+            const uint32_t kh = fdiv(r, p.fd_kw), kw = r - kh * p.KW;
+            Kt[buf][0][j] = ci * HsWs;
+            Kt[buf][1][j] = k < kend ? (int)((kh << 16) | kw) : KH_BAD;
+        } else if constexpr (MODE == CONV_DGRAD) {
+            const int j = tid & 31, k = kt + j;
+            const uint32_t co = fdiv(k, p.fd_nk);
+            const uint32_t r = k - co * (p.nkh * p.nkw);
+            const uint32_t khp = fdiv(r, p.fd_nkw), kwp = r - khp * p.nkw;
+            const int kh = kh0 + khp * p.s, kw = kw0 + kwp * p.s;
+            const bool ok = k < kend && kh < p.KH && kw < p.KW;
+            Kt[buf][0][j] = co * OHW;
+            Kt[buf][1][j] = ok ? (int)((khp << 16) | kwp) : KH_BAD;
+            Kt[buf][2][j] = ok ? (int)(co * p.Cin * KHW + kh * p.KW + kw) : -1;
+        }
+    };
 
     float ra[NA], rb[NB];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, int buf) {
         // ------------------------------------------------ A tile -> ra
         if constexpr (MODE == CONV_FWD) {
             const int k = kt + (tid & 31);
@@ -132,130 +174,117 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int m = m0 + (tid >> 5) + 8 * i;
-                ra[i] = (kok && m < p.M) ? Ag[(size_t)m * p.K + k] : 0.f;
+                ra[i] = ldg(rA, (unsigned)m * p.K + k, kok && m < p.M);
             }
         } else if constexpr (MODE == CONV_DGRAD) {
-            // A[m=ci][k=(co,khp,kwp)] = W[co][ci][kh0+khp*s][kw0+kwp*s]; lanes run along ci
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int e = tid + 256 * i;
                 const int m = m0 + (e % BM);
-                const bool mok = m < p.M;
-                const int k = kt + e / BM;
-                const uint32_t co = fdiv(k, p.fd_nk);
-                const uint32_t r = k - co * (p.nkh * p.nkw);
-                const uint32_t khp = fdiv(r, p.fd_nkw), kwp = r - khp * p.nkw;
-                const int kh = kh0 + khp * p.s, kw = kw0 + kwp * p.s;
-                const bool ok = mok && k < kend && kh < p.KH && kw < p.KW;
-                ra[i] = ok ? Ag[((size_t)co * p.Cin + m) * KHW + kh * p.KW + kw] : 0.f;
+                const int w = Kt[buf][2][e / BM];
+                ra[i] = ldg(rA, (unsigned)w + (unsigned)m * KHW, m < p.M && w >= 0);
             }
         } else if constexpr (MODE == CONV_WGRAD) {
             const int k = kt + (tid & 31);
             const bool kok = k < kend;
             const uint32_t kk = kok ? k : 0;
             const uint32_t img = fdiv(kk, p.fd_ohw), pix = kk - img * OHW;
+            const unsigned ab = img * p.Cout * OHW + pix;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int m = m0 + (tid >> 5) + 8 * i;
-                ra[i] = (kok && m < p.M) ? Ag[((size_t)img * p.Cout + m) * OHW + pix] : 0.f;
+                ra[i] = ldg(rA, ab + (unsigned)m * OHW, kok && m < p.M);
             }
         } else {
-            const float* Ab = Ag + (size_t)zb * p.sAb;
+            const unsigned ab = (unsigned)zb * (unsigned)p.sAb;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int e = tid + 256 * i;
                 const int ml = p.a_lane_k ? (e >> 5) : (e % BM);
                 const int kl = p.a_lane_k ? (e & 31) : (e / BM);
                 const int m = m0 + ml, k = kt + kl;
-                ra[i] = (m < p.M && k < kend) ? Ab[(size_t)m * p.sAm + (size_t)k * p.sAk] : 0.f;
+                ra[i] = ldg(rA, ab + (unsigned)m * (unsigned)p.sAm + (unsigned)k * (unsigned)p.sAk, m < p.M && k < kend);
             }
         }
         // ------------------------------------------------ B tile -> rb
         if constexpr (MODE == CONV_FWD) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int k = kt + tid / BN + (256 / BN) * i;
-                const uint32_t ci = fdiv(k, p.fd_khw);
-                const uint32_t r = k - ci * KHW;
-                const uint32_t kh = fdiv(r, p.fd_kw), kw = r - kh * p.KW;
-                const int iy = niy0 + (int)kh, ix = nix0 + (int)kw;
-                const bool ok = nvalid && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[i] = ok ? Bg[(size_t)nb_base + (size_t)ci * HsWs + (iy >> p.up) * p.Ws + (ix >> p.up)] : 0.f;
+                const int kl = tid / BN + (256 / BN) * i;
+                const int e0 = Kt[buf][0][kl], e1 = Kt[buf][1][kl];
+                const int iy = niy0 + (e1 >> 16), ix = nix0 + (e1 & 0xFFFF);
+                const bool ok = nvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[i] = ldg(rB, nb_base + e0 + (iy >> p.up) * p.Ws + (ix >> p.up), ok);
             }
         } else if constexpr (MODE == CONV_DGRAD) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int k = kt + tid / BN + (256 / BN) * i;
-                const uint32_t co = fdiv(k, p.fd_nk);
-                const uint32_t r = k - co * (p.nkh * p.nkw);
-                const uint32_t khp = fdiv(r, p.fd_nkw), kwp = r - khp * p.nkw;
-                const int kh = kh0 + khp * p.s, kw = kw0 + kwp * p.s;
-                const int oy = dg_oyb - (int)khp, ox = dg_oxb - (int)kwp;
-                const bool ok = nvalid && k < kend && kh < p.KH && kw < p.KW &&
-                                (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
-                rb[i] = ok ? Bg[(((size_t)dg_img * p.Cout + co) * p.OH + oy) * p.OW + ox] : 0.f;
+                const int kl = tid / BN + (256 / BN) * i;
+                const int e0 = Kt[buf][0][kl], e1 = Kt[buf][1][kl];
+                const int oy = dg_oyb - (e1 >> 16), ox = dg_oxb - (e1 & 0xFFFF);
+                const bool ok = nvalid && (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
+                rb[i] = ldg(rB, dg_base + e0 + oy * p.OW + ox, ok);
             }
         } else if constexpr (MODE == CONV_WGRAD) {
-            // B[k=(img,oy,ox)][n=(ci,kh,kw)]; lanes run along k (pixels)
             const int k = kt + (tid & 31);
             const bool kok = k < kend;
             const uint32_t kk = kok ? k : 0;
             const uint32_t img = fdiv(kk, p.fd_ohw), pix = kk - img * OHW;
             const uint32_t oy = fdiv(pix, p.fd_ow), ox = pix - oy * p.OW;
             const int iy0 = (int)oy * p.s - p.ph, ix0 = (int)ox * p.s - p.pw;
-            const size_t xb = (size_t)img * p.Cin * HsWs;
+            const unsigned xb = img * p.Cin * HsWs;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int n = n0 + (tid >> 5) + 8 * i;
-                const uint32_t ci = fdiv(n, p.fd_khw);
-                const uint32_t r = n - ci * KHW;
-                const uint32_t kh = fdiv(r, p.fd_kw), kw = r - kh * p.KW;
-                const int iy = iy0 + (int)kh, ix = ix0 + (int)kw;
-                const bool ok = kok && n < p.N && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[i] = ok ? Bg[xb + (size_t)ci * HsWs + (iy >> p.up) * p.Ws + (ix >> p.up)] : 0.f;
+                const int nl = (tid >> 5) + 8 * i;
+                const int e0 = Nt[0][nl], e1 = Nt[1][nl];
+                const int iy = iy0 + (e1 >> 16), ix = ix0 + (e1 & 0xFFFF);
+                const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[i] = ldg(rB, xb + e0 + (iy >> p.up) * p.Ws + (ix >> p.up), ok);
             }
         } else {
-            const float* Bb = Bg + (size_t)zb * p.sBb;
+            const unsigned bb = (unsigned)zb * (unsigned)p.sBb;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int e = tid + 256 * i;
                 const int nl = p.b_lane_n ? (e % BN) : (e >> 5);
                 const int kl = p.b_lane_n ? (e / BN) : (e & 31);
                 const int n = n0 + nl, k = kt + kl;
-                rb[i] = (n < p.N && k < kend) ? Bb[(size_t)k * p.sBk + (size_t)n * p.sBn] : 0.f;
+                rb[i] = ldg(rB, bb + (unsigned)k * (unsigned)p.sBk + (unsigned)n * (unsigned)p.sBn, n < p.N && k < kend);
             }
         }
     };
 
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        float* as = As[buf];
+        float* bs = Bs[buf];
         if constexpr (MODE == CONV_FWD || MODE == CONV_WGRAD) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) As[((tid >> 5) + 8 * i) * LDA + (tid & 31)] = ra[i];
+            for (int i = 0; i < NA; ++i) as[((tid >> 5) + 8 * i) * LDA + (tid & 31)] = ra[i];
         } else if constexpr (MODE == CONV_DGRAD) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) { const int e = tid + 256 * i; As[(e % BM) * LDA + e / BM] = ra[i]; }
+            for (int i = 0; i < NA; ++i) { const int e = tid + 256 * i; as[(e % BM) * LDA + e / BM] = ra[i]; }
         } else {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int e = tid + 256 * i;
                 const int ml = p.a_lane_k ? (e >> 5) : (e % BM);
                 const int kl = p.a_lane_k ? (e & 31) : (e / BM);
-                As[ml * LDA + kl] = ra[i];
+                as[ml * LDA + kl] = ra[i];
             }
         }
         if constexpr (MODE == CONV_FWD || MODE == CONV_DGRAD) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) Bs[(tid / BN + (256 / BN) * i) * LDB + (tid % BN)] = rb[i];
+            for (int i = 0; i < NB; ++i) bs[(tid / BN + (256 / BN) * i) * LDB + (tid % BN)] = rb[i];
         } else if constexpr (MODE == CONV_WGRAD) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) Bs[(tid & 31) * LDB + (tid >> 5) + 8 * i] = rb[i];
+            for (int i = 0; i < NB; ++i) bs[(tid & 31) * LDB + (tid >> 5) + 8 * i] = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int e = tid + 256 * i;
                 const int nl = p.b_lane_n ? (e % BN) : (e >> 5);
                 const int kl = p.b_lane_n ? (e / BN) : (e & 31);
-                Bs[kl * LDB + nl] = rb[i];
+                bs[kl * LDB + nl] = rb[i];
             }
         }
     };
@@ -271,28 +300,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int arow = (wm * TM * 32 + (lane & 31)) * LDA + (lane >> 5);
     const int bcol = (lane >> 5) * LDB + wn * TN * 32 + (lane & 31);
 
-    if (kbeg < kend) {
-        load_tile(kbeg);
-        store_tile();
+    // ---- main loop: one barrier per K-tile, LDS double buffered; the gathers of tile t+1 are
+    //      issued before the MFMAs of tile t and land in LDS after them (branch-free body) ----------
+    const int ntile = (kend - kbeg + BK - 1) / BK;
+    if (ntile > 0) {
+        decode_k(kbeg, 0);
         __syncthreads();
-        for (int kt = kbeg; kt < kend; kt += BK) {
-            const bool more = kt + BK < kend;
-            if (more) load_tile(kt + BK);
+        load_tile(kbeg, 0);
+        decode_k(kbeg + BK, 1);
+        store_tile(0);
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            const int cur = t & 1, kt = kbeg + t * BK;
+            load_tile(kt + BK, cur ^ 1);                 // past kend: every element is masked to 0
+            decode_k(kt + 2 * BK, cur);                  // table `cur` was last read while loading tile t
+            const float* as = As[cur] + arow;
+            const float* bs = Bs[cur] + bcol;
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 float a[TM], b[TN];
 #pragma unroll
-                for (int t = 0; t < TM; ++t) a[t] = As[arow + t * 32 * LDA + kk * 2];
+                for (int q = 0; q < TM; ++q) a[q] = as[q * 32 * LDA + kk * 2];
 #pragma unroll
-                for (int t = 0; t < TN; ++t) b[t] = Bs[bcol + kk * 2 * LDB + t * 32];
+                for (int q = 0; q < TN; ++q) b[q] = bs[kk * 2 * LDB + q * 32];
 #pragma unroll
                 for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < TN; ++tb)
                         acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
             }
+            store_tile(cur ^ 1);                         // buffer cur^1 was last read in iteration t-1
             __syncthreads();
-            if (more) { store_tile(); __syncthreads(); }
         }
     }
 
@@ -380,7 +418,7 @@ static int g_force_cfg = -1, g_force_split = 0;
 
 // Opt-in per-launch timing (bench.py roofline leg): HIP events on the launch stream around every
 // gemm_kernel launch + its algorithmic flops (2*M*N*K of the true, unpadded GEMM, all z-batches).
-struct ProfRec { int mode, cfg; double flops; hipEvent_t e0, e1; };
+struct ProfRec { int mode, cfg; double flops; hipEvent_t e0, e1; int M, N, K, nz, nsplit, Cin, Cout, H, W, KH, KW, s, up, Bn; };
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -420,6 +458,8 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     ProfRec rec{}; const bool prof = g_prof_on;
     if (prof) {
         rec.mode = mode; rec.cfg = best;
+        rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.nz = nz; rec.nsplit = p.nsplit; rec.Cin = p.Cin; rec.Cout = p.Cout;
+        rec.H = p.H; rec.W = p.W; rec.KH = p.KH; rec.KW = p.KW; rec.s = p.s; rec.up = p.up; rec.Bn = p.Bn;
         // DGRAD: p.N is the column count of parity class (0,0); all classes together cover B*H*W columns
         const double ncols = mode == CONV_DGRAD ? (double)p.Bn * p.H * p.W : (double)p.N * nz;
         rec.flops = 2.0 * (double)p.M * ncols * (double)p.K;
@@ -456,7 +496,8 @@ static int conv_geom(GemmP& p, int B, int Cin, int Hs, int Ws, int Cout, int KH,
     p.fd_khw = make_fd(KH * KW); p.fd_kw = make_fd(KW);
     p.nkh = (KH + s - 1) / s; p.nkw = (KW + s - 1) / s;
     p.fd_nk = make_fd(p.nkh * p.nkw); p.fd_nkw = make_fd(p.nkw);
-    if ((long long)B * Cin * p.H * p.W >= (1ll << 31) || (long long)B * Cout * p.OH * p.OW >= (1ll << 31))
+    if ((long long)B * Cin * p.H * p.W >= (1ll << 30) || (long long)B * Cout * p.OH * p.OW >= (1ll << 30) ||
+        (long long)Cout * Cin * KH * KW >= (1ll << 30))
         return MOGAN_ERR_SHAPE;
     return 0;
 }
@@ -472,6 +513,25 @@ int mogan_prof_enable(int on) {
     for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     g_prof.clear();
     g_prof_on = on != 0;
+    return 0;
+}
+
+// per-launch CSV (tools/profile_layers.py): consumes the records like mogan_prof_collect
+int mogan_prof_dump(const char* path) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    FILE* f = fopen(path, "w");
+    if (!f) return MOGAN_ERR_SHAPE;
+    fprintf(f, "mode,cfg,M,N,K,nz,nsplit,B,Cin,Cout,H,W,KH,KW,stride,up,gflop,ms\n");
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.6f,%.6f\n", r.mode, r.cfg, r.M, r.N, r.K, r.nz, r.nsplit,
+                r.Bn, r.Cin, r.Cout, r.H, r.W, r.KH, r.KW, r.s, r.up, r.flops / 1e9, ms);
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    fclose(f);
     return 0;
 }
 
@@ -508,6 +568,7 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
                      int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
+    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
 }
 
@@ -516,6 +577,7 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     // dx is the gradient w.r.t. the conv input in the (upsampled) H x W domain: (B,Cin,H,W)
     p.A = w; p.B = dy; p.C = dx; p.M = Cin; p.K = Cout * p.nkh * p.nkw; p.accumulate = 0;
+    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cout * p.OH * p.OW;
     const int Hc = (p.H + stride - 1) / stride, Wc = (p.W + stride - 1) / stride;
     p.N = B * Hc * Wc;   // class (0,0) has the most columns
     return run_gemm(CONV_DGRAD, p, stride * stride, (long long)B * Cin * p.H * p.W, ws, ws_bytes, stream);
@@ -526,6 +588,7 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
                        hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     p.A = dy; p.B = x; p.C = dw; p.M = Cout; p.N = Cin * KH * KW; p.K = B * p.OH * p.OW; p.accumulate = accumulate;
+    p.a_bytes = 4u * B * Cout * p.OH * p.OW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     return run_gemm(CONV_WGRAD, p, 1, (long long)Cout * Cin * KH * KW, ws, ws_bytes, stream);
 }
 
@@ -535,6 +598,11 @@ int mogan_bmm(const float* a, const float* b, float* c, int batch, int M, int N,
     if (batch <= 0 || M < 0 || N < 0 || K < 0) return MOGAN_ERR_SHAPE;
     GemmP p{};
     p.A = a; p.B = b; p.C = c; p.M = M; p.N = N; p.K = K; p.accumulate = accumulate;
+    if (sAb < 0 || sAm < 0 || sAk < 0 || sBb < 0 || sBk < 0 || sBn < 0) return MOGAN_ERR_SHAPE;
+    const long long ea = 1 + (long long)(batch - 1) * sAb + (long long)(M > 0 ? M - 1 : 0) * sAm + (long long)(K > 0 ? K - 1 : 0) * sAk;
+    const long long eb = 1 + (long long)(batch - 1) * sBb + (long long)(K > 0 ? K - 1 : 0) * sBk + (long long)(N > 0 ? N - 1 : 0) * sBn;
+    if (ea >= (1ll << 30) || eb >= (1ll << 30)) return MOGAN_ERR_SHAPE;
+    p.a_bytes = (unsigned)(4 * ea); p.b_bytes = (unsigned)(4 * eb);
     p.sAb = sAb; p.sAm = sAm; p.sAk = sAk; p.sBb = sBb; p.sBk = sBk; p.sBn = sBn; p.sCb = sCb; p.sCm = sCm; p.sCn = sCn;
     p.a_lane_k = (sAk <= sAm); p.b_lane_n = (sBn <= sBk);
     p.OH = p.OW = p.Hs = p.Ws = p.KH = p.KW = p.s = 1;

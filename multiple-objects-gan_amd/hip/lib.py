@@ -21,6 +21,7 @@ SIGNATURES = {
     "mogan_gemm_debug_force": [I, I],
     "mogan_prof_enable": [I],
     "mogan_prof_collect": [P, I],
+    "mogan_prof_dump": [ctypes.c_char_p],
     "mogan_conv2d_out_dims": [I, I, I, I, I, I, I, I, P, P],
     "mogan_conv2d_fwd": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],

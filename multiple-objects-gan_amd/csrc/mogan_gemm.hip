@@ -77,16 +77,19 @@ __device__ __forceinline__ float ldg(__amdgpu_buffer_rsrc_t r, unsigned idx, boo
 
 #define KH_BAD (0x4000 << 16)   // decode entry whose tap index is far out of range -> the bounds test fails
 
+// LDS images: As[m][k], Bs[n][k], row stride LD = BK+4 floats (144 B): fragment reads are 4 x ds_read_b128
+// per 32-row tile (bank-conflict free at this stride), staging writes are ds_write_b128 of 4 consecutive k.
+// MFMA k assignment inside a K-tile: lane half h = lane>>5 owns k in [16h, 16h+16); step kk uses k = 16h+kk.
 template <int MODE, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32;
-    constexpr int LDA = BK + 1, LDB = BN + 1;
-    constexpr int NA = BM * BK / 256, NB = BK * BN / 256;
+    constexpr bool SCHED = true;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, LD = BK + 4;
+    constexpr int QA = BM / 32, QB = BN / 32;            // quads (4 consecutive k of one row) per thread
     static_assert(WM * WN == 4, "4 waves per block");
-    __shared__ float As[2][BM * LDA];
-    __shared__ float Bs[2][BK * LDB];
-    __shared__ int Kt[2][3][BK];     // per-K-tile decode of k (conv fwd / dgrad), double buffered
-    __shared__ int Nt[2][BN];        // per-block decode of the column n (conv wgrad)
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    __shared__ __attribute__((aligned(16))) int Kt[2][3][BK];   // per-K-tile decode of k (conv fwd / dgrad)
+    __shared__ __attribute__((aligned(16))) int Nt[2][BN];      // per-block decode of the column n (conv wgrad)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -99,11 +102,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)p.b_bytes, 0x00020000);
     const int OHW = p.OH * p.OW, HsWs = p.Hs * p.Ws, KHW = p.KH * p.KW;
 
+    // staging maps.  k-fast: 8 lanes cover the 32 k of one row (memory contiguous along k);
+    // row-fast: lanes run along the rows (memory contiguous along the rows: pixels)
+    constexpr bool A_KFAST_C = (MODE == CONV_FWD || MODE == CONV_WGRAD);
+    constexpr bool B_KFAST_C = (MODE == CONV_WGRAD);
+    const bool a_kfast = (MODE == BMM) ? (p.a_lane_k != 0) : A_KFAST_C;
+    const bool b_kfast = (MODE == BMM) ? (p.b_lane_n == 0) : B_KFAST_C;
+
     // ---- per-thread, tile-invariant decode -------------------------------------------------
     int Ncls = p.N;
     int py = 0, px = 0, Hc = 0, Wc = 0, kh0 = 0, kw0 = 0;
-    bool nvalid = false; unsigned nb_base = 0; int niy0 = 0, nix0 = 0;
-    unsigned dg_base = 0; int dg_oyb = 0, dg_oxb = 0;
     if constexpr (MODE == CONV_DGRAD) {
         py = zb / p.s; px = zb % p.s;
         Hc = (p.H - py + p.s - 1) / p.s; Wc = (p.W - px + p.s - 1) / p.s;
@@ -111,25 +119,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         if (n0 >= Ncls) return;     // block-uniform
         kh0 = (py + p.ph) % p.s; kw0 = (px + p.pw) % p.s;
     }
+    // FWD / DGRAD: the QB rows (pixels) this thread stages are fixed: decode them once
+    bool nvalid[QB]; unsigned nbase[QB]; int ny0[QB], nx0[QB];
     if constexpr (MODE == CONV_FWD) {
-        const int n = n0 + (tid % BN);
-        nvalid = n < p.N;
-        const int nn = nvalid ? n : 0;
-        const int img = nn / OHW, pix = nn - img * OHW;
-        const int oy = pix / p.OW, ox = pix - oy * p.OW;
-        niy0 = oy * p.s - p.ph; nix0 = ox * p.s - p.pw;
-        nb_base = (unsigned)img * p.Cin * HsWs;
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            const int n = n0 + (tid + 256 * i) % BN;
+            nvalid[i] = n < p.N;
+            const int nn = nvalid[i] ? n : 0;
+            const int img = nn / OHW, pix = nn - img * OHW;
+            const int oy = pix / p.OW, ox = pix - oy * p.OW;
+            ny0[i] = oy * p.s - p.ph; nx0[i] = ox * p.s - p.pw;
+            nbase[i] = (unsigned)img * p.Cin * HsWs;
+        }
     }
     if constexpr (MODE == CONV_DGRAD) {
-        const int n = n0 + (tid % BN);
-        nvalid = n < Ncls;
-        const int nn = nvalid ? n : 0;
-        const int hw = Hc * Wc;
-        const int img = nn / hw, rem = nn - img * hw;
-        const int yc = rem / Wc, xc = rem - yc * Wc;
-        dg_base = (unsigned)img * p.Cout * OHW;
-        dg_oyb = (yc * p.s + py + p.ph - kh0) / p.s;      // exact
-        dg_oxb = (xc * p.s + px + p.pw - kw0) / p.s;
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            const int n = n0 + (tid + 256 * i) % BN;
+            nvalid[i] = n < Ncls;
+            const int nn = nvalid[i] ? n : 0;
+            const int hw = Hc * Wc;
+            const int img = nn / hw, rem = nn - img * hw;
+            const int yc = rem / Wc, xc = rem - yc * Wc;
+            nbase[i] = (unsigned)img * p.Cout * OHW;
+            ny0[i] = (yc * p.s + py + p.ph - kh0) / p.s;      // exact
+            nx0[i] = (xc * p.s + px + p.pw - kw0) / p.s;
+        }
     }
     if constexpr (MODE == CONV_WGRAD) {
         for (int j = tid; j < BN; j += 256) {
@@ -164,128 +180,101 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         }
     };
 
-    float ra[NA], rb[NB];
+    float ra[QA][4], rb[QB][4];
+    constexpr int NEA = QA * 4, NEB = QB * 4, NE = NEA + NEB;     // elements staged per thread per K-tile
+    constexpr int NSL = 16;                                       // slices: the first NSL of the 16 k-steps carry
+    constexpr int EPS = (NE + NSL - 1) / NSL;                     // the gather, the rest cover the load latency
 
-    auto load_tile = [&](int kt, int buf) {
-        // ------------------------------------------------ A tile -> ra
-        if constexpr (MODE == CONV_FWD) {
-            const int k = kt + (tid & 31);
-            const bool kok = k < kend;
+    // per-quad / per-tile decode kept in registers between the element slices
+    int4 qe0[QB], qe1[QB], qw[QA];
+    unsigned wg_ab[4], wg_xb[4]; int wg_iy0[4], wg_ix0[4]; bool wg_ok[4];
+    int wg_e0[QB], wg_e1[QB];
+
+    // stage ONE element e of the next K-tile (kt) into ra/rb; e is a compile-time constant after unrolling
+    auto stage_elem = [&](int e, int kt, int buf) {
+        const bool isA = e < NEA;
+        const int i = isA ? e / 4 : (e - NEA) / 4, j = e & 3;
+        if constexpr (MODE == CONV_WGRAD) {
+            if (e == 0) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int m = m0 + (tid >> 5) + 8 * i;
-                ra[i] = ldg(rA, (unsigned)m * p.K + k, kok && m < p.M);
-            }
-        } else if constexpr (MODE == CONV_DGRAD) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int e = tid + 256 * i;
-                const int m = m0 + (e % BM);
-                const int w = Kt[buf][2][e / BM];
-                ra[i] = ldg(rA, (unsigned)w + (unsigned)m * KHW, m < p.M && w >= 0);
-            }
-        } else if constexpr (MODE == CONV_WGRAD) {
-            const int k = kt + (tid & 31);
-            const bool kok = k < kend;
-            const uint32_t kk = kok ? k : 0;
-            const uint32_t img = fdiv(kk, p.fd_ohw), pix = kk - img * OHW;
-            const unsigned ab = img * p.Cout * OHW + pix;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int m = m0 + (tid >> 5) + 8 * i;
-                ra[i] = ldg(rA, ab + (unsigned)m * OHW, kok && m < p.M);
-            }
-        } else {
-            const unsigned ab = (unsigned)zb * (unsigned)p.sAb;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int e = tid + 256 * i;
-                const int ml = p.a_lane_k ? (e >> 5) : (e % BM);
-                const int kl = p.a_lane_k ? (e & 31) : (e / BM);
-                const int m = m0 + ml, k = kt + kl;
-                ra[i] = ldg(rA, ab + (unsigned)m * (unsigned)p.sAm + (unsigned)k * (unsigned)p.sAk, m < p.M && k < kend);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int k = kt + 4 * (tid & 7) + jj;
+                    wg_ok[jj] = k < kend;
+                    const uint32_t kk = wg_ok[jj] ? k : 0;
+                    const uint32_t img = fdiv(kk, p.fd_ohw), pix = kk - img * OHW;
+                    const uint32_t oy = fdiv(pix, p.fd_ow), ox = pix - oy * p.OW;
+                    wg_iy0[jj] = (int)oy * p.s - p.ph; wg_ix0[jj] = (int)ox * p.s - p.pw;
+                    wg_xb[jj] = img * p.Cin * HsWs;
+                    wg_ab[jj] = img * p.Cout * OHW + pix;
+                }
             }
         }
-        // ------------------------------------------------ B tile -> rb
-        if constexpr (MODE == CONV_FWD) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int kl = tid / BN + (256 / BN) * i;
-                const int e0 = Kt[buf][0][kl], e1 = Kt[buf][1][kl];
-                const int iy = niy0 + (e1 >> 16), ix = nix0 + (e1 & 0xFFFF);
-                const bool ok = nvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[i] = ldg(rB, nb_base + e0 + (iy >> p.up) * p.Ws + (ix >> p.up), ok);
-            }
-        } else if constexpr (MODE == CONV_DGRAD) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int kl = tid / BN + (256 / BN) * i;
-                const int e0 = Kt[buf][0][kl], e1 = Kt[buf][1][kl];
-                const int oy = dg_oyb - (e1 >> 16), ox = dg_oxb - (e1 & 0xFFFF);
-                const bool ok = nvalid && (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
-                rb[i] = ldg(rB, dg_base + e0 + oy * p.OW + ox, ok);
-            }
-        } else if constexpr (MODE == CONV_WGRAD) {
-            const int k = kt + (tid & 31);
-            const bool kok = k < kend;
-            const uint32_t kk = kok ? k : 0;
-            const uint32_t img = fdiv(kk, p.fd_ohw), pix = kk - img * OHW;
-            const uint32_t oy = fdiv(pix, p.fd_ow), ox = pix - oy * p.OW;
-            const int iy0 = (int)oy * p.s - p.ph, ix0 = (int)ox * p.s - p.pw;
-            const unsigned xb = img * p.Cin * HsWs;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int nl = (tid >> 5) + 8 * i;
-                const int e0 = Nt[0][nl], e1 = Nt[1][nl];
-                const int iy = iy0 + (e1 >> 16), ix = ix0 + (e1 & 0xFFFF);
-                const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                rb[i] = ldg(rB, xb + e0 + (iy >> p.up) * p.Ws + (ix >> p.up), ok);
+        if (isA) {
+            if constexpr (MODE == CONV_FWD) {
+                const int k = kt + 4 * (tid & 7) + j;
+                const int m = m0 + (tid >> 3) + 32 * i;
+                ra[i][j] = ldg(rA, (unsigned)m * p.K + k, m < p.M && k < kend);
+            } else if constexpr (MODE == CONV_DGRAD) {
+                const int q = tid + 256 * i;
+                const int m = m0 + q % BM;
+                if (j == 0) qw[i] = *(const int4*)&Kt[buf][2][4 * (q / BM)];
+                const int w = j == 0 ? qw[i].x : j == 1 ? qw[i].y : j == 2 ? qw[i].z : qw[i].w;
+                ra[i][j] = ldg(rA, (unsigned)w + (unsigned)m * KHW, m < p.M && w >= 0);
+            } else if constexpr (MODE == CONV_WGRAD) {
+                const int m = m0 + (tid >> 3) + 32 * i;
+                ra[i][j] = ldg(rA, wg_ab[j] + (unsigned)m * OHW, wg_ok[j] && m < p.M);
+            } else {
+                const int q = tid + 256 * i;
+                const int m = m0 + (a_kfast ? (q >> 3) : (q % BM));
+                const int k = kt + 4 * (a_kfast ? (q & 7) : (q / BM)) + j;
+                ra[i][j] = ldg(rA, (unsigned)zb * (unsigned)p.sAb + (unsigned)m * (unsigned)p.sAm + (unsigned)k * (unsigned)p.sAk,
+                               m < p.M && k < kend);
             }
         } else {
-            const unsigned bb = (unsigned)zb * (unsigned)p.sBb;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int e = tid + 256 * i;
-                const int nl = p.b_lane_n ? (e % BN) : (e >> 5);
-                const int kl = p.b_lane_n ? (e / BN) : (e & 31);
-                const int n = n0 + nl, k = kt + kl;
-                rb[i] = ldg(rB, bb + (unsigned)k * (unsigned)p.sBk + (unsigned)n * (unsigned)p.sBn, n < p.N && k < kend);
+            if constexpr (MODE == CONV_FWD || MODE == CONV_DGRAD) {
+                if (j == 0) {
+                    const int kq = (tid + 256 * i) / BN;
+                    qe0[i] = *(const int4*)&Kt[buf][0][4 * kq];
+                    qe1[i] = *(const int4*)&Kt[buf][1][4 * kq];
+                }
+                const int e0 = j == 0 ? qe0[i].x : j == 1 ? qe0[i].y : j == 2 ? qe0[i].z : qe0[i].w;
+                const int e1 = j == 0 ? qe1[i].x : j == 1 ? qe1[i].y : j == 2 ? qe1[i].z : qe1[i].w;
+                if constexpr (MODE == CONV_FWD) {
+                    const int iy = ny0[i] + (e1 >> 16), ix = nx0[i] + (e1 & 0xFFFF);
+                    const bool ok = nvalid[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    rb[i][j] = ldg(rB, nbase[i] + e0 + (iy >> p.up) * p.Ws + (ix >> p.up), ok);
+                } else {
+                    const int oy = ny0[i] - (e1 >> 16), ox = nx0[i] - (e1 & 0xFFFF);
+                    const bool ok = nvalid[i] && (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
+                    rb[i][j] = ldg(rB, nbase[i] + e0 + oy * p.OW + ox, ok);
+                }
+            } else if constexpr (MODE == CONV_WGRAD) {
+                if (j == 0) { const int nl = (tid >> 3) + 32 * i; wg_e0[i] = Nt[0][nl]; wg_e1[i] = Nt[1][nl]; }
+                const int iy = wg_iy0[j] + (wg_e1[i] >> 16), ix = wg_ix0[j] + (wg_e1[i] & 0xFFFF);
+                const bool ok = wg_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rb[i][j] = ldg(rB, wg_xb[j] + wg_e0[i] + (iy >> p.up) * p.Ws + (ix >> p.up), ok);
+            } else {
+                const int q = tid + 256 * i;
+                const int n = n0 + (b_kfast ? (q >> 3) : (q % BN));
+                const int k = kt + 4 * (b_kfast ? (q & 7) : (q / BN)) + j;
+                rb[i][j] = ldg(rB, (unsigned)zb * (unsigned)p.sBb + (unsigned)k * (unsigned)p.sBk + (unsigned)n * (unsigned)p.sBn,
+                               n < p.N && k < kend);
             }
         }
     };
 
     auto store_tile = [&](int buf) {
-        float* as = As[buf];
-        float* bs = Bs[buf];
-        if constexpr (MODE == CONV_FWD || MODE == CONV_WGRAD) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) as[((tid >> 5) + 8 * i) * LDA + (tid & 31)] = ra[i];
-        } else if constexpr (MODE == CONV_DGRAD) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) { const int e = tid + 256 * i; as[(e % BM) * LDA + e / BM] = ra[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int e = tid + 256 * i;
-                const int ml = p.a_lane_k ? (e >> 5) : (e % BM);
-                const int kl = p.a_lane_k ? (e & 31) : (e / BM);
-                as[ml * LDA + kl] = ra[i];
-            }
+        for (int i = 0; i < QA; ++i) {
+            const int q = tid + 256 * i;
+            const int row = a_kfast ? (q >> 3) : (q % BM), kq = a_kfast ? (q & 7) : (q / BM);
+            *(float4*)&As[buf][row * LD + 4 * kq] = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
         }
-        if constexpr (MODE == CONV_FWD || MODE == CONV_DGRAD) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bs[(tid / BN + (256 / BN) * i) * LDB + (tid % BN)] = rb[i];
-        } else if constexpr (MODE == CONV_WGRAD) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) bs[(tid & 31) * LDB + (tid >> 5) + 8 * i] = rb[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int e = tid + 256 * i;
-                const int nl = p.b_lane_n ? (e % BN) : (e >> 5);
-                const int kl = p.b_lane_n ? (e / BN) : (e & 31);
-                bs[kl * LDB + nl] = rb[i];
-            }
+        for (int i = 0; i < QB; ++i) {
+            const int q = tid + 256 * i;
+            const int row = b_kfast ? (q >> 3) : (q % BN), kq = b_kfast ? (q & 7) : (q / BN);
+            *(float4*)&Bs[buf][row * LD + 4 * kq] = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
         }
     };
 
@@ -297,39 +286,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int arow = (wm * TM * 32 + (lane & 31)) * LDA + (lane >> 5);
-    const int bcol = (lane >> 5) * LDB + wn * TN * 32 + (lane & 31);
+    const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * (BK / 2);
+    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * (BK / 2);
 
-    // ---- main loop: one barrier per K-tile, LDS double buffered; the gathers of tile t+1 are
-    //      issued before the MFMAs of tile t and land in LDS after them (branch-free body) ----------
+    // ---- main loop: one barrier per K-tile, LDS double buffered.  The gather of K-tile t+1 (address
+    //      arithmetic + buffer loads) is cut into 16 slices, one behind the MFMAs of each k-step of tile t,
+    //      fenced with sched_barrier: left to itself the compiler emits [whole gather][64 MFMAs][LDS writes],
+    //      and the two waves of a SIMD then phase-lock and idle the matrix pipe while both gather
+    //      (measured: SQ_WAIT_INST_ANY 77 %, MFMA busy 64 %). -------------------------------------------
     const int ntile = (kend - kbeg + BK - 1) / BK;
     if (ntile > 0) {
         decode_k(kbeg, 0);
         __syncthreads();
-        load_tile(kbeg, 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) stage_elem(e, kbeg, 0);
         decode_k(kbeg + BK, 1);
         store_tile(0);
         __syncthreads();
         for (int t = 0; t < ntile; ++t) {
             const int cur = t & 1, kt = kbeg + t * BK;
-            load_tile(kt + BK, cur ^ 1);                 // past kend: every element is masked to 0
-            decode_k(kt + 2 * BK, cur);                  // table `cur` was last read while loading tile t
-            const float* as = As[cur] + arow;
-            const float* bs = Bs[cur] + bcol;
+            float4 af[TM][4], bf[TN][4];
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                float a[TM], b[TN];
+            for (int q = 0; q < TM; ++q)
 #pragma unroll
-                for (int q = 0; q < TM; ++q) a[q] = as[q * 32 * LDA + kk * 2];
+                for (int v = 0; v < 4; ++v) af[q][v] = *(const float4*)&As[cur][arow + q * 32 * LD + 4 * v];
 #pragma unroll
-                for (int q = 0; q < TN; ++q) b[q] = bs[kk * 2 * LDB + q * 32];
+            for (int q = 0; q < TN; ++q)
 #pragma unroll
-                for (int ta = 0; ta < TM; ++ta)
+                for (int v = 0; v < 4; ++v) bf[q][v] = *(const float4*)&Bs[cur][brow + q * 32 * LD + 4 * v];
 #pragma unroll
-                    for (int tb = 0; tb < TN; ++tb)
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            for (int s16 = 0; s16 < 16; ++s16) {
+                const int v = s16 >> 2, c = s16 & 3;
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta) {
+                    const float a = c == 0 ? af[ta][v].x : c == 1 ? af[ta][v].y : c == 2 ? af[ta][v].z : af[ta][v].w;
+#pragma unroll
+                    for (int tb = 0; tb < TN; ++tb) {
+                        const float b = c == 0 ? bf[tb][v].x : c == 1 ? bf[tb][v].y : c == 2 ? bf[tb][v].z : bf[tb][v].w;
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ta][tb], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < EPS; ++x)
+                    if (s16 * EPS + x < NE) stage_elem(s16 * EPS + x, kt + BK, cur ^ 1);   // past kend: masked to 0
+                if (s16 == 15) decode_k(kt + 2 * BK, cur);       // table `cur` was last read while staging tile t
+                if (SCHED) __builtin_amdgcn_sched_barrier(0);
             }
-            store_tile(cur ^ 1);                         // buffer cur^1 was last read in iteration t-1
+            store_tile(cur ^ 1);                                 // buffer cur^1 was last read in iteration t-1
             __syncthreads();
         }
     }

@@ -164,10 +164,12 @@ int mogan_reparam_bwd(const float* logvar, const float* eps, const float* dc, fl
                       hipStream_t stream);
 
 /* ---------------------------------------------------------------- pooling / resize (CNN_ENCODER trunk)
- * max_pool2d(k,s, no padding) with argmax-free backward (recomputes the window max; ties -> first),
+ * max_pool2d(k,s, no padding): fwd records the offset of the first maximum of each window in idx (uint8,
+ * same shape as y; nullable), bwd gathers through it (ties -> first, like torch),
  * avg_pool2d(k,s,pad, count_include_pad), bilinear resize (align_corners=0) -- model.py:256,264,271,301 */
-int mogan_maxpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, hipStream_t stream);
-int mogan_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, int s,
+int mogan_maxpool_fwd(const float* x, float* y, uint8_t* idx, int planes, int H, int W, int k, int s,
+                      hipStream_t stream);
+int mogan_maxpool_bwd(const uint8_t* idx, const float* dy, float* dx, int planes, int H, int W, int k, int s,
                       hipStream_t stream);
 int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, int pad, hipStream_t stream);
 int mogan_avgpool_bwd(const float* dy, float* dx, int planes, int H, int W, int k, int s, int pad,

@@ -16,11 +16,45 @@ class HipLinear(nn.Linear):
         return ops.linear(x, self.weight, self.bias)
 
 
+class BNCallCounter:
+    """nn.BatchNorm bumps `num_batches_tracked` with one tiny kernel per call (96 per train step here).
+    The trainer instead makes every counter a view of one flat int64 tensor, counts the calls of a step on
+    the host and adds them with ONE launch per step (same buffer values, hipGraph-capturable)."""
+
+    def __init__(self, modules):
+        self.mods = [m for net in modules for m in net.modules()
+                     if isinstance(m, _HipBNMixin) and m.num_batches_tracked is not None]
+        self.index = {id(m): i for i, m in enumerate(self.mods)}
+        dev = self.mods[0].num_batches_tracked.device
+        self.flat = torch.zeros(len(self.mods), dtype=torch.long, device=dev)
+        for i, m in enumerate(self.mods):
+            self.flat[i] = m.num_batches_tracked
+            m._buffers["num_batches_tracked"] = self.flat[i]
+            m._call_counter = self
+        self.calls = [0] * len(self.mods)
+        self._cached, self._cached_dev = None, None
+
+    def hit(self, m):
+        self.calls[self.index[id(m)]] += 1
+
+    def flush(self):
+        if self._cached != self.calls:                  # first step (or a changed call pattern): eager only
+            self._cached = list(self.calls)
+            self._cached_dev = torch.tensor(self._cached, dtype=torch.long, device=self.flat.device)
+        self.flat.add_(self._cached_dev)
+        self.calls = [0] * len(self.mods)
+
+
 class _HipBNMixin:
+    _call_counter = None
+
     def fused(self, x, act=ops.ACT_NONE, slope=0.2, residual=None):
         if self.training:
             if self.num_batches_tracked is not None:
-                self.num_batches_tracked += 1
+                if self._call_counter is not None:
+                    self._call_counter.hit(self)
+                else:
+                    self.num_batches_tracked += 1
             return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
                               residual, self.eps, self.momentum)
         # eval mode: running statistics folded into a per-channel affine

@@ -32,6 +32,7 @@ from ..hip import ops
 from .miscc.config import cfg
 from .miscc.losses import KL_loss, discriminator_loss, generator_loss
 from .miscc.utils import copy_G_params, load_params, mkdir_p, weights_init
+from .model_base import BNCallCounter
 from .model import CNN_ENCODER, D_NET64, D_NET128, D_NET256, G_NET, RNN_ENCODER
 
 
@@ -104,6 +105,7 @@ class TrainEngine:
         self.text_encoder, self.image_encoder, self.netG, self.netsD = text_encoder, image_encoder, netG, netsD
         self.optG = FlatAdam(netG, cfg.TRAIN.GENERATOR_LR, with_ema=True)
         self.optDs = [FlatAdam(d, cfg.TRAIN.DISCRIMINATOR_LR) for d in netsD]
+        self.bn_counter = BNCallCounter([netG] + list(netsD))
         self.distributed = bool(distributed) and dist.is_available() and dist.is_initialized() \
             and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.distributed else 1
@@ -165,6 +167,7 @@ class TrainEngine:
             for p in d.parameters():
                 p.requires_grad_(True)
         self._opt_step(self.optG, self._allreduce_async(self.optG))       # Adam + EMA in one launch
+        self.bn_counter.flush()                                           # all num_batches_tracked, one launch
         out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach())
         out.update({k: v.detach() for k, v in parts.items()})
         return out
@@ -200,8 +203,8 @@ class TrainEngine:
         for o in [self.optG] + self.optDs:
             ts += [o.p, o.m, o.v, o.state] + ([o.ema] if o.ema is not None else [])
         for net in [self.netG] + list(self.netsD):
-            ts += list(net.buffers())
-        return ts
+            ts += [b for b in net.buffers() if b.dim() > 0]
+        return ts + [self.bn_counter.flat]
 
     def _snapshot(self):
         return [t.clone() for t in self._state_tensors()]

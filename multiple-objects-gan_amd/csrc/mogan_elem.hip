@@ -200,38 +200,35 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ m
 }
 
 // -------------------------------------------------------------------------------- pooling / resize
+// idx (nullable) records the offset a*k+b of the first maximum of each window for the backward
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          long long total, int H, int W, int OH, int OW, int k, int s) {
+                                                          uint8_t* __restrict__ idx, long long total, int H, int W,
+                                                          int OH, int OW, int k, int s) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
         const float* px = x + pl * H * W;
-        float m = -INFINITY;
-        for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) m = fmaxf(m, px[(oy * s + a) * W + ox * s + b]);
+        float m = -INFINITY; int am = 0;
+        for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) {
+            const float v = px[(oy * s + a) * W + ox * s + b];
+            if (v > m) { m = v; am = a * k + b; }
+        }
         y[i] = m;
+        if (idx) idx[i] = (uint8_t)am;
     }
 }
-// gather form: dx[p,iy,ix] = sum over windows containing (iy,ix) whose first max is at (iy,ix)
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// gather form: dx[p,iy,ix] = sum over the windows that contain (iy,ix) and whose first maximum is there
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy,
                                                           float* __restrict__ dx, long long total, int H, int W, int OH,
                                                           int OW, int k, int s) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
-        const float* px = x + pl * H * W;
-        const float v = px[iy * W + ix];
         float g = 0.f;
         const int oy0 = max(0, (iy - k + s) / s), oy1 = min(OH - 1, iy / s);
         const int ox0 = max(0, (ix - k + s) / s), ox1 = min(OW - 1, ix / s);
         for (int oy = oy0; oy <= oy1; ++oy)
             for (int ox = ox0; ox <= ox1; ++ox) {
-                // is (iy,ix) the first maximum of window (oy,ox)?
-                bool first = true;
-                for (int a = 0; a < k && first; ++a)
-                    for (int b = 0; b < k; ++b) {
-                        const int yy = oy * s + a, xx = ox * s + b;
-                        const float w = px[yy * W + xx];
-                        if (w > v || (w == v && (yy < iy || (yy == iy && xx < ix)))) { first = false; break; }
-                    }
-                if (first) g += dy[(pl * OH + oy) * OW + ox];
+                const long long o = (pl * OH + oy) * OW + ox;
+                if ((int)idx[o] == (iy - oy * s) * k + (ix - ox * s)) g += dy[o];
             }
         dx[i] = g;
     }
@@ -257,11 +254,12 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     const float inv = 1.f / (float)(k * k);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
+        // windows with oy*s - pad <= iy <= oy*s - pad + k - 1
+        const int oy0 = max(0, (iy + pad - k + s) / s), oy1 = min(OH - 1, (iy + pad) / s);
+        const int ox0 = max(0, (ix + pad - k + s) / s), ox1 = min(OW - 1, (ix + pad) / s);
         float g = 0.f;
-        for (int oy = 0; oy < OH; ++oy) {
-            const int a = iy + pad - oy * s; if (a < 0 || a >= k) continue;
-            for (int ox = 0; ox < OW; ++ox) { const int b = ix + pad - ox * s; if (b >= 0 && b < k) g += dy[(pl * OH + oy) * OW + ox]; }
-        }
+        for (int oy = oy0; oy <= oy1; ++oy)
+            for (int ox = ox0; ox <= ox1; ++ox) g += dy[(pl * OH + oy) * OW + ox];
         dx[i] = g * inv;
     }
 }
@@ -476,19 +474,21 @@ int mogan_reparam_bwd(const float* logvar, const float* eps, const float* dc, fl
     return ok_launch();
 }
 
-int mogan_maxpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, hipStream_t stream) {
+int mogan_maxpool_fwd(const float* x, float* y, uint8_t* idx, int planes, int H, int W, int k, int s,
+                      hipStream_t stream) {
     const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
     if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
     const long long n = (long long)planes * OH * OW;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW, k, s);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, idx, n, H, W, OH, OW, k, s);
     return ok_launch();
 }
-int mogan_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, int s,
+int mogan_maxpool_bwd(const uint8_t* idx, const float* dy, float* dx, int planes, int H, int W, int k, int s,
                       hipStream_t stream) {
     const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
     if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
     const long long n = (long long)planes * H * W;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, dy, dx, n, H, W, OH, OW, k, s);
+    if (k * k > 255) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, idx, dy, dx, n, H, W, OH, OW, k, s);
     return ok_launch();
 }
 int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, int pad, hipStream_t stream) {

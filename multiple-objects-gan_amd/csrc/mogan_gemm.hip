@@ -442,7 +442,7 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     const long long tiles = cdiv(p.M, bm) * cdiv(p.N, bn) * nz;
     int nsplit = 1;
     const int ktiles = (int)cdiv(p.K, 32);
-    if (tiles < 512 && ktiles >= 8) {
+    if (tiles < 512 && ktiles >= 8) {             // fewer than two blocks per CU and a K loop worth cutting
         nsplit = (int)cdiv(768, tiles);
         nsplit = (int)std::min<long long>(nsplit, ktiles / 4);
         if (nsplit < 1) nsplit = 1;

@@ -53,7 +53,7 @@ SIGNATURES = {
     "mogan_kl_bwd": [P, P, P, P, P, I, P],
     "mogan_reparam_fwd": [P, P, P, P, I, P],
     "mogan_reparam_bwd": [P, P, P, P, P, I, P],
-    "mogan_maxpool_fwd": [P, P, I, I, I, I, I, P],
+    "mogan_maxpool_fwd": [P, P, P, I, I, I, I, I, P],
     "mogan_maxpool_bwd": [P, P, P, I, I, I, I, I, P],
     "mogan_avgpool_fwd": [P, P, I, I, I, I, I, I, P],
     "mogan_avgpool_bwd": [P, P, I, I, I, I, I, I, P],

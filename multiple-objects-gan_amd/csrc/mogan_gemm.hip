@@ -32,6 +32,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FastDiv { uint32_t d, mul, shr; };
 
@@ -66,6 +67,7 @@ struct GemmP {
     // bmm strides (elements)
     long long sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn;
     int a_lane_k, b_lane_n;
+    int avec;                    // 16-byte loads legal for the k-contiguous operand(s)
     unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (< 4 GiB)
 };
 
@@ -75,12 +77,17 @@ __device__ __forceinline__ float ldg(__amdgpu_buffer_rsrc_t r, unsigned idx, boo
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
+__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, unsigned idx, bool ok) {
+    const unsigned off = ok ? idx * 4u : 0xFFFFFFF0u;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
 #define KH_BAD (0x4000 << 16)   // decode entry whose tap index is far out of range -> the bounds test fails
 
 // LDS images: As[m][k], Bs[n][k], row stride LD = BK+4 floats (144 B): fragment reads are 4 x ds_read_b128
 // per 32-row tile (bank-conflict free at this stride), staging writes are ds_write_b128 of 4 consecutive k.
 // MFMA k assignment inside a K-tile: lane half h = lane>>5 owns k in [16h, 16h+16); step kk uses k = 16h+kk.
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool AVEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     constexpr bool SCHED = true;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, LD = BK + 4;
@@ -213,7 +220,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             if constexpr (MODE == CONV_FWD) {
                 const int k = kt + 4 * (tid & 7) + j;
                 const int m = m0 + (tid >> 3) + 32 * i;
-                ra[i][j] = ldg(rA, (unsigned)m * p.K + k, m < p.M && k < kend);
+                if constexpr (AVEC) {       // K % 4 == 0: the 4 consecutive k of the quad are one aligned 16-byte load
+                    if (j == 0) {
+                        const f32x4 q4 = ldg4(rA, (unsigned)m * p.K + k, m < p.M && k < kend);
+                        ra[i][0] = q4[0]; ra[i][1] = q4[1]; ra[i][2] = q4[2]; ra[i][3] = q4[3];
+                    }
+                } else {
+                    ra[i][j] = ldg(rA, (unsigned)m * p.K + k, m < p.M && k < kend);
+                }
             } else if constexpr (MODE == CONV_DGRAD) {
                 const int q = tid + 256 * i;
                 const int m = m0 + q % BM;
@@ -222,13 +236,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                 ra[i][j] = ldg(rA, (unsigned)w + (unsigned)m * KHW, m < p.M && w >= 0);
             } else if constexpr (MODE == CONV_WGRAD) {
                 const int m = m0 + (tid >> 3) + 32 * i;
-                ra[i][j] = ldg(rA, wg_ab[j] + (unsigned)m * OHW, wg_ok[j] && m < p.M);
+                if constexpr (AVEC) {       // OH*OW % 4 == 0: the 4 pixels of the quad share (img, co) and are contiguous
+                    if (j == 0) {
+                        const f32x4 q4 = ldg4(rA, wg_ab[0] + (unsigned)m * OHW, wg_ok[0] && m < p.M);
+                        ra[i][0] = q4[0]; ra[i][1] = q4[1]; ra[i][2] = q4[2]; ra[i][3] = q4[3];
+                    }
+                } else {
+                    ra[i][j] = ldg(rA, wg_ab[j] + (unsigned)m * OHW, wg_ok[j] && m < p.M);
+                }
             } else {
                 const int q = tid + 256 * i;
                 const int m = m0 + (a_kfast ? (q >> 3) : (q % BM));
                 const int k = kt + 4 * (a_kfast ? (q & 7) : (q / BM)) + j;
-                ra[i][j] = ldg(rA, (unsigned)zb * (unsigned)p.sAb + (unsigned)m * (unsigned)p.sAm + (unsigned)k * (unsigned)p.sAk,
-                               m < p.M && k < kend);
+                const unsigned idx = (unsigned)zb * (unsigned)p.sAb + (unsigned)m * (unsigned)p.sAm + (unsigned)k * (unsigned)p.sAk;
+                if constexpr (AVEC) {       // host guarantees: both operands k-contiguous, 16-byte aligned rows, K % 4 == 0
+                    if (j == 0) {
+                        const f32x4 q4 = ldg4(rA, idx, m < p.M && k < kend);
+                        ra[i][0] = q4[0]; ra[i][1] = q4[1]; ra[i][2] = q4[2]; ra[i][3] = q4[3];
+                    }
+                } else {
+                    ra[i][j] = ldg(rA, idx, m < p.M && k < kend);
+                }
             }
         } else {
             if constexpr (MODE == CONV_FWD || MODE == CONV_DGRAD) {
@@ -257,8 +285,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                 const int q = tid + 256 * i;
                 const int n = n0 + (b_kfast ? (q >> 3) : (q % BN));
                 const int k = kt + 4 * (b_kfast ? (q & 7) : (q / BN)) + j;
-                rb[i][j] = ldg(rB, (unsigned)zb * (unsigned)p.sBb + (unsigned)k * (unsigned)p.sBk + (unsigned)n * (unsigned)p.sBn,
-                               n < p.N && k < kend);
+                const unsigned idx = (unsigned)zb * (unsigned)p.sBb + (unsigned)k * (unsigned)p.sBk + (unsigned)n * (unsigned)p.sBn;
+                if constexpr (AVEC) {
+                    if (j == 0) {
+                        const f32x4 q4 = ldg4(rB, idx, n < p.N && k < kend);
+                        rb[i][0] = q4[0]; rb[i][1] = q4[1]; rb[i][2] = q4[2]; rb[i][3] = q4[3];
+                    }
+                } else {
+                    rb[i][j] = ldg(rB, idx, n < p.N && k < kend);
+                }
             }
         }
     };
@@ -404,15 +439,21 @@ struct Cfg { int wm, wn, tm, tn; };
 static const Cfg kCfgs[] = {{2, 2, 2, 2}, {1, 4, 3, 1}, {4, 1, 1, 1}, {1, 4, 1, 1}, {2, 2, 1, 1}};
 enum { NCFG = 5 };
 
+template <int MODE, bool AVEC>
+static void launch_cfg2(int c, dim3 grid, hipStream_t st, const GemmP& p) {
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 2, 2, AVEC>), grid, dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 3, 1, AVEC>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<MODE, 4, 1, 1, 1, AVEC>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 1, 1, AVEC>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 1, 1, AVEC>), grid, dim3(256), 0, st, p); break;
+    }
+}
 template <int MODE>
 static void launch_cfg(int c, dim3 grid, hipStream_t st, const GemmP& p) {
-    switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 2, 2>), grid, dim3(256), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 3, 1>), grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<MODE, 4, 1, 1, 1>), grid, dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 1, 1>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 1, 1>), grid, dim3(256), 0, st, p); break;
-    }
+    if constexpr (MODE == CONV_DGRAD) launch_cfg2<MODE, false>(c, grid, st, p);
+    else if (p.avec) launch_cfg2<MODE, true>(c, grid, st, p);
+    else launch_cfg2<MODE, false>(c, grid, st, p);
 }
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -572,6 +613,7 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
+    p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
 }
 
@@ -592,6 +634,7 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     p.A = dy; p.B = x; p.C = dw; p.M = Cout; p.N = Cin * KH * KW; p.K = B * p.OH * p.OW; p.accumulate = accumulate;
     p.a_bytes = 4u * B * Cout * p.OH * p.OW; p.b_bytes = 4u * B * Cin * Hs * Ws;
+    p.avec = ((p.OH * p.OW) % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     return run_gemm(CONV_WGRAD, p, 1, (long long)Cout * Cin * KH * KW, ws, ws_bytes, stream);
 }
 
@@ -606,6 +649,8 @@ int mogan_bmm(const float* a, const float* b, float* c, int batch, int M, int N,
     const long long eb = 1 + (long long)(batch - 1) * sBb + (long long)(K > 0 ? K - 1 : 0) * sBk + (long long)(N > 0 ? N - 1 : 0) * sBn;
     if (ea >= (1ll << 30) || eb >= (1ll << 30)) return MOGAN_ERR_SHAPE;
     p.a_bytes = (unsigned)(4 * ea); p.b_bytes = (unsigned)(4 * eb);
+    p.avec = (sAk == 1 && sBk == 1 && K % 4 == 0 && sAm % 4 == 0 && sBn % 4 == 0 && sAb % 4 == 0 && sBb % 4 == 0 &&
+              (((uintptr_t)a | (uintptr_t)b) & 15) == 0);
     p.sAb = sAb; p.sAm = sAm; p.sAk = sAk; p.sBb = sBb; p.sBk = sBk; p.sBn = sBn; p.sCb = sCb; p.sCm = sCm; p.sCn = sCn;
     p.a_lane_k = (sAk <= sAm); p.b_lane_n = (sBn <= sBk);
     p.OH = p.OW = p.Hs = p.Ws = p.KH = p.KW = p.s = 1;

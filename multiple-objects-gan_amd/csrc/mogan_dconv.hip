@@ -1,0 +1,336 @@
+// mogan_dconv.hip -- direct ("halo tile in LDS") fp32 MFMA convolution for the shapes that carry the FLOPs of the
+// AttnGAN step: 3x3 s1 p1 (optionally behind a fused nearest-x2 upsample) and 4x4 s2 p1 at >= 16x16 output, plus the
+// 2x2 s1 sub-convolutions a 4x4 s2 dgrad decomposes into.
+//
+// Why a second conv kernel: the implicit-GEMM kernel (mogan_gemm.hip) re-gathers every input pixel KH*KW times from
+// global memory with per-element address arithmetic; measured on MI355X it tops out near 100 TFLOP/s while the same
+// loop without the gather runs at 141 (tools/lab/gemm_lab.hip).  Here a block stages, per chunk of CK input channels,
+//   Xs[CK][HH][WWP]  the input halo tile of its R x Cw output pixels (each input pixel loaded ONCE), and
+//   Ws[BM][CK*KH*KW] the weights of its BM output channels (16-byte loads),
+// and the MFMA operands are read from LDS with compile-time immediate offsets -- no address VALU in the inner loop:
+//   a = Ws[m][(2c+h)*KHW + tap]   b = Xs[2c+h][ry*S+kh][rx*S+kw]      (h = lane>>5 selects the channel of the k-pair)
+// K order = (ci, kh, kw) = the natural weight layout, so A rows are contiguous.
+//
+// Forward, data-gradient and (separate kernel below) weight-gradient all use this tile scheme:
+//   dgrad s1  = forward over dY with flipped/transposed weights (a small transform kernel builds them),
+//   dgrad s2  = four 2x2 s1 forwards (one per output parity) writing to stride-2 positions,
+//   wgrad     = K runs over the pixels of the tile, B = Xs read at [ci][ry*S+kh][rx*S+kw] with (ci,kh,kw) on the lanes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "../../include/mogan_hip.h"
+#include "mogan_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ldg(__amdgpu_buffer_rsrc_t r, unsigned idx) {   // idx = 0x3FFFFFFF -> 0.f
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4u, 0, 0));
+}
+__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, unsigned idx) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, idx * 4u, 0, 0));
+}
+#define IDX_OOB 0x3FFFFFFFu   // *4 = 0xFFFFFFFC: beyond any buffer extent -> the load returns 0
+
+struct DConvP {
+    const float* X; const float* Wt; float* Y; float* ws;
+    int B, Cin, Cout, Hs, Ws, H, W, up;      // stored input dims (Hs,Ws); conv sees H = Hs<<up
+    int OH, OW, pt, pl;                      // conv output grid and top/left padding
+    int yH, yW, ys, y0, x0;                  // output plane dims, pixel stride and offset (strided dgrad writes)
+    int R, Cw, tiles_x, tiles_y;             // block = R rows x Cw cols of one image
+    int nsplit, cps;                         // split over channel chunks: chunks per split
+    int npar;                                // 4: blockIdx.z also enumerates the stride-2 dgrad parity classes
+    long long slab;
+    int accumulate;
+    unsigned x_bytes, w_bytes;
+};
+
+// ------------------------------------------------------------------------------------------ forward
+template <int KH, int KW, int S, int WM, int WN, int TM, int TN, int CK>
+__global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
+    constexpr int BM = WM * TM * 32, NTB = WN * TN, PX = NTB * 32, KHW = KH * KW, KC = CK * KHW;
+    constexpr int WWP = ((31 * S + KW) + 3) & ~3, HHMAX = 7 * S + KH, CPL = HHMAX * WWP;
+    constexpr int LDW = KC | 1;                                  // odd row stride: conflict-free A reads
+    // halo elements per thread: the larger of the two block shapes (R=4,Cw=32) and (R=8,Cw=16)
+    constexpr int HALO_A = (3 * S + KH) * (31 * S + KW), HALO_B = (7 * S + KH) * (15 * S + KW);
+    constexpr int NXE = (CK * (HALO_A > HALO_B ? HALO_A : HALO_B) + 255) / 256;
+    constexpr int NWQ = (BM * (KC / 4) + 255) / 256;             // weight quads per thread
+    static_assert(WM * WN == 4 && KC % 4 == 0 && CK % 2 == 0, "tile");
+    __shared__ float Xs[CK * CPL];
+    __shared__ float Wl[BM * LDW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // spatial tile
+    int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y; const int img = tile / p.tiles_y;
+    const int oy0 = ty * p.R, ox0 = tx * p.Cw;
+    const int m0 = blockIdx.y * BM;
+    const int sp = blockIdx.z % p.nsplit, par = blockIdx.z / p.nsplit;
+    // stride-2 dgrad: parity class (py,px) selects its 2x2 weight set, padding and output phase
+    int pt = p.pt, pl = p.pl, y0 = p.y0, x0 = p.x0;
+    const float* wptr = p.Wt;
+    if (p.npar == 4) {
+        const int py = par >> 1, px = par & 1;
+        pt = 1 - (py + 1 - ((py + 1) & 1)) / 2; pl = 1 - (px + 1 - ((px + 1) & 1)) / 2;
+        y0 = py; x0 = px;
+        wptr += (size_t)par * p.Cin * p.Cout * KHW;
+    }
+    const int HH = (p.R - 1) * S + KH, WW = (p.Cw - 1) * S + KW;
+    const int nchunk_all = p.Cin / CK;
+    const int c_beg = sp * p.cps, c_end = min(nchunk_all, c_beg + p.cps);
+
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, (short)0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wptr, (short)0, (int)p.w_bytes, 0x00020000);
+
+    // ---- per-thread staging plan (chunk independent) ----------------------------------------------------
+    // halo: element e -> (c, hy, hx); global offset relative to the chunk's first channel, or OOB (zero padding)
+    unsigned xg[NXE]; int xl[NXE];
+    const int HsWs = p.Hs * p.Ws;
+    {
+        const int per_c = HH * WW, total = CK * per_c;
+        const int iy_base = oy0 * S - pt, ix_base = ox0 * S - pl;
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / per_c, r = e - c * per_c;
+            const int hy = r / WW, hx = r - hy * WW;
+            const int iy = iy_base + hy, ix = ix_base + hx;
+            const bool ok = e < total && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            xg[i] = ok ? (unsigned)(c * HsWs + (iy >> p.up) * p.Ws + (ix >> p.up)) : IDX_OOB;
+            xl[i] = e < total ? c * CPL + hy * WWP + hx : -1;
+        }
+    }
+    const unsigned x_img = (unsigned)img * p.Cin * HsWs;
+    // weights: quad q -> (row, kq): 4 consecutive k of one output channel
+    unsigned wg[NWQ]; int wl[NWQ];
+#pragma unroll
+    for (int i = 0; i < NWQ; ++i) {
+        const int q = tid + 256 * i;
+        const int row = q / (KC / 4), kq = q - row * (KC / 4);
+        const bool ok = q < BM * (KC / 4) && m0 + row < p.Cout;
+        wg[i] = ok ? (unsigned)((m0 + row) * p.Cin * KHW + 4 * kq) : IDX_OOB;
+        wl[i] = q < BM * (KC / 4) ? row * LDW + 4 * kq : -1;
+    }
+
+    float rx[NXE]; f32x4 rw[NWQ];
+    auto load_chunk = [&](int c) {
+        const unsigned xb = x_img + (unsigned)c * CK * HsWs, wb = (unsigned)c * KC;
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) rx[i] = ldg(rX, xg[i] == IDX_OOB ? IDX_OOB : xg[i] + xb);
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i) rw[i] = ldg4(rW, wg[i] == IDX_OOB ? IDX_OOB : wg[i] + wb);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) if (xl[i] >= 0) Xs[xl[i]] = rx[i];
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i)
+            if (wl[i] >= 0) { Wl[wl[i]] = rw[i][0]; Wl[wl[i] + 1] = rw[i][1]; Wl[wl[i] + 2] = rw[i][2]; Wl[wl[i] + 3] = rw[i][3]; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // lane bases of the MFMA operand reads
+    const int h = lane >> 5;
+    const int abase = (wm * TM * 32 + (lane & 31)) * LDW + h * KHW;
+    int bbase[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int pb = (wn * TN + t) * 32 + (lane & 31);
+        const int ry = pb / p.Cw, rxx = pb - ry * p.Cw;
+        bbase[t] = h * CPL + ry * S * WWP + rxx * S;
+    }
+
+    if (c_beg < c_end) {
+        load_chunk(c_beg);
+        store_chunk();
+        __syncthreads();
+        for (int c = c_beg; c < c_end; ++c) {
+            if (c + 1 < c_end) load_chunk(c + 1);
+#pragma unroll
+            for (int c2 = 0; c2 < CK / 2; ++c2) {
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw) {
+                        float a[TM], b[TN];
+#pragma unroll
+                        for (int t = 0; t < TM; ++t) a[t] = Wl[abase + t * 32 * LDW + 2 * c2 * KHW + kh * KW + kw];
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) b[t] = Xs[bbase[t] + 2 * c2 * CPL + kh * WWP + kw];
+#pragma unroll
+                        for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                            for (int tb = 0; tb < TN; ++tb)
+                                acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (c + 1 < c_end) { store_chunk(); __syncthreads(); }
+        }
+    }
+
+    // ---- epilogue: Y[img][co][oy*ys + y0][ox*ys + x0] -------------------------------------------------------
+    float* __restrict__ Yg = (p.nsplit > 1) ? (p.ws + (size_t)sp * p.slab) : p.Y;
+    const bool addc = (p.nsplit == 1) && p.accumulate;
+    const size_t plane = (size_t)p.yH * p.yW;
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int pb = (wn * TN + tb) * 32 + (lane & 31);
+        const int ry = pb / p.Cw, rxx = pb - ry * p.Cw;
+        const size_t pix = (size_t)((oy0 + ry) * p.ys + y0) * p.yW + (ox0 + rxx) * p.ys + x0;
+#pragma unroll
+        for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.Cout) {
+                    float* dst = Yg + ((size_t)img * p.Cout + m) * plane + pix;
+                    float v = acc[ta][tb][r];
+                    if (addc) v += *dst;
+                    *dst = v;
+                }
+            }
+    }
+}
+
+// weight transforms for the data gradient ---------------------------------------------------------------------
+// s1: Wd[ci][co][kh][kw] = W[co][ci][KH-1-kh][KW-1-kw]
+__global__ __launch_bounds__(256) void wflip_kernel(const float* __restrict__ w, float* __restrict__ wd, int Cout, int Cin,
+                                                    int KH, int KW) {
+    const long long total = (long long)Cout * Cin * KH * KW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int kw = (int)(i % KW); long long t = i / KW;
+        const int kh = (int)(t % KH); t /= KH;
+        const int co = (int)(t % Cout); const int ci = (int)(t / Cout);
+        wd[i] = w[(((size_t)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+    }
+}
+// s2 (4x4, p1): four parity kernels Wp[par][ci][co][a][b] = W[co][ci][kh0 + 2(1-a)][kw0 + 2(1-b)], kh0 = (py+1)&1
+__global__ __launch_bounds__(256) void wparity_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+    const long long per = (long long)Cin * Cout * 4, total = per * 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int par = (int)(i / per); long long r = i - par * per;
+        const int b = (int)(r & 1), a = (int)((r >> 1) & 1); r >>= 2;
+        const int co = (int)(r % Cout), ci = (int)(r / Cout);
+        const int py = par >> 1, px = par & 1;
+        const int kh = ((py + 1) & 1) + 2 * (1 - a), kw = ((px + 1) & 1) + 2 * (1 - b);
+        wp[i] = w[(((size_t)co * Cin + ci) * 4 + kh) * 4 + kw];
+    }
+}
+
+__global__ __launch_bounds__(256) void dconv_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                           long long n, long long slab, int nsplit, int acc) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    for (long long i = i4; i < n && i < i4 + 4; ++i) {
+        float s = acc ? out[i] : 0.f;
+        for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * slab + i];
+        out[i] = s;
+    }
+}
+
+static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <int KH, int KW, int S, int CK>
+static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
+    // tile config: 96-wide M when it pads less
+    const bool m96 = cdiv(p.Cout, 96) * 96 < cdiv(p.Cout, 128) * 128;
+    const int bm = m96 ? 96 : 128;
+    p.Cw = std::min(32, p.OW); p.R = 128 / p.Cw;
+    p.tiles_x = p.OW / p.Cw; p.tiles_y = p.OH / p.R;
+    const long long tiles = (long long)p.B * p.tiles_x * p.tiles_y * cdiv(p.Cout, bm) * p.npar;
+    const int nchunk = p.Cin / CK;
+    int nsplit = 1;
+    if (tiles < 384 && nchunk >= 8) nsplit = (int)std::min<long long>(cdiv(512, tiles), nchunk / 4);
+    const long long y_numel = (long long)p.B * p.Cout * p.yH * p.yW;
+    if (nsplit > 1) {
+        const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)y_numel)) : 0;
+        nsplit = fit < 2 ? 1 : (int)std::min<long long>(nsplit, fit);
+    }
+    p.cps = (int)cdiv(nchunk, nsplit); p.nsplit = (int)cdiv(nchunk, p.cps);
+    p.slab = y_numel; p.ws = (float*)ws;
+    dim3 grid((unsigned)(p.B * p.tiles_x * p.tiles_y), (unsigned)cdiv(p.Cout, bm), (unsigned)(p.nsplit * p.npar));
+    if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK>), grid, dim3(256), 0, st, p);
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(cdiv(y_numel, 4), 256)), dim3(256), 0, st,
+                           (const float*)ws, p.Y, y_numel, y_numel, p.nsplit, p.accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// ---- internal entry points (hidden visibility: not part of the C ABI) ---------------------------------------
+// return 1 = handled, 0 = not eligible (caller falls back to the implicit-GEMM kernel), <0 = error
+int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                        int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int H = Hs << up, W = Ws << up;
+    const int OH = (H + 2 * ph - KH) / stride + 1, OW = (W + 2 * pw - KW) / stride + 1;
+    const bool k33 = KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1;
+    const bool k44 = KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0;
+    if (!(k33 || k44)) return 0;
+    if (!pow2(OH) || !pow2(OW) || OW < 16 || OH < 8 || OH * std::min(32, OW) < 128) return 0;
+    if ((Cin % 8) != 0 || Cout < 64 || (((uintptr_t)w) & 15) != 0) return 0;
+    if ((long long)B * Cin * Hs * Ws >= (1ll << 29) || (long long)Cout * Cin * KH * KW >= (1ll << 29) ||
+        (long long)B * Cout * OH * OW >= (1ll << 30)) return 0;
+    DConvP p{};
+    p.X = x; p.Wt = w; p.Y = y; p.B = B; p.Cin = Cin; p.Cout = Cout; p.Hs = Hs; p.Ws = Ws; p.H = H; p.W = W; p.up = up;
+    p.OH = OH; p.OW = OW; p.pt = ph; p.pl = pw; p.yH = OH; p.yW = OW; p.ys = 1; p.y0 = 0; p.x0 = 0; p.accumulate = 0; p.npar = 1;
+    p.x_bytes = 4u * B * Cin * Hs * Ws; p.w_bytes = 4u * Cout * Cin * KH * KW;
+    if (k44) return 0;     // measured: the stride-2 halo variant (85 TF) loses to the implicit-GEMM kernel (98 TF)
+    const int rc = launch_fwd<3, 3, 1, 8>(p, ws, ws_bytes, st);
+    return rc ? rc : 1;
+}
+
+// data gradient of the same two conv families; dx is (B,Cin,H,W) in the conv-input domain
+int mogan_dconv_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                          int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int H = Hs << up, W = Ws << up;
+    const int OH = (H + 2 * ph - KH) / stride + 1, OW = (W + 2 * pw - KW) / stride + 1;
+    const bool k33 = KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1;
+    const bool k44 = KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0;
+    if (!(k33 || k44)) return 0;
+    // the dgrad "forward" runs over dY (OH x OW) and produces H x W (k33) or the (H/2 x W/2) parity grids (k44)
+    const int gH = k33 ? H : H / 2, gW = k33 ? W : W / 2;
+    if (!pow2(gH) || !pow2(gW) || gW < 16 || gH < 8 || gH * std::min(32, gW) < 128) return 0;
+    if ((Cout % 8) != 0 || Cin < 64) return 0;
+    const size_t wbytes = (size_t)Cout * Cin * KH * KW * sizeof(float);
+    if (!ws || ws_bytes < wbytes + 256) return 0;
+    if ((long long)B * Cout * OH * OW >= (1ll << 29) || (long long)Cout * Cin * KH * KW >= (1ll << 29) ||
+        (long long)B * Cin * H * W >= (1ll << 30)) return 0;
+    float* wt = (float*)ws;                                          // transformed weights live at the head of ws
+    void* ws2 = (char*)ws + ((wbytes + 255) & ~(size_t)255);
+    const size_t ws2_bytes = ws_bytes - ((wbytes + 255) & ~(size_t)255);
+    const long long wn = (long long)Cout * Cin * KH * KW;
+    const unsigned nb = (unsigned)std::min<long long>(cdiv(wn, 256), 65536);
+    DConvP p{};
+    p.X = dy; p.Y = dx; p.B = B; p.Cin = Cout; p.Cout = Cin; p.Hs = OH; p.Ws = OW; p.H = OH; p.W = OW; p.up = 0;
+    p.yH = H; p.yW = W; p.accumulate = 0; p.npar = 1;
+    p.x_bytes = 4u * B * Cout * OH * OW;
+    if (k33) {
+        hipLaunchKernelGGL(wflip_kernel, dim3(nb), dim3(256), 0, st, w, wt, Cout, Cin, KH, KW);
+        p.Wt = wt; p.w_bytes = (unsigned)wbytes;
+        p.OH = H; p.OW = W; p.pt = KH - 1 - ph; p.pl = KW - 1 - pw; p.ys = 1; p.y0 = 0; p.x0 = 0;
+        const int rc = launch_fwd<3, 3, 1, 8>(p, ws2, ws2_bytes, st);
+        return rc ? rc : 1;
+    }
+    hipLaunchKernelGGL(wparity_kernel, dim3(nb), dim3(256), 0, st, w, wt, Cout, Cin);
+    // the four parity classes run in ONE launch (blockIdx.z): oyb0 = (py+1-kh0)/2 with kh0 = (py+1)&1 -> pt = 1-oyb0
+    p.Wt = wt; p.w_bytes = 4u * Cin * Cout * 4; p.npar = 4;
+    p.OH = gH; p.OW = gW; p.ys = 2; p.y0 = 0; p.x0 = 0; p.pt = 0; p.pl = 0;
+    const int rc = launch_fwd<2, 2, 1, 8>(p, ws2, ws2_bytes, st);
+    return rc ? rc : 1;
+}

@@ -28,6 +28,7 @@
 #include <mutex>
 #include <vector>
 #include "../../include/mogan_hip.h"
+#include "mogan_internal.h"
 
 namespace {
 
@@ -467,6 +468,26 @@ static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 
+}  // namespace
+int mogan_use_dconv = 1;
+static ProfRec g_prof_open; static bool g_prof_open_valid = false;
+void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st) {
+    g_prof_open_valid = false;
+    if (!g_prof_on) return;
+    ProfRec r{}; r.mode = mode; r.cfg = cfg; r.flops = flops; r.M = M; r.N = N; r.K = K; r.nz = 1; r.nsplit = 1;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1); hipEventRecord(r.e0, st);
+    g_prof_open = r; g_prof_open_valid = true;
+}
+void mogan_prof_end(int taken, hipStream_t st) {       // !taken: the attempt fell through, drop the record
+    if (!g_prof_open_valid) return;
+    g_prof_open_valid = false;
+    if (!taken) { hipEventDestroy(g_prof_open.e0); hipEventDestroy(g_prof_open.e1); return; }
+    hipEventRecord(g_prof_open.e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(g_prof_open);
+}
+namespace {
+
 // Tile config: least padded MFMA work; ties -> larger tile.  Split-K: fill >= 2 waves of 256 CUs
 // when the tile grid alone cannot, keeping >= 128 of K per split.
 static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -582,7 +603,7 @@ int mogan_prof_dump(const char* path) {
 // out: rows of 5 doubles {mode, cfg, launches, algorithmic flops, milliseconds}, one per (mode,cfg) seen
 int mogan_prof_collect(double* out, int max_rows) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    double acc[4][NCFG][3] = {};
+    double acc[6][NCFG][3] = {};
     for (auto& r : g_prof) {
         hipEventSynchronize(r.e1);
         float ms = 0.f;
@@ -592,7 +613,7 @@ int mogan_prof_collect(double* out, int max_rows) {
     }
     g_prof.clear();
     int n = 0;
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 6; ++m)
         for (int c = 0; c < NCFG; ++c)
             if (acc[m][c][0] > 0 && n < max_rows) {
                 double* o = out + 5 * n++;
@@ -611,6 +632,12 @@ int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, in
 int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                      int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    if (mogan_use_dconv && g_force_cfg < 0) {
+        mogan_prof_begin(4, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
+        rc = mogan_dconv_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
@@ -620,6 +647,12 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
 int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    if (mogan_use_dconv && g_force_cfg < 0) {
+        mogan_prof_begin(5, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
+        rc = mogan_dconv_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     // dx is the gradient w.r.t. the conv input in the (upsampled) H x W domain: (B,Cin,H,W)
     p.A = w; p.B = dy; p.C = dx; p.M = Cin; p.K = Cout * p.nkh * p.nkw; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cout * p.OH * p.OW;

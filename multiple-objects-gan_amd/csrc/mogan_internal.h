@@ -1,0 +1,19 @@
+// Internal (non-ABI) cross-translation-unit helpers of libmogan_hip.so.  Hidden visibility: the exported
+// symbol set stays exactly what include/mogan_hip.h declares.
+#ifndef MOGAN_INTERNAL_H
+#define MOGAN_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#define MOGAN_HIDDEN __attribute__((visibility("hidden")))
+
+// direct (halo-tile) convolution; return 1 = handled, 0 = shape not eligible, < 0 = error
+MOGAN_HIDDEN int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout,
+                                     int KH, int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes,
+                                     hipStream_t st);
+MOGAN_HIDDEN int mogan_dconv_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws,
+                                       int Cout, int KH, int KW, int stride, int ph, int pw, int up, void* ws,
+                                       size_t ws_bytes, hipStream_t st);
+MOGAN_HIDDEN void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st);
+MOGAN_HIDDEN void mogan_prof_end(int taken, hipStream_t st);
+MOGAN_HIDDEN extern int mogan_use_dconv;
+#endif

@@ -54,6 +54,14 @@ CONV_CASES = [
     (2, 6, 12, 12, 8, (5, 5), 1, (2, 2), 0),       # Inception 5x5
     (1, 96, 32, 32, 96, (3, 3), 1, (1, 1), 0),     # 96-wide tile config
     (2, 160, 8, 8, 130, (3, 3), 1, (1, 1), 0),     # 128x128 tiles with ragged edges + long K
+    # shapes that take the direct (halo-tile) kernel when no tile config is forced (>= 64 channels each side)
+    (2, 64, 32, 32, 72, (3, 3), 1, (1, 1), 0),     # 3x3 s1, Cw=32, ragged M
+    (2, 64, 16, 16, 64, (3, 3), 1, (1, 1), 1),     # upBlock: 16x16 -> 32x32
+    (3, 64, 16, 16, 100, (3, 3), 1, (1, 1), 0),    # Cw=16, R=8; 96-wide M tile + ragged M
+    (1, 64, 64, 128, 64, (3, 3), 1, (1, 1), 0),    # non-square
+    (2, 256, 16, 16, 64, (3, 3), 1, (1, 1), 0),    # split over channel chunks
+    (2, 64, 64, 64, 72, (4, 4), 2, (1, 1), 0),     # 4x4 s2 -> 32x32; dgrad = four 2x2 parity convs in one launch
+    (2, 64, 32, 32, 256, (4, 4), 2, (1, 1), 0),    # 4x4 s2 -> 16x16; parity dgrad with channel split
 ]
 
 

@@ -37,7 +37,7 @@ from mogan_amd.attngan.trainer import TrainEngine, build_networks  # noqa: E402
 from mogan_amd.hip import lib  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-MODES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bmm", "dconv_fwd", "dconv_dgrad")
+MODES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bmm", "dconv_fwd", "dconv_dgrad", "dconv_wgrad")
 TILES = ("128x128", "96x128", "128x32", "32x128", "64x64")
 
 
@@ -71,7 +71,7 @@ def roofline_leg(engine, run_step, steps=2):
     rows = []
     for i in range(n):
         m, c, launches, flops, ms = buf[5 * i:5 * i + 5]
-        name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)]) if m < 4 else "dconv_fwd_kernel<%s>" % MODES[int(m)][6:]
+        name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)]) if m < 4 else ("dconv_wgrad_kernel" if int(m) == 6 else "dconv_fwd_kernel<%s>" % MODES[int(m)][6:])
         rows.append(dict(kernel=name,
                          launches_per_step=launches / steps, gflop_per_step=flops / steps / 1e9,
                          ms_per_step=ms / steps, tflops=(flops / 1e12) / (ms / 1e3) if ms > 0 else 0.0))

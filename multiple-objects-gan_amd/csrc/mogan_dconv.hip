@@ -52,14 +52,15 @@ template <int KH, int KW, int S, int WM, int WN, int TM, int TN, int CK>
 __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     constexpr int BM = WM * TM * 32, NTB = WN * TN, PX = NTB * 32, KHW = KH * KW, KC = CK * KHW;
     constexpr int WWP = ((31 * S + KW) + 3) & ~3, HHMAX = 7 * S + KH, CPL = HHMAX * WWP;
-    constexpr int LDW = KC | 1;                                  // odd row stride: conflict-free A reads
+    constexpr int LDW = KC + 4;      // 16-byte aligned rows: b128 LDS stores; the 4-way conflict of the A reads
+                                     // (8 LDS cycles per k-step) is hidden behind TM*TN 64-cycle MFMAs
     // halo elements per thread: the larger of the two block shapes (R=4,Cw=32) and (R=8,Cw=16)
     constexpr int HALO_A = (3 * S + KH) * (31 * S + KW), HALO_B = (7 * S + KH) * (15 * S + KW);
     constexpr int NXE = (CK * (HALO_A > HALO_B ? HALO_A : HALO_B) + 255) / 256;
     constexpr int NWQ = (BM * (KC / 4) + 255) / 256;             // weight quads per thread
     static_assert(WM * WN == 4 && KC % 4 == 0 && CK % 2 == 0, "tile");
     __shared__ float Xs[CK * CPL];
-    __shared__ float Wl[BM * LDW];
+    __shared__ __attribute__((aligned(16))) float Wl[BM * LDW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
         for (int i = 0; i < NXE; ++i) if (xl[i] >= 0) Xs[xl[i]] = rx[i];
 #pragma unroll
         for (int i = 0; i < NWQ; ++i)
-            if (wl[i] >= 0) { Wl[wl[i]] = rw[i][0]; Wl[wl[i] + 1] = rw[i][1]; Wl[wl[i] + 2] = rw[i][2]; Wl[wl[i] + 3] = rw[i][3]; }
+            if (wl[i] >= 0) *(f32x4*)&Wl[wl[i]] = rw[i];
     };
 
     f32x16 acc[TM][TN];
@@ -205,6 +206,149 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ weight gradient
+// dW[co][(ci,kh,kw)] = sum over pixels dY[co][pix] * X[ci][pix*S - p + (kh,kw)]:  M = co, N = (ci,kh,kw), K = pixels.
+// K-chunk = a tile of 64 output pixels (RT x CW) of one image: Ys[BM][64] (dY, 16-byte loads) and the halo tile
+// Xs[CKW][HHW][WWP] of the <= CKW input channels this block's 128 columns touch.  Lanes carry the column
+// (ci,kh,kw) -> per-lane LDS base; the pixel pair of each k-step is a compile-time offset.
+struct WGradP {
+    const float* dY; const float* X; float* dW; float* ws;
+    int B, Cin, Cout, Hs, Ws, H, W, up, OH, OW, pt, pl;
+    int N;                    // Cin*KH*KW
+    int tiles_x, tiles_y, ntiles, tps, nsplit;     // pixel tiles, tiles per split
+    long long slab; int accumulate;
+    unsigned x_bytes, y_bytes;
+};
+
+template <int KH, int KW, int S, int CW, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, KHW = KH * KW, PXK = 64, RT = PXK / CW;
+    constexpr int HHW = (RT - 1) * S + KH, WW = (CW - 1) * S + KW, WWP = (WW + 3) & ~3, CPLW = HHW * WWP;
+    constexpr int CKW = BN / KHW + 2, LDY = PXK + 4;
+    constexpr int NXE = (CKW * HHW * WW + 255) / 256, NYQ = BM * (PXK / 4) / 256;
+    static_assert(WM * WN == 4 && BN == 128, "tile");
+    __shared__ __attribute__((aligned(16))) float Ys[BM * LDY];
+    __shared__ float Xs[CKW * CPLW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, sp = blockIdx.z;
+    const int ci_first = n0 / KHW;
+    const int t_beg = sp * p.tps, t_end = min(p.ntiles, t_beg + p.tps);
+    const int HsWs = p.Hs * p.Ws;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, (short)0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, (short)0, (int)p.y_bytes, 0x00020000);
+
+    // staging plans
+    unsigned xc[NXE]; int xhy[NXE], xhx[NXE], xl[NXE];
+#pragma unroll
+    for (int i = 0; i < NXE; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (HHW * WW), r = e - c * (HHW * WW);
+        const int hy = r / WW, hx = r - hy * WW;
+        const bool ok = e < CKW * HHW * WW && ci_first + c < p.Cin;
+        xc[i] = ok ? (unsigned)((ci_first + c) * HsWs) : IDX_OOB;
+        xhy[i] = hy; xhx[i] = hx;
+        xl[i] = e < CKW * HHW * WW ? c * CPLW + hy * WWP + hx : -1;
+    }
+    unsigned yg[NYQ]; int yl[NYQ];
+#pragma unroll
+    for (int i = 0; i < NYQ; ++i) {
+        const int q = tid + 256 * i;
+        const int row = q / (PXK / 4), p0 = 4 * (q - row * (PXK / 4));
+        const int ry = p0 / CW, rxx = p0 - ry * CW;
+        yg[i] = m0 + row < p.Cout ? (unsigned)((m0 + row) * p.OH * p.OW + ry * p.OW + rxx) : IDX_OOB;
+        yl[i] = row * LDY + p0;
+    }
+    float rx[NXE]; f32x4 ry4[NYQ];
+    auto load_tile = [&](int t) {
+        const int tx = t % p.tiles_x; int u = t / p.tiles_x;
+        const int ty = u % p.tiles_y; const int img = u / p.tiles_y;
+        const int oy0 = ty * RT, ox0 = tx * CW;
+        const int iyb = oy0 * S - p.pt, ixb = ox0 * S - p.pl;
+        const unsigned xb = (unsigned)img * p.Cin * HsWs;
+        const unsigned yb = (unsigned)img * p.Cout * p.OH * p.OW + oy0 * p.OW + ox0;
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const int iy = iyb + xhy[i], ix = ixb + xhx[i];
+            const bool ok = xc[i] != IDX_OOB && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            rx[i] = ldg(rX, ok ? xb + xc[i] + (iy >> p.up) * p.Ws + (ix >> p.up) : IDX_OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < NYQ; ++i) ry4[i] = ldg4(rY, yg[i] == IDX_OOB ? IDX_OOB : yb + yg[i]);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) if (xl[i] >= 0) Xs[xl[i]] = rx[i];
+#pragma unroll
+        for (int i = 0; i < NYQ; ++i) *(f32x4*)&Ys[yl[i]] = ry4[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int abase = (wm * TM * 32 + (lane & 31)) * LDY + h;
+    int bbase[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int n = n0 + (wn * TN + t) * 32 + (lane & 31);
+        const int ci = n / KHW, tap = n - ci * KHW;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        bbase[t] = n < p.N ? (ci - ci_first) * CPLW + kh * WWP + kw + h * S : 0;
+    }
+
+    if (t_beg < t_end) {
+        load_tile(t_beg);
+        store_tile();
+        __syncthreads();
+        for (int t = t_beg; t < t_end; ++t) {
+            if (t + 1 < t_end) load_tile(t + 1);
+#pragma unroll
+            for (int pp = 0; pp < PXK / 2; ++pp) {
+                constexpr int dummy = 0; (void)dummy;
+                const int ry = (2 * pp) / CW, rxx = (2 * pp) % CW;
+                float a[TM], b[TN];
+#pragma unroll
+                for (int q = 0; q < TM; ++q) a[q] = Ys[abase + q * 32 * LDY + 2 * pp];
+#pragma unroll
+                for (int q = 0; q < TN; ++q) b[q] = Xs[bbase[q] + ry * S * WWP + rxx * S];
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TN; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            }
+            __syncthreads();
+            if (t + 1 < t_end) { store_tile(); __syncthreads(); }
+        }
+    }
+
+    float* __restrict__ Wg = (p.nsplit > 1) ? (p.ws + (size_t)sp * p.slab) : p.dW;
+    const bool addc = (p.nsplit == 1) && p.accumulate;
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int n = n0 + (wn * TN + tb) * 32 + (lane & 31);
+#pragma unroll
+        for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < p.N && m < p.Cout) {
+                    float* dst = Wg + (size_t)m * p.N + n;
+                    float v = acc[ta][tb][r];
+                    if (addc) v += *dst;
+                    *dst = v;
+                }
+            }
+    }
+}
+
 // weight transforms for the data gradient ---------------------------------------------------------------------
 // s1: Wd[ci][co][kh][kw] = W[co][ci][KH-1-kh][KW-1-kw]
 __global__ __launch_bounds__(256) void wflip_kernel(const float* __restrict__ w, float* __restrict__ wd, int Cout, int Cin,
@@ -271,6 +415,35 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 
+template <int KH, int KW, int S>
+static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
+    const bool m96 = cdiv(p.Cout, 96) * 96 < cdiv(p.Cout, 128) * 128;
+    const int bm = m96 ? 96 : 128;
+    const int cw = std::min(32, p.OW), rt = 64 / cw;
+    p.tiles_x = p.OW / cw; p.tiles_y = p.OH / rt; p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const long long blocks = cdiv(p.N, 128) * cdiv(p.Cout, bm);
+    const long long w_numel = (long long)p.Cout * p.N;
+    int nsplit = (int)std::min<long long>(cdiv(640, blocks), std::max(1, p.ntiles / 2));
+    if (nsplit > 1) {
+        const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)w_numel)) : 0;
+        nsplit = fit < 2 ? 1 : (int)std::min<long long>(nsplit, fit);
+    }
+    p.tps = (int)cdiv(p.ntiles, nsplit); p.nsplit = (int)cdiv(p.ntiles, p.tps);
+    p.slab = w_numel; p.ws = (float*)ws;
+    dim3 grid((unsigned)cdiv(p.N, 128), (unsigned)cdiv(p.Cout, bm), (unsigned)p.nsplit);
+    if (cw == 32) {
+        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 1, 4, 3, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    } else {
+        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 1, 4, 3, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    }
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(cdiv(w_numel, 4), 256)), dim3(256), 0, st,
+                           (const float*)ws, p.dW, w_numel, w_numel, p.nsplit, p.accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
 }  // namespace
 
 // ---- internal entry points (hidden visibility: not part of the C ABI) ---------------------------------------
@@ -332,5 +505,24 @@ int mogan_dconv_dgrad_try(const float* dy, const float* w, float* dx, int B, int
     p.Wt = wt; p.w_bytes = 4u * Cin * Cout * 4; p.npar = 4;
     p.OH = gH; p.OW = gW; p.ys = 2; p.y0 = 0; p.x0 = 0; p.pt = 0; p.pl = 0;
     const int rc = launch_fwd<2, 2, 1, 8>(p, ws2, ws2_bytes, st);
+    return rc ? rc : 1;
+}
+
+int mogan_dconv_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                          int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
+                          hipStream_t st) {
+    const int H = Hs << up, W = Ws << up;
+    const int OH = (H + 2 * ph - KH) / stride + 1, OW = (W + 2 * pw - KW) / stride + 1;
+    const bool k33 = KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1;
+    const bool k44 = KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0;
+    if (!(k33 || k44)) return 0;
+    if (!pow2(OH) || !pow2(OW) || OW < 16 || OH < 4 || Cout < 64 || Cin * KH * KW < 256) return 0;
+    if ((((uintptr_t)dy) & 15) != 0) return 0;
+    if ((long long)B * Cin * Hs * Ws >= (1ll << 29) || (long long)B * Cout * OH * OW >= (1ll << 29)) return 0;
+    WGradP p{};
+    p.dY = dy; p.X = x; p.dW = dw; p.B = B; p.Cin = Cin; p.Cout = Cout; p.Hs = Hs; p.Ws = Ws; p.H = H; p.W = W; p.up = up;
+    p.OH = OH; p.OW = OW; p.pt = ph; p.pl = pw; p.N = Cin * KH * KW; p.accumulate = accumulate;
+    p.x_bytes = 4u * B * Cin * Hs * Ws; p.y_bytes = 4u * B * Cout * OH * OW;
+    const int rc = k33 ? launch_wgrad<3, 3, 1>(p, ws, ws_bytes, st) : launch_wgrad<4, 4, 2>(p, ws, ws_bytes, st);
     return rc ? rc : 1;
 }

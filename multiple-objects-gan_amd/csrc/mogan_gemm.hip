@@ -603,7 +603,7 @@ int mogan_prof_dump(const char* path) {
 // out: rows of 5 doubles {mode, cfg, launches, algorithmic flops, milliseconds}, one per (mode,cfg) seen
 int mogan_prof_collect(double* out, int max_rows) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    double acc[6][NCFG][3] = {};
+    double acc[7][NCFG][3] = {};
     for (auto& r : g_prof) {
         hipEventSynchronize(r.e1);
         float ms = 0.f;
@@ -613,7 +613,7 @@ int mogan_prof_collect(double* out, int max_rows) {
     }
     g_prof.clear();
     int n = 0;
-    for (int m = 0; m < 6; ++m)
+    for (int m = 0; m < 7; ++m)
         for (int c = 0; c < NCFG; ++c)
             if (acc[m][c][0] > 0 && n < max_rows) {
                 double* o = out + 5 * n++;
@@ -665,6 +665,12 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
                        int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
                        hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    if (mogan_use_dconv && g_force_cfg < 0) {
+        mogan_prof_begin(6, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, Cin * KH * KW, B * p.OH * p.OW, stream);
+        rc = mogan_dconv_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     p.A = dy; p.B = x; p.C = dw; p.M = Cout; p.N = Cin * KH * KW; p.K = B * p.OH * p.OW; p.accumulate = accumulate;
     p.a_bytes = 4u * B * Cout * p.OH * p.OW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     p.avec = ((p.OH * p.OW) % 4 == 0) && (((uintptr_t)dy & 15) == 0);

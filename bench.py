@@ -51,6 +51,22 @@ def make_device_batch(B, seed, device):
     return b, bt
 
 
+def load_traffic():
+    """HBM bytes per launch per kernel family from the committed PMC pass (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command); launch-weighted over the instantiations."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.isfile(path):
+        return {}
+    acc = {}
+    for name, v in json.load(open(path))["kernels"].items():
+        fam = name.split("<")[0]
+        n = v.get("launches") or 0
+        a = acc.setdefault(fam, [0.0, 0])
+        a[0] += ((v.get("fetch_kb_per_launch") or 0.0) + (v.get("write_kb_per_launch") or 0.0)) * 1024.0 * n
+        a[1] += n
+    return {f: (b / n if n else None) for f, (b, n) in acc.items()}
+
+
 def roofline_leg(engine, run_step, steps=2):
     """Eager steps with every gemm_kernel launch bracketed by HIP events on its stream."""
     import ctypes
@@ -126,7 +142,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = bool(os.environ.get("MOGAN_FORCE_DIST")) and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -139,7 +156,8 @@ def main():
     cfg.TRAIN.BATCH_SIZE = B
     text_encoder, image_encoder, netG, netsD = build_networks(device=device, seed=1234)   # identical replicas
     use_graph = (world == 1) and not args.no_graph
-    engine = TrainEngine(text_encoder, image_encoder, netG, netsD, distributed=world > 1, use_graph=use_graph)
+    engine = TrainEngine(text_encoder, image_encoder, netG, netsD, distributed=world > 1 or force_dist,
+                         use_graph=use_graph and not force_dist)
     batch, bt_cpu = make_device_batch(B, seed=rank, device=device)
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
 
@@ -179,32 +197,45 @@ def main():
         "config": {"workload": "MS-COCO AttnGAN 256x256 G+D train step: G_NET + D_NET64/128/256 + "
                                "GlobalAttentionGeneral + Inception/DAMSM losses (random-init), coco_train.yml "
                                "widths (GF 48, DF 96, T 12), fp32", "batch_per_gpu": B, "global_batch": world * B,
-                   "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager"},
+                   "parallelism": "dp%d" % world, "launch": "hipGraph" if engine.use_graph else "eager"},
         "losses": {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.dim() == 0},
     }
     if rank == 0 and not args.no_roofline:
         rows, eager_ms = roofline_leg(engine, run_step)
-        dom = rows[0]
+        fams = {}
+        for r in rows:                                   # kernel families = the three MFMA kernels of csrc/
+            f = r["kernel"].split("<")[0]
+            a = fams.setdefault(f, dict(kernel=f, launches_per_step=0.0, gflop_per_step=0.0, ms_per_step=0.0))
+            for k in ("launches_per_step", "gflop_per_step", "ms_per_step"):
+                a[k] += r[k]
+        traffic = load_traffic()
+        for f, a in fams.items():
+            a["tflops"] = a["gflop_per_step"] / a["ms_per_step"] if a["ms_per_step"] else 0.0
+            a["frac"] = a["tflops"] / PEAK_F32_MFMA_TFLOPS
+            a["traffic_bytes_per_launch"] = traffic.get(f)
+        dom = max(fams.values(), key=lambda a: a["ms_per_step"])
         tot_ms = sum(r["ms_per_step"] for r in rows)
         tot_gf = sum(r["gflop_per_step"] for r in rows)
         out["roofline"] = {
             "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": dom["frac"], "traffic": dom["traffic_bytes_per_launch"],
             "launches_per_step": dom["launches_per_step"],
             "avg_launch_ms": dom["ms_per_step"] / dom["launches_per_step"],
             "gflop_per_launch": dom["gflop_per_step"] / dom["launches_per_step"],
+            "families": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()}
+                         for a in sorted(fams.values(), key=lambda a: -a["ms_per_step"])],
             "all_gemm": {"gflop_per_step": tot_gf, "gflop_per_image": tot_gf / B, "ms_per_step": tot_ms,
                          "achieved": tot_gf / tot_ms if tot_ms else 0.0,
                          "frac": (tot_gf / tot_ms) / PEAK_F32_MFMA_TFLOPS if tot_ms else 0.0,
                          "share_of_step_ms": tot_ms / ms},
             "eager_ms_per_step": eager_ms,
-            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]],
+            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:10]],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(engine, bt_cpu, engine.encode_batch_for_cpu(batch), B)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

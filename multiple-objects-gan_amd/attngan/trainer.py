@@ -107,7 +107,7 @@ class TrainEngine:
         self.optDs = [FlatAdam(d, cfg.TRAIN.DISCRIMINATOR_LR) for d in netsD]
         self.bn_counter = BNCallCounter([netG] + list(netsD))
         self.distributed = bool(distributed) and dist.is_available() and dist.is_initialized() \
-            and dist.get_world_size() > 1
+            and (dist.get_world_size() > 1 or bool(os.environ.get("MOGAN_FORCE_DIST")))   # env: exercise the RCCL path at N=1
         self.world = dist.get_world_size() if self.distributed else 1
         self.comm_stream = torch.cuda.Stream() if self.distributed else None
         self.use_graph = use_graph
@@ -280,9 +280,15 @@ def build_networks(n_words=27297, device="cuda", image_encoder=None, seed=None):
         netsD.append(D_NET256())
     text_encoder, image_encoder, netG = text_encoder.to(device), image_encoder.to(device), netG.to(device)
     netsD = [d.to(device) for d in netsD]
-    netG.apply(weights_init)              # on the device: orthogonal init of the 160M-parameter D256
-    for d in netsD:
-        d.apply(weights_init)
+    if os.environ.get("MOGAN_FAST_INIT"):     # profiling runs: rocSOLVER's QR (orthogonal_) crashes under rocprofv3 --pmc
+        for net in [netG] + netsD:
+            for p in net.parameters():
+                if p.dim() > 1:
+                    torch.nn.init.normal_(p, 0.0, (1.0 / p[0].numel()) ** 0.5)
+    else:
+        netG.apply(weights_init)          # on the device: orthogonal init of the 160M-parameter D256
+        for d in netsD:
+            d.apply(weights_init)
     return text_encoder, image_encoder, netG, netsD
 
 

@@ -376,13 +376,20 @@ __global__ __launch_bounds__(256) void wparity_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void dconv_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            long long n, long long slab, int nsplit, int acc) {
-    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    for (long long i = i4; i < n && i < i4 + 4; ++i) {
-        float s = acc ? out[i] : 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * slab + i];
-        out[i] = s;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // fixed summation order (deterministic)
+    if (i >= n) return;
+    const float* p = ws + i;
+    float s = acc ? out[i] : 0.f;
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * slab];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; k < nsplit; ++k) s += p[(size_t)k * slab];
+    out[i] = s;
 }
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -410,7 +417,7 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK>), grid, dim3(256), 0, st, p);
     if (p.nsplit > 1)
-        hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(cdiv(y_numel, 4), 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(y_numel, 256)), dim3(256), 0, st,
                            (const float*)ws, p.Y, y_numel, y_numel, p.nsplit, p.accumulate);
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
@@ -439,7 +446,7 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
         else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
     }
     if (p.nsplit > 1)
-        hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(cdiv(w_numel, 4), 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(w_numel, 256)), dim3(256), 0, st,
                            (const float*)ws, p.dW, w_numel, w_numel, p.nsplit, p.accumulate);
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }

@@ -414,25 +414,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
 }
 
-// out[i] = (acc ? out[i] : 0) + sum_s ws[s*slab + i], fixed order
+// out[i] = (acc ? out[i] : 0) + sum_s ws[s*slab + i]: fixed summation order (deterministic).  One element per
+// thread (small outputs still give hundreds of blocks), 8 independent slab loads in flight per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                             long long n, long long slab, int nsplit, int acc) {
-    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    if (i4 + 3 < n && (slab & 3) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)ws) & 15) == 0) {
-        float4 s = acc ? *(const float4*)(out + i4) : make_float4(0, 0, 0, 0);
-        for (int k = 0; k < nsplit; ++k) {
-            const float4 v = *(const float4*)(ws + (size_t)k * slab + i4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        *(float4*)(out + i4) = s;
-    } else {
-        for (long long i = i4; i < n && i < i4 + 4; ++i) {
-            float s = acc ? out[i] : 0.f;
-            for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * slab + i];
-            out[i] = s;
-        }
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = ws + i;
+    float s = acc ? out[i] : 0.f;
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * slab];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; k < nsplit; ++k) s += p[(size_t)k * slab];
+    out[i] = s;
 }
 
 // ------------------------------------------------------------------------------ host dispatch
@@ -543,7 +542,7 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
         g_prof.push_back(rec);
     }
     if (p.nsplit > 1) {
-        const long long nblk = cdiv(cdiv(c_numel, 4), 256);
+        const long long nblk = cdiv(c_numel, 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)ws, p.C,
                            c_numel, c_numel, p.nsplit, p.accumulate);
     }

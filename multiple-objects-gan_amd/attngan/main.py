@@ -1,0 +1,88 @@
+"""Entry point of the coco-attngan variant (mirror of code/coco/attngan/main.py): same flags
+(--cfg --gpu --resume --data_dir --manualSeed), plus --synthetic N to train on generated batches when the
+COCO pickles are not present.  One process per GPU: launch with
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 main.py --cfg cfg/coco_train.yml
+(`--gpu` is kept for compatibility; the device comes from LOCAL_RANK)."""
+import argparse
+import datetime
+import os
+import pprint
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.realpath(__file__)), "..", "..")))
+    import mogan_loader
+    mogan_loader.load()
+    from mogan_amd.attngan.miscc.config import cfg, cfg_from_file
+    from mogan_amd.attngan.datasets import SyntheticTextDataset, TextDataset
+    from mogan_amd.attngan.trainer import condGANTrainer as trainer
+else:
+    from .miscc.config import cfg, cfg_from_file
+    from .datasets import SyntheticTextDataset, TextDataset
+    from .trainer import condGANTrainer as trainer
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description='Train a AttnGAN network')
+    parser.add_argument('--cfg', dest='cfg_file', help='optional config file', default='cfg/coco_train.yml', type=str)
+    parser.add_argument('--gpu', dest='gpu_id', type=str, default='0')
+    parser.add_argument('--resume', dest='resume', type=str, default='')
+    parser.add_argument('--data_dir', dest='data_dir', type=str, default='')
+    parser.add_argument('--manualSeed', type=int, help='manual seed')
+    parser.add_argument('--synthetic', type=int, default=0, help='train on N generated samples instead of COCO')
+    parser.add_argument('--max_epoch', type=int, default=None)
+    parser.add_argument('--batch_size', type=int, default=None, help='per-GPU minibatch')
+    parser.add_argument('--output_dir', type=str, default='')
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.cfg_file is not None:
+        cfg_from_file(args.cfg_file)
+    cfg.GPU_ID = args.gpu_id
+    if args.data_dir != '':
+        cfg.DATA_DIR = args.data_dir
+    if args.max_epoch is not None:
+        cfg.TRAIN.MAX_EPOCH = args.max_epoch
+    if args.batch_size is not None:
+        cfg.TRAIN.BATCH_SIZE = args.batch_size
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if rank == 0:
+        print('Using config:')
+        pprint.pprint(cfg)
+    if args.manualSeed is None:
+        args.manualSeed = 100 if not cfg.TRAIN.FLAG else random.randint(1, 10000)
+    random.seed(args.manualSeed + rank)
+    np.random.seed(args.manualSeed + rank)
+    torch.manual_seed(args.manualSeed)           # identical replicas: same init seed on every rank
+    if args.resume == '':
+        stamp = datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')
+        output_dir = args.output_dir or '../../../output/%s_%s_%s' % (cfg.DATASET_NAME, cfg.CONFIG_NAME, stamp)
+    else:
+        output_dir = args.resume
+    if args.synthetic > 0:
+        dataset = SyntheticTextDataset(args.synthetic, seed=args.manualSeed + rank)
+    else:
+        dataset = TextDataset(cfg.DATA_DIR, cfg.IMG_DIR, 'train' if cfg.TRAIN.FLAG else 'test',
+                              base_size=cfg.TREE.BASE_SIZE)
+    assert dataset
+    loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True, shuffle=True,
+                                         num_workers=min(int(cfg.WORKERS), 8 if args.synthetic else int(cfg.WORKERS)))
+    algo = trainer(output_dir, loader, dataset.n_words, dataset.ixtoword, args.resume, distributed=world > 1)
+    algo.train()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

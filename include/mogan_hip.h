@@ -153,6 +153,13 @@ int mogan_bce_fwd(const float* p, float target, float weight, float* loss, int n
                   hipStream_t stream);
 int mogan_bce_bwd(const float* p, float target, float weight, const float* gout, float* dp, int n,
                   hipStream_t stream);
+/* BCEWithLogits (mean) of raw logits x[n] against a constant target, torch's stable form
+ * max(x,0) - x*t + log1p(exp(-|x|)) -- the StackGAN-family losses (code/coco/stackgan/miscc/utils.py:68-125,
+ * code/clevr/miscc/utils.py:91-144, code/multi-mnist/miscc/utils.py:71-123).  bwd: dx = gout*w*(sigmoid(x)-t)/n */
+int mogan_bce_logits_fwd(const float* x, float target, float weight, float* loss, int n, int accumulate,
+                         hipStream_t stream);
+int mogan_bce_logits_bwd(const float* x, float target, float weight, const float* gout, float* dx, int n,
+                         hipStream_t stream);
 /* KL_loss (miscc/losses.py:230-234): loss = -0.5*mean(1 + logvar - mu^2 - exp(logvar)) */
 int mogan_kl_fwd(const float* mu, const float* logvar, float* loss, int n, hipStream_t stream);
 int mogan_kl_bwd(const float* mu, const float* logvar, const float* gout, float* dmu, float* dlogvar, int n,

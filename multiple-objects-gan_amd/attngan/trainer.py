@@ -42,8 +42,9 @@ class FlatAdam:
 
     ALIGN = 64   # elements
 
-    def __init__(self, module, lr, with_ema=False):
+    def __init__(self, module, lr, with_ema=False, eps_mode=None):
         self.module, self.lr = module, float(lr)
+        self.eps_mode = int(cfg.ADAM_EPS_MODE if eps_mode is None else eps_mode)
         self.params = [p for p in module.parameters() if p.requires_grad]
         dev = self.params[0].device
         offs, total = [], 0
@@ -67,7 +68,7 @@ class FlatAdam:
 
     def step(self, grad_scale=1.0):
         ops.adam_step(self.p, self.g, self.m, self.v, self.ema, self.lr, 0.5, 0.999, 1e-8,
-                      dev_state=self.state, eps_mode=int(cfg.ADAM_EPS_MODE), grad_scale=grad_scale)
+                      dev_state=self.state, eps_mode=self.eps_mode, grad_scale=grad_scale)
 
     def ema_params(self):
         return [self.ema[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]

@@ -181,6 +181,26 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
     if (logf(1.f - pv) > -100.f) g += (1.f - target) / (1.f - pv);
     dp[i] = gout[0] * weight * g / (float)n;
 }
+// BCEWithLogitsLoss(mean) against a constant target, torch's stable form: max(x,0) - x*t + log1p(exp(-|x|))
+__global__ __launch_bounds__(256) void bce_logits_fwd_kernel(const float* __restrict__ x, float target, float weight,
+                                                             float* __restrict__ loss, int n, int accumulate) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = x[i];
+        s += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    }
+    s = block_sum_f(s, sh);
+    if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.f) + weight * s / (float)n;
+}
+__global__ __launch_bounds__(256) void bce_logits_bwd_kernel(const float* __restrict__ x, float target, float weight,
+                                                             const float* __restrict__ gout, float* __restrict__ dx,
+                                                             int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float sg = 1.f / (1.f + expf(-x[i]));
+    dx[i] = gout[0] * weight * (sg - target) / (float)n;
+}
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
                                                      float* __restrict__ loss, int n) {
     __shared__ float sh[4];
@@ -448,6 +468,19 @@ int mogan_bce_fwd(const float* p, float target, float weight, float* loss, int n
 int mogan_bce_bwd(const float* p, float target, float weight, const float* gout, float* dp, int n, hipStream_t stream) {
     if (n <= 0) return MOGAN_ERR_SHAPE;
     hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, target, weight, gout, dp, n);
+    return ok_launch();
+}
+int mogan_bce_logits_fwd(const float* x, float target, float weight, float* loss, int n, int accumulate,
+                         hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(1), dim3(256), 0, stream, x, target, weight, loss, n, accumulate);
+    return ok_launch();
+}
+int mogan_bce_logits_bwd(const float* x, float target, float weight, const float* gout, float* dx, int n,
+                         hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(bce_logits_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, target, weight, gout, dx,
+                       n);
     return ok_launch();
 }
 int mogan_kl_fwd(const float* mu, const float* logvar, float* loss, int n, hipStream_t stream) {

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mogan_attn_bwd": [P, P, P, P, P, P, I, I, I, I, P],
     "mogan_bce_fwd": [P, F, F, P, I, I, P],
     "mogan_bce_bwd": [P, F, F, P, P, I, P],
+    "mogan_bce_logits_fwd": [P, F, F, P, I, I, P],
+    "mogan_bce_logits_bwd": [P, F, F, P, P, I, P],
     "mogan_kl_fwd": [P, P, P, I, P],
     "mogan_kl_bwd": [P, P, P, P, P, I, P],
     "mogan_reparam_fwd": [P, P, P, P, I, P],

@@ -480,6 +480,30 @@ def bce(p, target):
     return BCEFn.apply(p, float(target))
 
 
+class BCELogitsFn(torch.autograd.Function):
+    """nn.BCEWithLogitsLoss()(x, const target) (code/coco/stackgan/miscc/utils.py:73,114)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        x = _c(x).view(-1)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        call("mogan_bce_logits_fwd", ptr(x), target, 1.0, ptr(loss), x.numel(), 0, stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.target = target
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        call("mogan_bce_logits_bwd", ptr(x), ctx.target, 1.0, ptr(_c(g).view(1)), ptr(dx), x.numel(), stream_ptr())
+        return dx, None
+
+
+def bce_with_logits(x, target):
+    return BCELogitsFn.apply(x, float(target))
+
+
 class KLFn(torch.autograd.Function):
     """KL_loss (miscc/losses.py:230-234)."""
 

@@ -67,10 +67,9 @@ def _install_stubs():
 _ORIG = {}
 
 
-def load(align_corners=False):
-    """Returns a namespace with the reference modules: model, GlobalAttention, losses,
-    utils, cfg. `align_corners` patches the default of affine_grid/grid_sample
-    (torch 0.4.1 semantics = True, torch>=1.3 default = False)."""
+def _patch_torch(align_corners):
+    """Stubs + torch patches shared by every tree. `align_corners` patches the default of
+    affine_grid/grid_sample (torch 0.4.1 semantics = True, torch>=1.3 default = False)."""
     if not reference_available():
         raise RuntimeError("reference not present at %s" % REF_ROOT)
     _install_stubs()
@@ -94,6 +93,10 @@ def load(align_corners=False):
         lambda inp, grid, mode="bilinear", padding_mode="zeros", align_corners=align_corners: \
         gs(inp, grid, mode=mode, padding_mode=padding_mode, align_corners=align_corners)
 
+
+def load(align_corners=False):
+    """Returns a namespace with the reference's AttnGAN modules: model, GlobalAttention, losses, utils, cfg."""
+    _patch_torch(align_corners)
     if ATTNGAN_DIR not in sys.path:
         sys.path.insert(0, ATTNGAN_DIR)
     ns = types.SimpleNamespace()
@@ -122,3 +125,49 @@ def set_cfg(cfg, **kw):
     cfg.TRAIN.SMOOTH.GAMMA2 = 5.0
     cfg.TRAIN.SMOOTH.GAMMA3 = 10.0
     cfg.TRAIN.SMOOTH.LAMBDA = 50.0
+
+
+# ------------------------------------------------------------------ StackGAN-family trees
+TREE_DIRS = {"coco": os.path.join(REF_ROOT, "code", "coco", "stackgan"),
+             "clevr": os.path.join(REF_ROOT, "code", "clevr"),
+             "mnist": os.path.join(REF_ROOT, "code", "multi-mnist")}
+_ALL_TREE_DIRS = [ATTNGAN_DIR] + list(TREE_DIRS.values())
+
+
+def load_tree(tree, align_corners=False):
+    """Import model / miscc.config / miscc.utils of one of the sibling trees (they all use the same
+    top-level module names, so previously imported ones are purged first).  Extra stubs: cPickle,
+    torchfile, tensorboard (py2 / uninstalled imports of miscc/utils.py and trainer.py)."""
+    _patch_torch(align_corners)
+    import pickle
+    sys.modules["cPickle"] = pickle
+    _stub("torchfile")
+    _stub("tensorboard", summary=object, FileWriter=object)
+    for name in [n for n in sys.modules if n in ("model", "trainer", "GlobalAttention", "datasets")
+                 or n == "miscc" or n.startswith("miscc.")]:
+        del sys.modules[name]
+    for d in _ALL_TREE_DIRS:
+        while d in sys.path:
+            sys.path.remove(d)
+    sys.path.insert(0, TREE_DIRS[tree])
+    ns = types.SimpleNamespace()
+    ns.config = importlib.import_module("miscc.config")
+    ns.cfg = ns.config.cfg
+    ns.utils = importlib.import_module("miscc.utils")
+    ns.model = importlib.import_module("model")
+    return ns
+
+
+def set_tree_cfg(cfg, tree, stage=1, **kw):
+    cfg.CUDA = False
+    cfg.TRAIN.FLAG = True
+    cfg.USE_BBOX_LAYOUT = kw.get("USE_BBOX_LAYOUT", True)
+    cfg.Z_DIM = kw.get("Z_DIM", 100)
+    cfg.GAN.GF_DIM = kw["GF_DIM"]
+    cfg.GAN.DF_DIM = kw["DF_DIM"]
+    cfg.GAN.CONDITION_DIM = kw["CONDITION_DIM"]
+    cfg.GAN.R_NUM = kw.get("R_NUM", 2)
+    if tree == "coco":
+        cfg.STAGE = stage
+        cfg.TEXT.DIMENSION = kw.get("TEXT_DIM", 1024)
+        cfg.TRAIN.COEFF.KL = 2.0

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, det_array, det_fill_state, load_pkg, probe, probe_close
+from helpers import AdamDeltaCheck, GOLDEN, det_array, det_fill_state, load_pkg, probe, probe_close
 from standin import StandInEncoder
 
 load_pkg()
@@ -225,6 +225,8 @@ def test_two_train_steps(use_graph):
     g = golden("step")
     G, Ds, enc = _build_all()
     eng = TrainEngine(None, enc, G, Ds, use_graph=use_graph)
+    nets = [("G", G)] + [("D%d" % i, D) for i, D in enumerate(Ds)]
+    init = {n: {k: probe(v) for k, v in net.state_dict().items()} for n, net in nets}
     for step in range(2):
         bt = synthetic.to_device(synthetic.make_batch(4, words_num=5, nef=16, seed=100 + step), DEV)
         logs = eng.step(bt)
@@ -250,3 +252,9 @@ def test_two_train_steps(use_graph):
                                 what="D%d %s" % (i, k))
         for (k, _), a in zip(G.named_parameters(), eng.optG.ema_params()):
             probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], 1e-4, what="ema " + k)
+        # the Adam update itself, judged on parameter deltas (see helpers.AdamDeltaCheck)
+        for n, net in nets:
+            deltas = AdamDeltaCheck(lr=2e-4)
+            for k, v in net.named_parameters():
+                deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))])
+            deltas.check(0.15 if n == "G" else 0.05, what="%s step %d" % (n, step))

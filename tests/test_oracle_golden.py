@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, det_array, load_pkg, probe, probe_close
+from helpers import AdamDeltaCheck, GOLDEN, det_array, load_pkg, probe, probe_close
 from oracle import attngan_oracle as O
 from standin import StandInEncoder
 
@@ -263,6 +263,8 @@ def test_two_train_steps():
     cfg = SMALL
     G, Ds, enc = _build_all(cfg)
     st = O.TrainState(G, Ds, cfg)
+    nets = [("G", G)] + [("D%d" % i, D) for i, D in enumerate(Ds)]
+    init = {n: {k: probe(v) for k, v in O.parameters(net)} for n, net in nets}
     for step in range(2):
         bt = synthetic.make_batch(4, words_num=cfg.words_num, nef=cfg.emb_dim, seed=100 + step)
         logs = O.train_step(st, bt, enc)
@@ -283,3 +285,8 @@ def test_two_train_steps():
                                 what="D%d %s" % (i, k))
         for (k, _), a in zip(O.parameters(G), st.ema):
             probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], tol, what="ema " + k)
+        for n, net in nets:                       # the Adam update itself (helpers.AdamDeltaCheck)
+            deltas = AdamDeltaCheck(lr=2e-4)
+            for k, v in O.parameters(net):
+                deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))])
+            deltas.check(0.02, what="%s step %d" % (n, step))

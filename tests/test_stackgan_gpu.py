@@ -1,0 +1,175 @@
+"""HIP path of the StackGAN-family trees (coco-stackgan stage I/II, clevr, multi-mnist) against the golden
+vectors captured from the reference (tests/golden/stackgan_*.npz) -- forward, gradients, BN running statistics,
+losses and the two-step train trajectory (eager and hipGraph).  Tolerances follow SURVEY.md §8(c): generated
+tensors max-abs <= 1e-4-ish, scalar losses rel 1e-5 (first step), D grads 1e-4, G grads 1e-2 (fp32 through the
+stacked BN generator is ill-conditioned), post-Adam parameters through abs-sum-relative checksums."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import AdamDeltaCheck, checksum_close, det_fill_state, load_pkg, probe, probe_close
+from stackgan_cases import CASES, T, golden, sub
+
+pytestmark = pytest.mark.gpu
+load_pkg()
+from mogan_amd.stackgan import synthetic  # noqa: E402
+from mogan_amd.stackgan.engine import StackGANEngine  # noqa: E402
+from mogan_amd.attngan.synthetic import to_device  # noqa: E402
+
+DEV = "cuda"
+# absolute tolerance on generated pixels.  coco_s2 runs the full-width (68 M parameter) stage-II generator at
+# B=2: an fp64 run of the oracle differs from the fp32 reference itself by max-abs 9.1e-5 (rms 1.7e-5), the HIP
+# path by 1.35e-4 -- both fp32 paths sit ~1e-4 from the exact result.
+NOISE = {"coco_s1": 2e-4, "clevr": 2e-4, "mnist": 2e-4, "coco_s2": 5e-4}
+
+
+def tree_modules(tree):
+    if tree == "coco":
+        from mogan_amd.stackgan.coco import model
+        from mogan_amd.stackgan.coco.miscc.config import cfg
+    elif tree == "clevr":
+        from mogan_amd.stackgan.clevr import model
+        from mogan_amd.stackgan.clevr.miscc.config import cfg
+    else:
+        from mogan_amd.stackgan.multi_mnist import model
+        from mogan_amd.stackgan.multi_mnist.miscc.config import cfg
+    return model, cfg
+
+
+def build(case, device=DEV):
+    tree, stage, B, kw = CASES[case]
+    model, cfg = tree_modules(tree)
+    cfg.GAN.GF_DIM, cfg.GAN.DF_DIM, cfg.GAN.CONDITION_DIM = kw["gf_dim"], kw["df_dim"], kw["cond_dim"]
+    cfg.GAN.R_NUM = kw.get("r_num", 2)
+    cfg.USE_BBOX_LAYOUT = True
+    if tree == "coco":
+        cfg.STAGE, cfg.TEXT.DIMENSION = stage, kw["text_dim"]
+    if stage == 2:
+        G, D = model.STAGE2_G(model.STAGE1_G()), model.STAGE2_D()
+    else:
+        G, D = model.STAGE1_G(), model.STAGE1_D()
+    det_fill_state(G, "G.")
+    det_fill_state(D, "D.")
+    return tree, stage, B, cfg, model, G.to(device).train(), D.to(device).train()
+
+
+def close(got, want, rtol, atol=0.0, what=""):
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=rtol, atol=atol, err_msg=what)
+
+
+def run_g(G, tree, stage, b):
+    if tree == "coco" and stage == 2:
+        s1, fake, mu, logvar, ll = G(b["txt_embedding"], b["z"], b["tmi"], b["tm_s2"], b["tmi_s2"], b["label_one_hot"],
+                                     eps=b["eps"], eps_s1=b["eps_s1"])
+        return fake, mu, logvar, ll, s1
+    if tree == "coco":
+        _, fake, mu, logvar, ll = G(b["txt_embedding"], b["z"], b["tmi"], b["label_one_hot"], eps=b["eps"])
+        return fake, mu, logvar, ll, None
+    out = G(b["z"], b["tmi"], b["label_one_hot"])
+    return (out[1] if isinstance(out, tuple) else out), None, None, None, None
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_networks(case):
+    g = golden("stackgan_%s_nets" % case)
+    tree, stage, B, cfg, model, G, D = build(case)
+    assert list(G.state_dict().keys()) == [str(k) for k in g["g_keys"]]
+    assert list(D.state_dict().keys()) == [str(k) for k in g["d_keys"]]
+    b = to_device(synthetic.make_batch(tree, B, stage=stage, seed=21, text_dim=12), DEV)
+    b["z"] = b["z"].clone().requires_grad_(True)
+    fake, mu, logvar, ll, s1 = run_g(G, tree, stage, b)
+    loss = (fake * T("G.gimg", fake.shape).to(DEV)).sum()
+    if mu is not None:
+        loss = loss + (mu * T("G.gmu", mu.shape).to(DEV)).sum() + (logvar * T("G.glv", logvar.shape).to(DEV)).sum()
+    loss.backward()
+    close(sub(fake), g["fake_sub"], rtol=1e-3, atol=NOISE[case], what="fake")
+    probe_close(probe(fake), g["fake_p"], 1e-4, what="fake probe")
+    if s1 is not None:
+        close(sub(s1), g["s1_sub"], rtol=1e-3, atol=1e-4, what="stage-I image")
+    if "dz" in g.files:
+        assert float((b["z"].grad.cpu() - torch.from_numpy(g["dz"])).norm() / np.linalg.norm(g["dz"])) < 1e-2
+    if mu is not None:
+        close(mu, g["mu"], rtol=1e-4, atol=1e-5)
+        close(logvar, g["logvar"], rtol=1e-4, atol=1e-5)
+        close(ll, g["local_labels"], rtol=1e-3, atol=1e-4)
+    for k, p in G.named_parameters():
+        key = "gg_" + k.replace(".", "__")
+        if key in g.files:
+            probe_close(probe(p.grad), g[key], 1e-2, what="G grad " + k)
+    for k, v in G.state_dict().items():
+        if "running" in k:
+            probe_close(probe(v), g["gs_" + k.replace(".", "__")], 1e-4, what=k)
+    # discriminator
+    tm, tmi = (b["tm_s2"], b["tmi_s2"]) if stage == 2 else (b["tm"], b["tmi"])
+    x = b["real_imgs"].clone().requires_grad_(True)
+    f = D(x, b["label_one_hot"], tm, tmi)
+    cond = T("D.cond", (B, 128), 0.5).to(DEV) if tree == "coco" else b["label_one_hot"].sum(1)
+    c = D.get_cond_logits(f, cond)
+    cw = D.get_cond_logits(f[:B - 1], cond[1:])
+    loss = (f * T("D.gf", f.shape).to(DEV)).sum() + (c * T("D.gc", c.shape).to(DEV)).sum() \
+        + (cw * T("D.gcw", cw.shape).to(DEV)).sum()
+    if D.get_uncond_logits is not None:
+        u = D.get_uncond_logits(f)
+        loss = loss + (u * T("D.gu", u.shape).to(DEV)).sum()
+        close(u, g["d_uncond"], rtol=1e-3, atol=1e-4)
+    loss.backward()
+    close(f, g["d_feat"], rtol=1e-3, atol=1e-4)
+    close(c, g["d_cond"], rtol=1e-3, atol=1e-4)
+    close(cw, g["d_wrong"], rtol=1e-3, atol=1e-4)
+    probe_close(probe(x.grad), g["d_dx_p"], 1e-3, what="dx")
+    for k, p in D.named_parameters():
+        probe_close(probe(p.grad), g["dg_" + k.replace(".", "__")], 5e-3 if p.dim() == 1 else 1e-3,
+                    what="D grad " + k)
+    for k, v in D.state_dict().items():
+        if "running" in k:
+            probe_close(probe(v), g["ds_" + k.replace(".", "__")], 1e-4, what=k)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("case", list(CASES))
+def test_two_train_steps(case, use_graph):
+    """S/trainer.py:188-231 op order (D updated before the G loss goes through it), Adam, BN buffers."""
+    g = golden("stackgan_%s_step" % case)
+    tree, stage, B, cfg, model, G, D = build(case)
+    variant = model.VARIANT
+    init = {name: {k: probe(v) for k, v in net.state_dict().items() if v.is_floating_point()}
+            for name, net in (("G", G), ("D", D))}
+    trainable = {name: {k for k, p_ in net.named_parameters() if p_.requires_grad} for name, net in (("G", G), ("D", D))}
+    eng = StackGANEngine(G, D, cfg, variant, stage=stage, use_graph=use_graph)
+    for step in range(2):
+        b = to_device(synthetic.make_batch(tree, B, stage=stage, seed=300 + step, text_dim=12), DEV)
+        logs = eng.step(b)
+        p = "s%d_" % step
+        chaotic = case == "coco_s2" and step > 0
+        for k in ("errD", "errD_real", "errD_wrong", "errD_fake", "errG") + (("kl",) if variant.text else ()):
+            np.testing.assert_allclose(float(logs[k]), float(g[p + k]), rtol=3e-2 if chaotic else 2e-4 * (1 + 20 * step),
+                                       err_msg=k)
+        if chaotic:
+            # Second step of the full-width stage-II generator at B=2: the first Adam step moved 68 M weights by
+            # +-lr each and the sign of near-zero gradients is fp32 noise, so the *reference's own* fp32 trajectory
+            # is already max-abs 6.3e-2 / rms 8.9e-3 away from an fp64 run of the same step (losses: errG 0.7 %,
+            # errD_fake 1.9 %; measured with oracle/stackgan_oracle.py in float64).  Judge at that noise level.
+            d = sub(logs["fake"]).cpu().numpy() - g[p + "fake_sub"]
+            assert np.sqrt((d ** 2).mean()) < 2.5e-2 and np.abs(d).max() < 0.25, (np.sqrt((d ** 2).mean()), np.abs(d).max())
+        else:
+            close(sub(logs["fake"]), g[p + "fake_sub"], rtol=2e-3 * (1 + 10 * step), atol=NOISE[case] * (1 + 10 * step))
+        for name, net in (("G", G), ("D", D)):
+            deltas = AdamDeltaCheck(lr=2e-4)
+            for k, v in net.state_dict().items():
+                if v.is_floating_point():
+                    want = g["%s%s_%s" % (p, name, k.replace(".", "__"))]
+                    # checksums of the tensor; the sampled elements are judged through their Adam deltas below
+                    checksum_close(probe(v), want, (2e-3 if v.dim() == 1 else 5e-4) * (1 + 4 * step),
+                                   what=name + " " + k)
+                    if k in trainable[name] and not (tree == "mnist" and k.startswith("label.")):
+                        deltas.add(init[name][k], probe(v), want)
+                    elif "running" not in k:
+                        np.testing.assert_array_equal(probe(v), init[name][k], err_msg="frozen " + k)
+                elif k.endswith("num_batches_tracked"):
+                    want = g["%s%s_%s" % (p, name, k.replace(".", "__"))]
+                    assert float(v) == float(want[0]), k
+            # G gradients through the stacked BN generator are ill-conditioned in fp32 (rel-L2
+            # 1.7e-3..3.2e-3 between fp32 and fp64 runs of the reference itself) -> more sign flips than in D
+            # (the chaotic second step of coco_s2, see above, doubles that)
+            deltas.check((0.30 if chaotic else 0.15) if name == "G" else (0.10 if chaotic else 0.05),
+                         what="%s %s step %d" % (case, name, step))

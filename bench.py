@@ -68,10 +68,15 @@ def load_traffic():
 
 
 def roofline_leg(engine, run_step, steps=2):
-    """Eager steps with every gemm_kernel launch bracketed by HIP events on its stream."""
+    """Eager steps with every MFMA-kernel launch bracketed by HIP events on its stream.  The branches are kept on
+    ONE stream for this leg (no side streams), so a launch's duration is that kernel alone on the GPU."""
     import ctypes
-    g = engine.use_graph
+    from mogan_amd.hip import ops
+    g, ms_, wg = engine.use_graph, getattr(engine, "multi_stream", False), ops._WGRAD_ENV
     engine.use_graph = False
+    if hasattr(engine, "multi_stream"):
+        engine.multi_stream = False
+    ops._WGRAD_ENV = False
     run_step()                                        # eager warm-up (allocator)
     torch.cuda.synchronize()
     lib.call("mogan_prof_enable", 1)
@@ -84,6 +89,9 @@ def roofline_leg(engine, run_step, steps=2):
     n = lib.load().mogan_prof_collect(ctypes.cast(buf, ctypes.c_void_p), 32)
     lib.call("mogan_prof_enable", 0)
     engine.use_graph = g
+    if hasattr(engine, "multi_stream"):
+        engine.multi_stream = ms_
+    ops._WGRAD_ENV = wg
     rows = []
     for i in range(n):
         m, c, launches, flops, ms = buf[5 * i:5 * i + 5]
@@ -133,7 +141,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="minibatch per GPU (BASELINE config: 16)")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (N=1 only) instead "
+                    "of eager multi-stream launches (the default: measured faster once the independent branches "
+                    "and the weight gradients run on side streams)")
+    ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--debug-losses", action="store_true", help="print the losses of every step (adds a host sync)")
@@ -155,7 +166,7 @@ def main():
     B = args.batch
     cfg.TRAIN.BATCH_SIZE = B
     text_encoder, image_encoder, netG, netsD = build_networks(device=device, seed=1234)   # identical replicas
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (world == 1) and args.graph and not args.no_graph
     engine = TrainEngine(text_encoder, image_encoder, netG, netsD, distributed=world > 1 or force_dist,
                          use_graph=use_graph and not force_dist)
     batch, bt_cpu = make_device_batch(B, seed=rank, device=device)
@@ -197,7 +208,9 @@ def main():
         "config": {"workload": "MS-COCO AttnGAN 256x256 G+D train step: G_NET + D_NET64/128/256 + "
                                "GlobalAttentionGeneral + Inception/DAMSM losses (random-init), coco_train.yml "
                                "widths (GF 48, DF 96, T 12), fp32", "batch_per_gpu": B, "global_batch": world * B,
-                   "parallelism": "dp%d" % world, "launch": "hipGraph" if engine.use_graph else "eager"},
+                   "parallelism": "dp%d" % world,
+                   "launch": "hipGraph" if engine.use_graph else "eager, %d streams + wgrad side streams" % (
+                       1 + (len(engine.side) if engine.multi_stream else 0))},
         "losses": {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.dim() == 0},
     }
     if rank == 0 and not args.no_roofline:

@@ -6,12 +6,17 @@ Same function names / arguments / return values as the reference.  Differences u
   * words_loss evaluates all (image, caption) pairs in three batched launches instead of the
     reference's B-iteration python loop over func_attention (losses.py:72-112).
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from ...hip import ops
 from .config import cfg
+
+
+_nullctx = contextlib.nullcontext
 
 
 def _call_d(netD, img, local_labels, transf_matrices, transf_matrices_inv):
@@ -105,32 +110,45 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
 
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,
                    cap_lens, class_ids, gpus=None, local_labels=None, transf_matrices=None,
-                   transf_matrices_inv=None, return_logs=True):
+                   transf_matrices_inv=None, return_logs=True, streams=None):
     """losses.py:177-226.  Returns (errG_total, logs) like the reference; `return_logs=False` skips the
-    .item() host syncs (needed under hipGraph capture) and returns a dict of 0-dim tensors instead."""
+    .item() host syncs (needed under hipGraph capture) and returns a dict of 0-dim tensors instead.
+    `streams` (len(netsD)+1 side streams, already waiting on the current one): the D_i branches and the
+    Inception/DAMSM branch are independent until their losses are summed, so each runs on its own stream and
+    autograd replays the backward of each branch on that same stream."""
     numDs = len(netsD)
     batch_size = real_labels.size(0)
-    errG_total = 0
     parts = {}
+
+    def on(k):
+        return torch.cuda.stream(streams[k]) if streams is not None else _nullctx()
+
     for i in range(numDs):
-        if i == 0:
-            features = netsD[i](fake_imgs[i], local_labels, transf_matrices, transf_matrices_inv)
-        else:
-            features = netsD[i](fake_imgs[i])
-        g_loss = ops.bce(netsD[i].COND_DNET(features, sent_emb), 1.0)
-        if netsD[i].UNCOND_DNET is not None:
-            g_loss = ops.bce(netsD[i].UNCOND_DNET(features), 1.0) + g_loss
-        errG_total = errG_total + g_loss
-        parts['g_loss%d' % i] = g_loss
-        if i == (numDs - 1):
-            region_features, cnn_code = image_encoder(fake_imgs[i])
-            w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
-                                             class_ids, batch_size)
-            w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-            s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
-            s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-            errG_total = errG_total + w_loss + s_loss
-            parts['w_loss'], parts['s_loss'] = w_loss, s_loss
+        with on(i):
+            if i == 0:
+                features = netsD[i](fake_imgs[i], local_labels, transf_matrices, transf_matrices_inv)
+            else:
+                features = netsD[i](fake_imgs[i])
+            g_loss = ops.bce(netsD[i].COND_DNET(features, sent_emb), 1.0)
+            if netsD[i].UNCOND_DNET is not None:
+                g_loss = ops.bce(netsD[i].UNCOND_DNET(features), 1.0) + g_loss
+            parts['g_loss%d' % i] = g_loss
+    with on(numDs):
+        region_features, cnn_code = image_encoder(fake_imgs[numDs - 1])
+        w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
+                                         class_ids, batch_size)
+        w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+        s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+        s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    if streams is not None:
+        cur = torch.cuda.current_stream()
+        for st in streams[:numDs + 1]:
+            cur.wait_stream(st)
+    errG_total = 0
+    for i in range(numDs):                       # same summation order as the reference loop
+        errG_total = errG_total + parts['g_loss%d' % i]
+    errG_total = errG_total + w_loss + s_loss
+    parts['w_loss'], parts['s_loss'] = w_loss, s_loss
     if not return_logs:
         return errG_total, parts
     logs = ''.join('%s: %.2f ' % (k, v.item()) for k, v in parts.items())

@@ -115,6 +115,11 @@ class TrainEngine:
         self._graph = None
         self._static = None
         self.last = {}
+        # independent branches of the step (the three D updates; in the G step the three D forwards and the
+        # Inception/DAMSM branch) run on side streams so that their many small launches overlap; captured, they
+        # become parallel branches of the hipGraph.  MOGAN_STREAMS=0 keeps everything on one stream.
+        self.multi_stream = os.environ.get("MOGAN_STREAMS", "1") != "0"
+        self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
 
     # -- data parallel: sum all-reduce of a flat gradient bucket over RCCL on a side stream ----------
     def _allreduce_async(self, flat):
@@ -126,6 +131,21 @@ class TrainEngine:
         if pending is not None:
             torch.cuda.current_stream().wait_event(pending)
         flat.step(grad_scale=1.0 / self.world)
+
+    def _d_loss(self, i, b, fake_imgs, real_labels, fake_labels):
+        kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
+                  transf_matrices_inv=b["tmi"]) if i == 0 else {}
+        return discriminator_loss(self.netsD[i], b["imgs"][i], fake_imgs[i], b["sent_emb"], real_labels,
+                                  fake_labels, None, **kw)
+
+    def _d_update(self, i, b, fake_imgs, real_labels, fake_labels):
+        """zero_grad, loss, backward, (all-reduce,) Adam of D_i on the current stream."""
+        self.optDs[i].zero_grad()
+        errD = self._d_loss(i, b, fake_imgs, real_labels, fake_labels)
+        with ops.wgrad_overlap():
+            errD.backward()
+        self._opt_step(self.optDs[i], self._allreduce_async(self.optDs[i]))
+        return errD.detach()
 
     # -- the reference loop body -------------------------------------------------------------------
     def device_step(self, b):
@@ -143,32 +163,45 @@ class TrainEngine:
         # largest-first: D256's 643 MB gradient all-reduce then overlaps the D128 and D64 forward/backward and
         # each optimizer step waits only for its own bucket.  Same results as the reference order 0,1,2.
         order = list(range(len(netsD)))[::-1]
-        prev = None
-        for i in order:
-            self.optDs[i].zero_grad()
-            kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
-                      transf_matrices_inv=b["tmi"]) if i == 0 else {}
-            errD = discriminator_loss(netsD[i], b["imgs"][i], fake_imgs[i], b["sent_emb"], real_labels,
-                                      fake_labels, None, **kw)
-            errD.backward()
-            pending = self._allreduce_async(self.optDs[i])
-            if prev is not None:                         # the previous D's all-reduce hid behind this D's work
-                self._opt_step(self.optDs[prev[0]], prev[1])
-            prev = (i, pending)
-            out["errD%d" % i] = errD.detach()
-        self._opt_step(self.optDs[prev[0]], prev[1])
+        cur = torch.cuda.current_stream()
+        if self.multi_stream:
+            for i in order:
+                s = self.side[i]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    out["errD%d" % i] = self._d_update(i, b, fake_imgs, real_labels, fake_labels)
+            for i in order:
+                cur.wait_stream(self.side[i])
+        else:
+            prev = None
+            for i in order:
+                self.optDs[i].zero_grad()
+                errD = self._d_loss(i, b, fake_imgs, real_labels, fake_labels)
+                with ops.wgrad_overlap():
+                    errD.backward()
+                pending = self._allreduce_async(self.optDs[i])
+                if prev is not None:                         # the previous D's all-reduce hid behind this D's work
+                    self._opt_step(self.optDs[prev[0]], prev[1])
+                prev = (i, pending)
+                out["errD%d" % i] = errD.detach()
+            self._opt_step(self.optDs[prev[0]], prev[1])
         # G update: gradients flow through the (updated) Ds to the fake images only
         self.optG.zero_grad()
         for d in netsD:
             for p in d.parameters():
                 p.requires_grad_(False)
+        if self.multi_stream:
+            for s in self.side:
+                s.wait_stream(cur)
         errG_total, parts = generator_loss(netsD, self.image_encoder, fake_imgs, real_labels, b["words_embs"],
                                            b["sent_emb"], match_labels, b["cap_lens"], b.get("class_ids"), None,
                                            local_labels=b["label_one_hot"], transf_matrices=b["tm"],
-                                           transf_matrices_inv=b["tmi"], return_logs=False)
+                                           transf_matrices_inv=b["tmi"], return_logs=False,
+                                           streams=self.side if self.multi_stream else None)
         kl_loss = KL_loss(mu, logvar)
         errG_total = errG_total + kl_loss
-        errG_total.backward()
+        with ops.wgrad_overlap():
+            errG_total.backward()
         for d in netsD:
             for p in d.parameters():
                 p.requires_grad_(True)

@@ -4,6 +4,9 @@ These are the ONLY callers of libmogan_hip.so.  PyTorch supplies device memory, 
 autograd tape; all arithmetic on tensors happens inside the HIP kernels.  Every function raises
 (MoganHipError) if the library is missing or an input is not on the GPU -- there is no fallback.
 """
+import contextlib
+import os
+
 import torch
 
 from . import lib
@@ -25,6 +28,49 @@ def _grad_buf(param):
     if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != param.shape:
         return None
     return g
+
+
+# Weight gradients have no consumer until the optimizer step, so (in DIRECT_GRAD mode) they are launched on a
+# side stream paired with the stream the backward runs on: the dgrad chain continues on the main stream and the
+# wgrad launches fill the CUs its tails leave idle.  Opt-in per backward call through `with wgrad_overlap():`
+# (the engines wrap every .backward() in it); leaving the context makes the current stream wait for the side
+# stream, so the all-reduce / Adam / anybody reading .grad afterwards is ordered behind the weight gradients.
+WGRAD_SIDE_STREAM = False
+_WGRAD_ENV = os.environ.get("MOGAN_WGRAD_STREAM", "1") != "0"
+_wgrad_streams = {}
+_wgrad_keep = []         # operands of in-flight side-stream launches; released after the join so the caching
+                         # allocator cannot hand their memory to a main-stream kernel that runs concurrently
+
+
+@contextlib.contextmanager
+def wgrad_overlap():
+    global WGRAD_SIDE_STREAM
+    # not under hipGraph capture: hipStreamEndCapture segfaults (ROCm 7.2) on the nested fork pattern
+    # capture stream -> branch stream -> wgrad stream; captured steps keep the weight gradients in line
+    prev, WGRAD_SIDE_STREAM = WGRAD_SIDE_STREAM, _WGRAD_ENV and not torch.cuda.is_current_stream_capturing()
+    try:
+        yield
+    finally:
+        WGRAD_SIDE_STREAM = prev
+        join_wgrad()
+
+
+def _wgrad_stream():
+    cur = torch.cuda.current_stream()
+    side = _wgrad_streams.get(cur.cuda_stream)
+    if side is None:
+        side = _wgrad_streams[cur.cuda_stream] = torch.cuda.Stream()
+    return cur, side
+
+
+def join_wgrad():
+    if not _wgrad_streams:
+        return
+    cur = torch.cuda.current_stream()
+    side = _wgrad_streams.get(cur.cuda_stream)
+    if side is not None:
+        cur.wait_stream(side)
+    del _wgrad_keep[:]
 
 
 def _c(t):
@@ -99,7 +145,13 @@ class Conv2dFn(torch.autograd.Function):
             dx = conv2d_dgrad(dy, w, x.shape, stride, ph, pw, up)
         if ctx.needs_input_grad[1]:
             g = _grad_buf(w)
-            if g is not None:
+            if g is not None and WGRAD_SIDE_STREAM:
+                cur, side = _wgrad_stream()
+                side.wait_stream(cur)                     # dy (and the zeroed / partly accumulated grad) are ready
+                with torch.cuda.stream(side):
+                    conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up, out=g, accumulate=True)
+                _wgrad_keep.append((dy, x))               # freed only after the join (see join_wgrad)
+            elif g is not None:
                 conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up, out=g, accumulate=True)
             else:
                 dw = conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up)

@@ -15,6 +15,7 @@ import torch.distributed as dist
 
 from ..attngan.model_base import BNCallCounter
 from ..attngan.trainer import FlatAdam, allreduce_flat
+from ..hip import ops
 from . import losses
 
 
@@ -72,7 +73,8 @@ class StackGANEngine:
         self.optD.zero_grad()
         errD, errD_real, errD_wrong, errD_fake = losses.discriminator_loss(
             netD, b["real_imgs"], fake_imgs, b["label_one_hot"], tm, tmi, cond)
-        errD.backward()
+        with ops.wgrad_overlap():
+            errD.backward()
         self._sync_step(self.optD)
         # G update through the updated D; D's own weight gradients are not needed (the reference computes
         # them and drops them at the next zero_grad)
@@ -88,7 +90,8 @@ class StackGANEngine:
             out["kl"] = kl.detach()
         else:
             errG_total = errG
-        errG_total.backward()
+        with ops.wgrad_overlap():
+            errG_total.backward()
         for p in netD.parameters():
             p.requires_grad_(True)
         self._sync_step(self.optG)

@@ -48,19 +48,28 @@ struct DConvP {
 };
 
 // ------------------------------------------------------------------------------------------ forward
-template <int KH, int KW, int S, int WM, int WN, int TM, int TN, int CK>
+// CW = tile width in output pixels (32 or 16; the tile is R = 128/CW rows).  DB = LDS double buffering: the halo and
+// weight images of chunk c+1 are written into the second buffer *between the MFMA k-steps of chunk c* (one barrier per
+// chunk, no store phase).  PMC on the single-buffer version (96->96 3x3 at 256x256): MFMA pipe busy 76 %, every wave
+// parked 13 % of its cycles at the two barriers around the store phase, and the two blocks of a CU run in lockstep.
+template <int KH, int KW, int S, int WM, int WN, int TM, int TN, int CK, int CW, bool DB>
 __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     constexpr int BM = WM * TM * 32, NTB = WN * TN, PX = NTB * 32, KHW = KH * KW, KC = CK * KHW;
-    constexpr int WWP = ((31 * S + KW) + 3) & ~3, HHMAX = 7 * S + KH, CPL = HHMAX * WWP;
-    constexpr int LDW = KC + 4;      // 16-byte aligned rows: b128 LDS stores; the 4-way conflict of the A reads
-                                     // (8 LDS cycles per k-step) is hidden behind TM*TN 64-cycle MFMAs
-    // halo elements per thread: the larger of the two block shapes (R=4,Cw=32) and (R=8,Cw=16)
-    constexpr int HALO_A = (3 * S + KH) * (31 * S + KW), HALO_B = (7 * S + KH) * (15 * S + KW);
-    constexpr int NXE = (CK * (HALO_A > HALO_B ? HALO_A : HALO_B) + 255) / 256;
-    constexpr int NWQ = (BM * (KC / 4) + 255) / 256;             // weight quads per thread
-    static_assert(WM * WN == 4 && KC % 4 == 0 && CK % 2 == 0, "tile");
-    __shared__ float Xs[CK * CPL];
-    __shared__ __attribute__((aligned(16))) float Wl[BM * LDW];
+    constexpr int R = PX / CW;
+    constexpr int HH = (R - 1) * S + KH, WW = (CW - 1) * S + KW;
+    constexpr int WWP = (WW + 7) & ~7, CPL = HH * WWP;
+    // odd row stride: the A operand read (lane = output channel, stride LDW dwords) then touches 32 distinct banks.
+    // PMC with LDW = KC+4 (16-byte rows, b128 stores): 12*lane mod 32 -> 4-way conflicts on every A read, LDS array
+    // busy 50 % of the kernel, 69 % of that in conflict cycles.  The price is scalar LDS stores of the weight quads.
+    constexpr int LDW = KC + 1;
+    constexpr int NXE = (CK * HH * WW + 255) / 256;               // halo elements per thread
+    constexpr int NWQ = (BM * (KC / 4) + 255) / 256;              // weight quads per thread
+    constexpr int NBUF = DB ? 2 : 1, XSZ = CK * CPL, WSZ = BM * LDW;
+    constexpr int NSTEP = (CK / 2) * KHW, FIRST = NSTEP / 2;      // stores of the next chunk ride on steps >= FIRST
+    constexpr int XPS = (NXE + (NSTEP - FIRST) - 1) / (NSTEP - FIRST), WPS = (NWQ + (NSTEP - FIRST) - 1) / (NSTEP - FIRST);
+    static_assert(WM * WN == 4 && KC % 4 == 0 && CK % 2 == 0 && PX == 128, "tile");
+    __shared__ float Xs[NBUF * XSZ];
+    __shared__ __attribute__((aligned(16))) float Wl[NBUF * WSZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     int tile = blockIdx.x;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile % p.tiles_y; const int img = tile / p.tiles_y;
-    const int oy0 = ty * p.R, ox0 = tx * p.Cw;
+    const int oy0 = ty * R, ox0 = tx * CW;
     const int m0 = blockIdx.y * BM;
     const int sp = blockIdx.z % p.nsplit, par = blockIdx.z / p.nsplit;
     // stride-2 dgrad: parity class (py,px) selects its 2x2 weight set, padding and output phase
@@ -80,7 +89,6 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
         y0 = py; x0 = px;
         wptr += (size_t)par * p.Cin * p.Cout * KHW;
     }
-    const int HH = (p.R - 1) * S + KH, WW = (p.Cw - 1) * S + KW;
     const int nchunk_all = p.Cin / CK;
     const int c_beg = sp * p.cps, c_end = min(nchunk_all, c_beg + p.cps);
 
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     unsigned xg[NXE]; int xl[NXE];
     const int HsWs = p.Hs * p.Ws;
     {
-        const int per_c = HH * WW, total = CK * per_c;
+        constexpr int per_c = HH * WW, total = CK * per_c;
         const int iy_base = oy0 * S - pt, ix_base = ox0 * S - pl;
 #pragma unroll
         for (int i = 0; i < NXE; ++i) {
@@ -102,7 +110,10 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
             const int iy = iy_base + hy, ix = ix_base + hx;
             const bool ok = e < total && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             xg[i] = ok ? (unsigned)(c * HsWs + (iy >> p.up) * p.Ws + (ix >> p.up)) : IDX_OOB;
-            xl[i] = e < total ? c * CPL + hy * WWP + hx : -1;
+            // stride 2: even and odd halo columns are stored in separate half rows, so that the 32 lanes of a B read
+            // (output pixels ox, input column 2*ox+kw) touch consecutive dwords instead of every second one
+            const int col = S == 2 ? (hx & 1) * (WWP / 2) + (hx >> 1) : hx;
+            xl[i] = e < total ? c * CPL + hy * WWP + col : -1;
         }
     }
     const unsigned x_img = (unsigned)img * p.Cin * HsWs;
@@ -125,12 +136,17 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) rw[i] = ldg4(rW, wg[i] == IDX_OOB ? IDX_OOB : wg[i] + wb);
     };
-    auto store_chunk = [&]() {
+    auto store_x = [&](int i, float* Xd) { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; };
+    auto store_w = [&](int i, float* Wd) {
+        if (wl[i] >= 0) {
+            Wd[wl[i]] = rw[i][0]; Wd[wl[i] + 1] = rw[i][1]; Wd[wl[i] + 2] = rw[i][2]; Wd[wl[i] + 3] = rw[i][3];
+        }
+    };
+    auto store_chunk = [&](float* Xd, float* Wd) {
 #pragma unroll
-        for (int i = 0; i < NXE; ++i) if (xl[i] >= 0) Xs[xl[i]] = rx[i];
+        for (int i = 0; i < NXE; ++i) store_x(i, Xd);
 #pragma unroll
-        for (int i = 0; i < NWQ; ++i)
-            if (wl[i] >= 0) *(f32x4*)&Wl[wl[i]] = rw[i];
+        for (int i = 0; i < NWQ; ++i) store_w(i, Wd);
     };
 
     f32x16 acc[TM][TN];
@@ -148,16 +164,22 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int pb = (wn * TN + t) * 32 + (lane & 31);
-        const int ry = pb / p.Cw, rxx = pb - ry * p.Cw;
-        bbase[t] = h * CPL + ry * S * WWP + rxx * S;
+        const int ry = pb / CW, rxx = pb - ry * CW;
+        bbase[t] = h * CPL + ry * S * WWP + (S == 2 ? rxx : rxx * S);
     }
 
     if (c_beg < c_end) {
         load_chunk(c_beg);
-        store_chunk();
+        store_chunk(Xs, Wl);
         __syncthreads();
+        int cur = 0;
         for (int c = c_beg; c < c_end; ++c) {
-            if (c + 1 < c_end) load_chunk(c + 1);
+            const bool more = c + 1 < c_end;
+            if (more) load_chunk(c + 1);
+            const float* Xc = Xs + cur * XSZ;
+            const float* Wc = Wl + cur * WSZ;
+            float* Xn = Xs + (cur ^ (NBUF - 1)) * XSZ;
+            float* Wn = Wl + (cur ^ (NBUF - 1)) * WSZ;
 #pragma unroll
             for (int c2 = 0; c2 < CK / 2; ++c2) {
 #pragma unroll
@@ -166,19 +188,38 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
                     for (int kw = 0; kw < KW; ++kw) {
                         float a[TM], b[TN];
 #pragma unroll
-                        for (int t = 0; t < TM; ++t) a[t] = Wl[abase + t * 32 * LDW + 2 * c2 * KHW + kh * KW + kw];
+                        for (int t = 0; t < TM; ++t) a[t] = Wc[abase + t * 32 * LDW + 2 * c2 * KHW + kh * KW + kw];
 #pragma unroll
-                        for (int t = 0; t < TN; ++t) b[t] = Xs[bbase[t] + 2 * c2 * CPL + kh * WWP + kw];
+                        for (int t = 0; t < TN; ++t)
+                            b[t] = Xc[bbase[t] + 2 * c2 * CPL + kh * WWP + (S == 2 ? (kw & 1) * (WWP / 2) + (kw >> 1) : kw)];
 #pragma unroll
                         for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                             for (int tb = 0; tb < TN; ++tb)
                                 acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                        if constexpr (DB) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int step = (c2 * KH + kh) * KW + kw;       // compile-time after unrolling
+                            if (step >= FIRST && more) {
+                                const int s0 = step - FIRST;
+#pragma unroll
+                                for (int j = 0; j < XPS; ++j)
+                                    if (s0 * XPS + j < NXE) store_x(s0 * XPS + j, Xn);
+#pragma unroll
+                                for (int j = 0; j < WPS; ++j)
+                                    if (s0 * WPS + j < NWQ) store_w(s0 * WPS + j, Wn);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             }
             __syncthreads();
-            if (c + 1 < c_end) { store_chunk(); __syncthreads(); }
+            if constexpr (DB) {
+                cur ^= 1;
+            } else {
+                if (more) { store_chunk(Xs, Wl); __syncthreads(); }
+            }
         }
     }
 
@@ -189,7 +230,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int pb = (wn * TN + tb) * 32 + (lane & 31);
-        const int ry = pb / p.Cw, rxx = pb - ry * p.Cw;
+        const int ry = pb / CW, rxx = pb - ry * CW;
         const size_t pix = (size_t)((oy0 + ry) * p.ys + y0) * p.yW + (ox0 + rxx) * p.ys + x0;
 #pragma unroll
         for (int ta = 0; ta < TM; ++ta)
@@ -414,8 +455,16 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     p.cps = (int)cdiv(nchunk, nsplit); p.nsplit = (int)cdiv(nchunk, p.cps);
     p.slab = y_numel; p.ws = (float*)ws;
     dim3 grid((unsigned)(p.B * p.tiles_x * p.tiles_y), (unsigned)cdiv(p.Cout, bm), (unsigned)(p.nsplit * p.npar));
-    if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK>), grid, dim3(256), 0, st, p);
+    // 96-wide tiles double-buffer their LDS images (2 x 36 KB, two blocks per CU still fit in 160 KB); the 128-wide
+    // ones (2 x 46 KB would leave one block per CU) keep the single buffer
+    constexpr bool DB1 = true;
+    if (p.Cw == 32) {
+        if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK, 32, DB1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK, 32, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK, 16, DB1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK, 16, false>), grid, dim3(256), 0, st, p);
+    }
     if (p.nsplit > 1)
         hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(y_numel, 256)), dim3(256), 0, st,
                            (const float*)ws, p.Y, y_numel, y_numel, p.nsplit, p.accumulate);
@@ -470,8 +519,12 @@ int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin
     p.X = x; p.Wt = w; p.Y = y; p.B = B; p.Cin = Cin; p.Cout = Cout; p.Hs = Hs; p.Ws = Ws; p.H = H; p.W = W; p.up = up;
     p.OH = OH; p.OW = OW; p.pt = ph; p.pl = pw; p.yH = OH; p.yW = OW; p.ys = 1; p.y0 = 0; p.x0 = 0; p.accumulate = 0; p.npar = 1;
     p.x_bytes = 4u * B * Cin * Hs * Ws; p.w_bytes = 4u * Cout * Cin * KH * KW;
-    if (k44) return 0;     // measured: the stride-2 halo variant (85 TF) loses to the implicit-GEMM kernel (98 TF)
-    const int rc = launch_fwd<3, 3, 1, 8>(p, ws, ws_bytes, st);
+    // 4x4 s2 only at >= 64-pixel rows: measured 124 vs 98 TF (implicit GEMM) at 64x64 output, 98 vs 98 at 32x32 and
+    // 90 vs 98 at 16x16 (more M-blocks re-reading the same halo tile)
+    if (k44 && OW < 64) return 0;
+    // 4x4 s2: chunks of 4 channels (32 k-steps, like the 36 of a 3x3 chunk of 8) keep the staging registers and the
+    // double-buffered LDS images (2 x 36 KB) within two blocks per CU
+    const int rc = k44 ? launch_fwd<4, 4, 2, 4>(p, ws, ws_bytes, st) : launch_fwd<3, 3, 1, 8>(p, ws, ws_bytes, st);
     return rc ? rc : 1;
 }
 

@@ -1,0 +1,28 @@
+"""How much of a step is host launch time?  Times run_step() on the host without synchronizing, then the
+synchronized wall time (eager mode)."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from mogan_amd.attngan.miscc.config import cfg, set_coco_train_defaults
+from mogan_amd.attngan.trainer import TrainEngine, build_networks
+
+os.environ.setdefault("MOGAN_FAST_INIT", "1")
+device = torch.device("cuda", 0)
+set_coco_train_defaults()
+B = 16
+te, ie, G, Ds = build_networks(device=device, seed=1)
+eng = TrainEngine(te, ie, G, Ds)
+batch, _ = bench.make_device_batch(B, 0, device)
+def step():
+    b = dict(batch); b["z"] = torch.randn(B, 100, device=device); b["eps"] = torch.randn(B, 100, device=device)
+    return eng.step(b)
+for _ in range(3): step()
+torch.cuda.synchronize()
+host = []; wall = []
+for _ in range(8):
+    t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    host.append(t1 - t0); wall.append(t2 - t0)
+print("host launch ms/step", [round(h * 1e3, 1) for h in host])
+print("wall ms/step       ", [round(w * 1e3, 1) for w in wall])

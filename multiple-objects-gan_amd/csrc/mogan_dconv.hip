@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
         int cur = 0;
         for (int c = c_beg; c < c_end; ++c) {
             const bool more = c + 1 < c_end;
-            if (more) load_chunk(c + 1);
+            if constexpr (!DB) load_chunk(c + 1);   // branch-free body (one basic block): a chunk past the end reads harmless data
+            else if (more) load_chunk(c + 1);
             const float* Xc = Xs + cur * XSZ;
             const float* Wc = Wl + cur * WSZ;
             float* Xn = Xs + (cur ^ (NBUF - 1)) * XSZ;
@@ -212,6 +213,17 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                }
+            }
+            if constexpr (!DB) {
+                // issue-order template (see dconv_wgrad_kernel): one global load of the next chunk behind each of the
+                // first k-steps instead of a load phase in front of the MFMA loop.  +2..4 % over the double-buffered
+                // variant on the 3x3 / 2x2 / 4x4-s2 layers (e.g. dgrad 96->192 at 128x128: 134 vs 129 TFLOP/s).
+#pragma unroll
+                for (int g = 0; g < NSTEP; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    if (g < NXE + NWQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
             __syncthreads();
@@ -258,19 +270,27 @@ struct WGradP {
     int B, Cin, Cout, Hs, Ws, H, W, up, OH, OW, pt, pl;
     int N;                    // Cin*KH*KW
     int tiles_x, tiles_y, ntiles, tps, nsplit;     // pixel tiles, tiles per split
+    int lg_tx, lg_ty;                              // log2 of tiles_x / tiles_y (both are powers of two)
     long long slab; int accumulate;
     unsigned x_bytes, y_bytes;
 };
 
-template <int KH, int KW, int S, int CW, int WM, int WN, int TM, int TN>
+// DBW = LDS double buffering: the dY / halo images of pixel-tile t+1 are written into the second buffer between the
+// MFMA k-steps of tile t (one barrier per tile).  Lab numbers that motivated it (96->96 3x3 at 256x256, TFLOP/s):
+// product 87, without the X gather 104, without any global load 113, without the store phase and its two barriers 115.
+template <int KH, int KW, int S, int CW, int WM, int WN, int TM, int TN, bool DBW>
 __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, KHW = KH * KW, PXK = 64, RT = PXK / CW;
     constexpr int HHW = (RT - 1) * S + KH, WW = (CW - 1) * S + KW, WWP = (WW + 3) & ~3, CPLW = HHW * WWP;
     constexpr int CKW = BN / KHW + 2, LDY = PXK + 4;
     constexpr int NXE = (CKW * HHW * WW + 255) / 256, NYQ = BM * (PXK / 4) / 256;
+    constexpr bool PIPE = (S == 2);
+    constexpr int NBUF = DBW ? 2 : 1, YSZ = BM * LDY, XSZ = CKW * CPLW;
+    constexpr int NSTEP = PXK / 2, FIRST = NSTEP / 2;
+    constexpr int XPS = (NXE + (NSTEP - FIRST) - 1) / (NSTEP - FIRST), YPS = (NYQ + (NSTEP - FIRST) - 1) / (NSTEP - FIRST);
     static_assert(WM * WN == 4 && BN == 128, "tile");
-    __shared__ __attribute__((aligned(16))) float Ys[BM * LDY];
-    __shared__ float Xs[CKW * CPLW];
+    __shared__ __attribute__((aligned(16))) float Ys[NBUF * YSZ];
+    __shared__ float Xs[NBUF * XSZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -281,15 +301,20 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, (short)0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, (short)0, (int)p.y_bytes, 0x00020000);
 
-    // staging plans
-    unsigned xc[NXE]; int xhy[NXE], xhx[NXE], xl[NXE];
+    // staging plans.  Halo element e -> (c, hy, hx).  Its global index is pre[i] + (a per-tile scalar): the part that
+    // depends on the element is computed once here, so a tile costs one add per element (interior tiles) or an add, two
+    // compares and a select (tiles that touch the image border) instead of the full (iy >> up) * Ws + (ix >> up) chain.
+    // With the fused upsample (3x3 p1 only: tile origins are even, iyb/ixb odd) (iyb+hy)>>1 = (iyb+1)/2 + ((hy-1)>>1).
+    constexpr unsigned PRE_BAD = 0x20000000u;       // * 4 bytes >= 2 GiB > any extent: the buffer load returns 0
+    unsigned pre[NXE]; int xhy[NXE], xhx[NXE], xl[NXE];
 #pragma unroll
     for (int i = 0; i < NXE; ++i) {
         const int e = tid + 256 * i;
         const int c = e / (HHW * WW), r = e - c * (HHW * WW);
         const int hy = r / WW, hx = r - hy * WW;
         const bool ok = e < CKW * HHW * WW && ci_first + c < p.Cin;
-        xc[i] = ok ? (unsigned)((ci_first + c) * HsWs) : IDX_OOB;
+        const int inoff = p.up ? ((hy - 1) >> 1) * p.Ws + ((hx - 1) >> 1) : hy * p.Ws + hx;
+        pre[i] = ok ? (unsigned)((ci_first + c) * HsWs + inoff) : PRE_BAD;
         xhy[i] = hy; xhx[i] = hx;
         xl[i] = e < CKW * HHW * WW ? c * CPLW + hy * WWP + hx : -1;
     }
@@ -304,26 +329,46 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
     }
     float rx[NXE]; f32x4 ry4[NYQ];
     auto load_tile = [&](int t) {
-        const int tx = t % p.tiles_x; int u = t / p.tiles_x;
-        const int ty = u % p.tiles_y; const int img = u / p.tiles_y;
+        const int tx = t & (p.tiles_x - 1); const int u = t >> p.lg_tx;
+        const int ty = u & (p.tiles_y - 1); const int img = u >> p.lg_ty;
         const int oy0 = ty * RT, ox0 = tx * CW;
         const int iyb = oy0 * S - p.pt, ixb = ox0 * S - p.pl;
-        const unsigned xb = (unsigned)img * p.Cin * HsWs;
         const unsigned yb = (unsigned)img * p.Cout * p.OH * p.OW + oy0 * p.OW + ox0;
+        // block-uniform part of the halo index (may be "negative" for border tiles: unsigned wrap-around is intended,
+        // such elements are masked below)
+        const unsigned sbase = (unsigned)img * p.Cin * HsWs +
+            (unsigned)(p.up ? ((iyb + 1) >> 1) * p.Ws + ((ixb + 1) >> 1) : iyb * p.Ws + ixb);
+        const bool interior = iyb >= 0 && ixb >= 0 && iyb + HHW <= p.H && ixb + WW <= p.W;
+#if defined(LAB) && (LAB == 1 || LAB == 3)
 #pragma unroll
-        for (int i = 0; i < NXE; ++i) {
-            const int iy = iyb + xhy[i], ix = ixb + xhx[i];
-            const bool ok = xc[i] != IDX_OOB && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            rx[i] = ldg(rX, ok ? xb + xc[i] + (iy >> p.up) * p.Ws + (ix >> p.up) : IDX_OOB);
+        for (int i = 0; i < NXE; ++i) rx[i] = (float)i;
+#else
+        if (!PIPE && interior) {
+#pragma unroll
+            for (int i = 0; i < NXE; ++i) rx[i] = ldg(rX, pre[i] + sbase);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NXE; ++i) {
+                const bool ok = (unsigned)(iyb + xhy[i]) < (unsigned)p.H && (unsigned)(ixb + xhx[i]) < (unsigned)p.W;
+                rx[i] = ldg(rX, ok ? pre[i] + sbase : PRE_BAD);
+            }
         }
+#endif
 #pragma unroll
-        for (int i = 0; i < NYQ; ++i) ry4[i] = ldg4(rY, yg[i] == IDX_OOB ? IDX_OOB : yb + yg[i]);
+        for (int i = 0; i < NYQ; ++i)
+#if defined(LAB) && (LAB == 2 || LAB == 3)
+            ry4[i] = f32x4{1.f, 2.f, 3.f, (float)i};
+#else
+            ry4[i] = ldg4(rY, yg[i] == IDX_OOB ? IDX_OOB : yb + yg[i]);
+#endif
     };
-    auto store_tile = [&]() {
+    auto store_x = [&](int i, float* Xd) { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; };
+    auto store_y = [&](int i, float* Yd) { *(f32x4*)&Yd[yl[i]] = ry4[i]; };
+    auto store_tile = [&](float* Xd, float* Yd) {
 #pragma unroll
-        for (int i = 0; i < NXE; ++i) if (xl[i] >= 0) Xs[xl[i]] = rx[i];
+        for (int i = 0; i < NXE; ++i) store_x(i, Xd);
 #pragma unroll
-        for (int i = 0; i < NYQ; ++i) *(f32x4*)&Ys[yl[i]] = ry4[i];
+        for (int i = 0; i < NYQ; ++i) store_y(i, Yd);
     };
 
     f32x16 acc[TM][TN];
@@ -346,27 +391,68 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
 
     if (t_beg < t_end) {
         load_tile(t_beg);
-        store_tile();
+        store_tile(Xs, Ys);
         __syncthreads();
+        int cur = 0;
         for (int t = t_beg; t < t_end; ++t) {
-            if (t + 1 < t_end) load_tile(t + 1);
+            const bool more = t + 1 < t_end;
+            if constexpr (PIPE) load_tile(t + 1 < p.ntiles ? t + 1 : t);      // branch-free body (one basic block)
+            else if (more) load_tile(t + 1);
+            const float* Xc = Xs + cur * XSZ;
+            const float* Yc = Ys + cur * YSZ;
+            float* Xn = Xs + (cur ^ (NBUF - 1)) * XSZ;
+            float* Yn = Ys + (cur ^ (NBUF - 1)) * YSZ;
 #pragma unroll
             for (int pp = 0; pp < PXK / 2; ++pp) {
                 constexpr int dummy = 0; (void)dummy;
                 const int ry = (2 * pp) / CW, rxx = (2 * pp) % CW;
                 float a[TM], b[TN];
 #pragma unroll
-                for (int q = 0; q < TM; ++q) a[q] = Ys[abase + q * 32 * LDY + 2 * pp];
+                for (int q = 0; q < TM; ++q) a[q] = Yc[abase + q * 32 * LDY + 2 * pp];
 #pragma unroll
-                for (int q = 0; q < TN; ++q) b[q] = Xs[bbase[q] + ry * S * WWP + rxx * S];
+                for (int q = 0; q < TN; ++q) b[q] = Xc[bbase[q] + ry * S * WWP + rxx * S];
 #pragma unroll
                 for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < TN; ++tb)
                         acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                if constexpr (DBW) {
+                    if (pp >= FIRST && more) {
+                        const int s0 = pp - FIRST;
+#pragma unroll
+                        for (int j = 0; j < XPS; ++j)
+                            if (s0 * XPS + j < NXE) store_x(s0 * XPS + j, Xn);
+#pragma unroll
+                        for (int j = 0; j < YPS; ++j)
+                            if (s0 * YPS + j < NYQ) store_y(s0 * YPS + j, Yn);
+                    }
+#if !defined(LAB) || LAB != 5
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
             }
+            if constexpr (PIPE) {
+                // issue-order template for the scheduler: per k-step its LDS operand reads and MFMAs, and one of the
+                // NXE+NYQ global loads of the next tile behind each of the first k-steps (instead of all of them in
+                // front of the MFMA loop, where both blocks of a CU sit in their load phase at the same time).
+                // Measured on the 4x4 s2 layers: 83 -> 97 TFLOP/s; no gain on the 3x3 variant (fewer halo loads).
+#pragma unroll
+                for (int g = 0; g < PXK / 2; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    if (g < NXE + NYQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+#if defined(LAB) && LAB == 4
+            // lab: no store phase, no barriers (stale LDS)
+#else
             __syncthreads();
-            if (t + 1 < t_end) { store_tile(); __syncthreads(); }
+            if constexpr (DBW) {
+                cur ^= 1;
+            } else {
+                if (more) { store_tile(Xs, Ys); __syncthreads(); }
+            }
+#endif
         }
     }
 
@@ -457,7 +543,7 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     dim3 grid((unsigned)(p.B * p.tiles_x * p.tiles_y), (unsigned)cdiv(p.Cout, bm), (unsigned)(p.nsplit * p.npar));
     // 96-wide tiles double-buffer their LDS images (2 x 36 KB, two blocks per CU still fit in 160 KB); the 128-wide
     // ones (2 x 46 KB would leave one block per CU) keep the single buffer
-    constexpr bool DB1 = true;
+    constexpr bool DB1 = false;     // single LDS buffer + the issue-order template; DB = true keeps the double-buffered loop
     if (p.Cw == 32) {
         if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK, 32, DB1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK, 32, false>), grid, dim3(256), 0, st, p);
@@ -477,6 +563,7 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     const int bm = m96 ? 96 : 128;
     const int cw = std::min(32, p.OW), rt = 64 / cw;
     p.tiles_x = p.OW / cw; p.tiles_y = p.OH / rt; p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    p.lg_tx = __builtin_ctz(p.tiles_x); p.lg_ty = __builtin_ctz(p.tiles_y);
     const long long blocks = cdiv(p.N, 128) * cdiv(p.Cout, bm);
     const long long w_numel = (long long)p.Cout * p.N;
     int nsplit = (int)std::min<long long>(cdiv(640, blocks), std::max(1, p.ntiles / 2));
@@ -487,12 +574,16 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     p.tps = (int)cdiv(p.ntiles, nsplit); p.nsplit = (int)cdiv(p.ntiles, p.tps);
     p.slab = w_numel; p.ws = (float*)ws;
     dim3 grid((unsigned)cdiv(p.N, 128), (unsigned)cdiv(p.Cout, bm), (unsigned)p.nsplit);
+    // LDS double buffering (DBW) is implemented but off: measured 65 TF with the stores pinned between the k-steps
+    // (the sched_barriers stop the compiler from running the LDS operand reads ahead of the MFMAs) and 87 = no gain
+    // without the pinning; the lab variant without global loads runs at 113, so the loads, not the barriers, cost
+    constexpr bool DBW = false;
     if (cw == 32) {
-        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 1, 4, 3, 1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 1, 4, 3, 1, DBW>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 2, 2, 2, 2, false>), grid, dim3(256), 0, st, p);
     } else {
-        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 1, 4, 3, 1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 1, 4, 3, 1, DBW>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 2, 2, 2, 2, false>), grid, dim3(256), 0, st, p);
     }
     if (p.nsplit > 1)
         hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(w_numel, 256)), dim3(256), 0, st,

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_HERE, "libmogan_hip.so")
+LIB_PATH = os.environ.get("MOGAN_LIB") or os.path.join(_HERE, "libmogan_hip.so")   # MOGAN_LIB: tools/lab variants
 
 P, I, F, L, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
 

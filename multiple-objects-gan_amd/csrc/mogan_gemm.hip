@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                 for (int x = 0; x < EPS; ++x)
                     if (s16 * EPS + x < NE) stage_elem(s16 * EPS + x, kt + BK, cur ^ 1);   // past kend: masked to 0
                 if (s16 == 15) decode_k(kt + 2 * BK, cur);       // table `cur` was last read while staging tile t
-                if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                if (SCHED) __builtin_amdgcn_sched_barrier(0);    // (a sched_group_barrier template instead: no gain, lab 8)
             }
             store_tile(cur ^ 1);                                 // buffer cur^1 was last read in iteration t-1
             __syncthreads();

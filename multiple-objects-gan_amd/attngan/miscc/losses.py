@@ -108,6 +108,33 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     return cond_real_errD + (cond_fake_errD + cond_wrong_errD) / 2.
 
 
+def generator_d_branch(netD, fake_img, sent_emb, local_labels=None, transf_matrices=None, transf_matrices_inv=None):
+    """One term of losses.py:187-203: BCE(cond logits of D(fake), 1) [+ BCE(uncond logits, 1)]."""
+    features = _call_d(netD, fake_img, local_labels, transf_matrices, transf_matrices_inv)
+    g_loss = ops.bce(netD.COND_DNET(features, sent_emb), 1.0)
+    if netD.UNCOND_DNET is not None:
+        g_loss = ops.bce(netD.UNCOND_DNET(features), 1.0) + g_loss
+    return g_loss
+
+
+def generator_damsm_branch(image_encoder, fake_img, words_embs, sent_emb, match_labels, cap_lens, class_ids, batch_size):
+    """losses.py:205-221: Inception features of the last fake image -> DAMSM word and sentence losses (* LAMBDA)."""
+    region_features, cnn_code = image_encoder(fake_img)
+    w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size)
+    w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+    s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    return w_loss, s_loss
+
+
+def generator_total(parts, numDs):
+    """Sum in the reference's order: g_loss0, g_loss1, g_loss2, then w_loss, s_loss (losses.py:203,221)."""
+    errG_total = 0
+    for i in range(numDs):
+        errG_total = errG_total + parts['g_loss%d' % i]
+    return errG_total + parts['w_loss'] + parts['s_loss']
+
+
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,
                    cap_lens, class_ids, gpus=None, local_labels=None, transf_matrices=None,
                    transf_matrices_inv=None, return_logs=True, streams=None):
@@ -125,30 +152,18 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
 
     for i in range(numDs):
         with on(i):
-            if i == 0:
-                features = netsD[i](fake_imgs[i], local_labels, transf_matrices, transf_matrices_inv)
-            else:
-                features = netsD[i](fake_imgs[i])
-            g_loss = ops.bce(netsD[i].COND_DNET(features, sent_emb), 1.0)
-            if netsD[i].UNCOND_DNET is not None:
-                g_loss = ops.bce(netsD[i].UNCOND_DNET(features), 1.0) + g_loss
-            parts['g_loss%d' % i] = g_loss
+            kw = dict(local_labels=local_labels, transf_matrices=transf_matrices,
+                      transf_matrices_inv=transf_matrices_inv) if i == 0 else {}
+            parts['g_loss%d' % i] = generator_d_branch(netsD[i], fake_imgs[i], sent_emb, **kw)
     with on(numDs):
-        region_features, cnn_code = image_encoder(fake_imgs[numDs - 1])
-        w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
-                                         class_ids, batch_size)
-        w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-        s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
-        s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+        w_loss, s_loss = generator_damsm_branch(image_encoder, fake_imgs[numDs - 1], words_embs, sent_emb,
+                                                match_labels, cap_lens, class_ids, batch_size)
     if streams is not None:
         cur = torch.cuda.current_stream()
         for st in streams[:numDs + 1]:
             cur.wait_stream(st)
-    errG_total = 0
-    for i in range(numDs):                       # same summation order as the reference loop
-        errG_total = errG_total + parts['g_loss%d' % i]
-    errG_total = errG_total + w_loss + s_loss
     parts['w_loss'], parts['s_loss'] = w_loss, s_loss
+    errG_total = generator_total(parts, numDs)
     if not return_logs:
         return errG_total, parts
     logs = ''.join('%s: %.2f ' % (k, v.item()) for k, v in parts.items())

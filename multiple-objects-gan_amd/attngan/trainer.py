@@ -30,7 +30,8 @@ import torch.distributed as dist
 
 from ..hip import ops
 from .miscc.config import cfg
-from .miscc.losses import KL_loss, discriminator_loss, generator_loss
+from .miscc.losses import (KL_loss, discriminator_loss, generator_d_branch, generator_damsm_branch, generator_loss,
+                           generator_total)
 from .miscc.utils import copy_G_params, load_params, mkdir_p, weights_init
 from .model_base import BNCallCounter
 from .model import CNN_ENCODER, D_NET64, D_NET128, D_NET256, G_NET, RNN_ENCODER
@@ -164,14 +165,39 @@ class TrainEngine:
         # each optimizer step waits only for its own bucket.  Same results as the reference order 0,1,2.
         order = list(range(len(netsD)))[::-1]
         cur = torch.cuda.current_stream()
+        nD = len(netsD)
         if self.multi_stream:
-            for i in order:
+            # One branch per discriminator: its update (zero_grad, loss, backward, all-reduce, Adam) and then -- on the
+            # same stream, hence behind its own Adam and independent of the other Ds -- the G-step forward through it.
+            # The Inception/DAMSM branch only needs the fake image, so it starts right after D256's branch was queued
+            # and overlaps the D updates (and, for N>1, D256's 643 MB gradient all-reduce).  The branches meet again
+            # where the generator loss is summed; autograd replays each branch's backward on its own stream.
+            parts = {}
+
+            def d_branch(i):
                 s = self.side[i]
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
                     out["errD%d" % i] = self._d_update(i, b, fake_imgs, real_labels, fake_labels)
-            for i in order:
-                cur.wait_stream(self.side[i])
+                    for p in netsD[i].parameters():          # G step: no weight gradients of the Ds
+                        p.requires_grad_(False)
+                    kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
+                              transf_matrices_inv=b["tmi"]) if i == 0 else {}
+                    parts["g_loss%d" % i] = generator_d_branch(netsD[i], fake_imgs[i], b["sent_emb"], **kw)
+
+            d_branch(order[0])
+            s = self.side[nD]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                parts["w_loss"], parts["s_loss"] = generator_damsm_branch(
+                    self.image_encoder, fake_imgs[nD - 1], b["words_embs"], b["sent_emb"], match_labels, b["cap_lens"],
+                    b.get("class_ids"), B)
+            for i in order[1:]:
+                d_branch(i)
+            for s in self.side:
+                cur.wait_stream(s)
+            self.optG.zero_grad()
+            errG_total = generator_total(parts, nD)
         else:
             prev = None
             for i in order:
@@ -185,19 +211,15 @@ class TrainEngine:
                 prev = (i, pending)
                 out["errD%d" % i] = errD.detach()
             self._opt_step(self.optDs[prev[0]], prev[1])
-        # G update: gradients flow through the (updated) Ds to the fake images only
-        self.optG.zero_grad()
-        for d in netsD:
-            for p in d.parameters():
-                p.requires_grad_(False)
-        if self.multi_stream:
-            for s in self.side:
-                s.wait_stream(cur)
-        errG_total, parts = generator_loss(netsD, self.image_encoder, fake_imgs, real_labels, b["words_embs"],
-                                           b["sent_emb"], match_labels, b["cap_lens"], b.get("class_ids"), None,
-                                           local_labels=b["label_one_hot"], transf_matrices=b["tm"],
-                                           transf_matrices_inv=b["tmi"], return_logs=False,
-                                           streams=self.side if self.multi_stream else None)
+            # G update: gradients flow through the (updated) Ds to the fake images only
+            self.optG.zero_grad()
+            for d in netsD:
+                for p in d.parameters():
+                    p.requires_grad_(False)
+            errG_total, parts = generator_loss(netsD, self.image_encoder, fake_imgs, real_labels, b["words_embs"],
+                                               b["sent_emb"], match_labels, b["cap_lens"], b.get("class_ids"), None,
+                                               local_labels=b["label_one_hot"], transf_matrices=b["tm"],
+                                               transf_matrices_inv=b["tmi"], return_logs=False)
         kl_loss = KL_loss(mu, logvar)
         errG_total = errG_total + kl_loss
         with ops.wgrad_overlap():

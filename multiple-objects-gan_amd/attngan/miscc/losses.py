@@ -92,10 +92,11 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
 
 
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels, gpus=None,
-                       local_labels=None, transf_matrices=None, transf_matrices_inv=None):
+                       local_labels=None, transf_matrices=None, transf_matrices_inv=None, real_features=None):
     """losses.py:136-174.  D(real) and D(fake.detach()) are two separate calls (separate BN batch
     statistics); real_labels/fake_labels are the constant 1/0 vectors of prepare_labels."""
-    real_features = _call_d(netD, real_imgs, local_labels, transf_matrices, transf_matrices_inv)
+    if real_features is None:       # (the engine may have run D(real) already, concurrently with the G forward)
+        real_features = _call_d(netD, real_imgs, local_labels, transf_matrices, transf_matrices_inv)
     fake_features = _call_d(netD, fake_imgs.detach(), local_labels, transf_matrices, transf_matrices_inv)
     batch_size = real_features.size(0)
     cond_real_errD = ops.bce(netD.COND_DNET(real_features, conditions), 1.0)

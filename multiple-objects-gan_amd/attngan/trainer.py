@@ -133,16 +133,25 @@ class TrainEngine:
             torch.cuda.current_stream().wait_event(pending)
         flat.step(grad_scale=1.0 / self.world)
 
-    def _d_loss(self, i, b, fake_imgs, real_labels, fake_labels):
+    def _d_real(self, i, b):
+        """zero_grad + D_i(real): independent of the generator, so it can run beside the G forward."""
+        from .miscc.losses import _call_d
+        self.optDs[i].zero_grad()
+        if i == 0:
+            return _call_d(self.netsD[i], b["imgs"][i], b["label_one_hot"], b["tm"], b["tmi"])
+        return _call_d(self.netsD[i], b["imgs"][i], None, None, None)
+
+    def _d_loss(self, i, b, fake_imgs, real_labels, fake_labels, real_features=None):
         kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
                   transf_matrices_inv=b["tmi"]) if i == 0 else {}
         return discriminator_loss(self.netsD[i], b["imgs"][i], fake_imgs[i], b["sent_emb"], real_labels,
-                                  fake_labels, None, **kw)
+                                  fake_labels, None, real_features=real_features, **kw)
 
-    def _d_update(self, i, b, fake_imgs, real_labels, fake_labels):
-        """zero_grad, loss, backward, (all-reduce,) Adam of D_i on the current stream."""
-        self.optDs[i].zero_grad()
-        errD = self._d_loss(i, b, fake_imgs, real_labels, fake_labels)
+    def _d_update(self, i, b, fake_imgs, real_labels, fake_labels, real_features=None):
+        """[zero_grad,] loss, backward, (all-reduce,) Adam of D_i on the current stream."""
+        if real_features is None:
+            self.optDs[i].zero_grad()
+        errD = self._d_loss(i, b, fake_imgs, real_labels, fake_labels, real_features)
         with ops.wgrad_overlap():
             errD.backward()
         self._opt_step(self.optDs[i], self._allreduce_async(self.optDs[i]))
@@ -157,6 +166,25 @@ class TrainEngine:
         real_labels = b["z"].new_ones(B)
         fake_labels = b["z"].new_zeros(B)
         match_labels = b["match_labels"]
+        real_feat = {}
+        if self.multi_stream:
+            # D_i(real) depends neither on the generator nor on the text encoder: it runs beside them.  With an
+            # `inputs_ready` event (recorded by the caller once the batch tensors are on the device) the D branches
+            # do not even wait for the main stream, i.e. they also overlap the tail of the previous step (G backward,
+            # Adam): only their own stream order (D_i's previous Adam) and the input batch matter.
+            cur0 = torch.cuda.current_stream()
+            ready = b.get("inputs_ready")
+            for i in range(len(netsD))[::-1]:
+                if ready is not None:
+                    self.side[i].wait_event(ready)
+                else:
+                    self.side[i].wait_stream(cur0)
+                with torch.cuda.stream(self.side[i]):
+                    real_feat[i] = self._d_real(i, b)
+            if ready is not None:
+                cur0.wait_event(ready)
+        if "words_embs" not in b:        # trainer.py:281-289 (eager path: after the fork above)
+            b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
         fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"],
                                         b["label_one_hot"], b.get("eps"))
         out = {}
@@ -178,7 +206,7 @@ class TrainEngine:
                 s = self.side[i]
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
-                    out["errD%d" % i] = self._d_update(i, b, fake_imgs, real_labels, fake_labels)
+                    out["errD%d" % i] = self._d_update(i, b, fake_imgs, real_labels, fake_labels, real_feat.get(i))
                     for p in netsD[i].parameters():          # G step: no weight gradients of the Ds
                         p.requires_grad_(False)
                     kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
@@ -250,7 +278,7 @@ class TrainEngine:
     def step(self, batch):
         """One train iteration on a device batch (see synthetic.make_batch for the fields)."""
         b = dict(batch)
-        if "words_embs" not in b:
+        if "words_embs" not in b and self.use_graph:      # the LSTM stays outside the capture
             b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
         if "match_labels" not in b:
             b["match_labels"] = torch.arange(b["z"].shape[0], device=b["z"].device)

@@ -444,6 +444,53 @@ class condGANTrainer(object):
                 os.remove(ckpts[0])
                 ckpts = ckpts[1:]
 
+    def sampling(self, split_dir, num_samples=30000):
+        """trainer.py:387-470: load cfg.TRAIN.NET_G (EMA generator of a checkpoint) and cfg.TRAIN.NET_E (DAMSM text
+        encoder), generate one 256x256 image per caption of the data loader with netG.eval() and save it as
+        <NET_G minus .pth>/<split>/single/<key>_s<batch index>.png"""
+        from PIL import Image
+        from .datasets import prepare_data
+        if cfg.TRAIN.NET_G == '':
+            print('Error: the path for morels is not found!')
+            return None
+        if split_dir == 'test':
+            split_dir = 'valid'
+        netG = G_NET()
+        netG.apply(weights_init)
+        sd = torch.load(cfg.TRAIN.NET_G, map_location='cpu')
+        netG.load_state_dict(sd["netG"])
+        print('Load G from: ', cfg.TRAIN.NET_G)
+        netG = netG.to(self.device).eval()
+        text_encoder = RNN_ENCODER(self.n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
+        if cfg.TRAIN.NET_E != '':
+            text_encoder.load_state_dict(torch.load(cfg.TRAIN.NET_E, map_location='cpu'))
+            print('Load text encoder from:', cfg.TRAIN.NET_E)
+        text_encoder = text_encoder.to(self.device).eval()
+        save_dir = '%s/%s' % (cfg.TRAIN.NET_G[:cfg.TRAIN.NET_G.rfind('.pth')], split_dir)
+        mkdir_p(save_dir)
+        written = []
+        for step, data in enumerate(self.data_loader, 0):
+            if step >= num_samples:
+                break
+            imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data(data, self.device)
+            B = captions.shape[0]
+            with torch.no_grad():
+                hidden = text_encoder.init_hidden(B)
+                words_embs, sent_emb = text_encoder(captions, cap_lens.cpu(), hidden)
+                mask = (captions == 0)
+                if mask.size(1) > words_embs.size(2):
+                    mask = mask[:, :words_embs.size(2)]
+                noise = torch.randn(B, cfg.GAN.Z_DIM, device=self.device)
+                fake_imgs, _, _, _ = netG(noise, sent_emb.contiguous(), words_embs.contiguous(), mask, tmi, label_one_hot)
+            out = fake_imgs[-1].add(1.0).mul(127.5).clamp(0, 255).byte().permute(0, 2, 3, 1).cpu().numpy()
+            for j in range(B):
+                s_tmp = '%s/single/%s' % (save_dir, keys[j])
+                mkdir_p(s_tmp[:s_tmp.rfind('/')] if '/' in keys[j] else '%s/single' % save_dir)
+                fullpath = '%s_s%d.png' % (s_tmp, step)
+                Image.fromarray(out[j]).save(fullpath)
+                written.append(fullpath)
+        return written
+
     def train(self):
         from .datasets import prepare_data
         text_encoder, image_encoder, netG, netsD, start_epoch = self.build_models()

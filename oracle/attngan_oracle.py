@@ -66,9 +66,13 @@ def glu(x):
     return x[:, :c] * torch.sigmoid(x[:, c:])
 
 
-def bn(net, key, x, training=True, eps=1e-5):
+BN_TRAINING = True       # module switch: False = netG.eval() (running statistics), used by the sampling-path tests
+
+
+def bn(net, key, x, training=None, eps=1e-5):
     """nn.BatchNorm1d/2d in train mode: batch statistics, running stats momentum 0.1
-    (unbiased variance into running_var), num_batches_tracked += 1."""
+    (unbiased variance into running_var), num_batches_tracked += 1; eval mode: running statistics."""
+    training = BN_TRAINING if training is None else training
     rm, rv = net[key + ".running_mean"], net[key + ".running_var"]
     y = F.batch_norm(x, rm, rv, net[key + ".weight"], net[key + ".bias"], training, 0.1, eps)
     if training and (key + ".num_batches_tracked") in net:

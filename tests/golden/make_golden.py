@@ -177,6 +177,21 @@ def gen_gnet(ns):
     save("gnet", **out)
 
 
+def gen_gnet_eval(ns):
+    """netG.eval() forward (trainer.py:398,431-437 `sampling`): BatchNorm on its running statistics."""
+    ref_shim.set_cfg(ns.cfg, **SMALL)
+    bt = _g_inputs(3, SMALL["EMBEDDING_DIM"], SMALL["WORDS_NUM"])
+    G = ns.model.G_NET()
+    det_fill_state(G, "G.")
+    G.eval()
+    eps = bt["eps"]
+    G.ca_net.reparametrize = lambda mu, logvar: eps.mul(logvar.mul(0.5).exp()).add(mu)
+    with torch.no_grad():
+        imgs, atts, mu, logvar = G(bt["z"], bt["sent_emb"], bt["words_embs"], bt["mask"], bt["tmi"], bt["label_one_hot"])
+    save("gnet_eval", img64=imgs[0], img128=imgs[1][:, :, ::2, ::2], img256=imgs[2][:, :, ::4, ::4],
+         img256_p=probe(imgs[2]), att128_p=probe(atts[1]), mu=mu)
+
+
 def gen_dnets(ns):
     ref_shim.set_cfg(ns.cfg, **SMALL)
     B = 3
@@ -337,6 +352,7 @@ def main():
     gen_blocks(ns)
     gen_attn(ns)
     gen_gnet(ns)
+    gen_gnet_eval(ns)
     gen_dnets(ns)
     gen_losses(ns)
     gen_step(ns)

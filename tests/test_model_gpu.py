@@ -216,6 +216,24 @@ def test_losses():
     close(mu.grad, g["dmu"], 1e-7, 1e-4); close(lv.grad, g["dlv"], 1e-7, 1e-4)
 
 
+def test_g_net_eval_mode():
+    """netG.eval() forward of the sampling path (trainer.py:398,431-437): BN folded into per-channel affines."""
+    g = golden("gnet_eval")
+    from mogan_amd.attngan.model import G_NET
+    G = G_NET()
+    det_fill_state(G, "G.")
+    G = G.to(DEV).eval()
+    bt = synthetic.to_device(synthetic.make_batch(3, words_num=5, nef=16, seed=11), DEV)
+    with torch.no_grad():
+        imgs, atts, mu, logvar = G(bt["z"], bt["sent_emb"], bt["words_embs"], bt["mask"], bt["tmi"], bt["label_one_hot"],
+                                   bt["eps"])
+    close(imgs[0], g["img64"], 1e-3, 1e-4)
+    close(imgs[2][:, :, ::4, ::4], g["img256"], 1e-3, 1e-4)
+    probe_close(probe(atts[1]), g["att128_p"], 1e-4, what="att128")
+    close(mu, g["mu"], 1e-4, 1e-5)
+    assert all(int(v) == 0 for k, v in G.state_dict().items() if k.endswith("num_batches_tracked"))
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_two_train_steps(use_graph):
     """the op order of the step (fake images generated once, each D updated

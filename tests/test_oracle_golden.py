@@ -208,6 +208,27 @@ def test_d_nets():
                 probe_close(probe(v), g[p + "s_" + k.replace(".", "__")], 1e-5, what=k)
 
 
+def test_g_net_eval_mode():
+    """netG.eval() forward of the sampling path (trainer.py:398): BN on running statistics."""
+    g = golden("gnet_eval")
+    cfg = SMALL
+    bt = synthetic.make_batch(3, words_num=cfg.words_num, nef=cfg.emb_dim, seed=11)
+    net = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."), requires_grad=False)
+    O.BN_TRAINING = False
+    try:
+        imgs, atts, mu, logvar, _ = O.g_net(net, cfg, bt["z"], bt["sent_emb"], bt["words_embs"], bt["mask"], bt["tmi"],
+                                            bt["label_one_hot"], bt["eps"])
+    finally:
+        O.BN_TRAINING = True
+    close(imgs[0], g["img64"], rtol=1e-4, atol=1e-5)
+    close(imgs[2][:, :, ::4, ::4], g["img256"], rtol=1e-4, atol=1e-5)
+    probe_close(probe(atts[1]), g["att128_p"], 1e-5, what="att128")
+    close(mu, g["mu"])
+    for k, v in net.items():                      # eval mode leaves the buffers alone
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 0
+
+
 def _build_all(cfg):
     G = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."))
     Ds = [O.from_state_dict(det_state(O.d_net_spec(i, cfg), "D%d." % i)) for i in range(3)]

@@ -44,6 +44,7 @@ __C.TREE = AttrDict(BRANCH_NUM=3, BASE_SIZE=64)
 __C.TRAIN = AttrDict(
     BATCH_SIZE=64, MAX_EPOCH=600, SNAPSHOT_INTERVAL=2000, DISCRIMINATOR_LR=2e-4, GENERATOR_LR=2e-4,
     ENCODER_LR=2e-4, RNN_GRAD_CLIP=0.25, FLAG=True, NET_E='', NET_G='', B_NET_D=True,
+    GLOBAL_BATCH_LOSS=False,       # addition: see attngan/parallel.py
     SMOOTH=AttrDict(GAMMA1=5.0, GAMMA3=10.0, GAMMA2=5.0, LAMBDA=1.0))
 
 __C.GAN = AttrDict(DF_DIM=64, GF_DIM=128, Z_DIM=100, CONDITION_DIM=100, R_NUM=2, B_ATTENTION=True,

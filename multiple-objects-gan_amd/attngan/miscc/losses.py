@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from ...hip import ops
+from .. import parallel
 from .config import cfg
 
 
@@ -98,6 +99,9 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     if real_features is None:       # (the engine may have run D(real) already, concurrently with the G forward)
         real_features = _call_d(netD, real_imgs, local_labels, transf_matrices, transf_matrices_inv)
     fake_features = _call_d(netD, fake_imgs.detach(), local_labels, transf_matrices, transf_matrices_inv)
+    if parallel.enabled():          # heads, wrong-pair shift and BCE means over the gathered batch (parallel.py)
+        real_features, fake_features = parallel.gather_cat(real_features), parallel.gather_cat(fake_features)
+        conditions = parallel.gather_const(conditions)
     batch_size = real_features.size(0)
     cond_real_errD = ops.bce(netD.COND_DNET(real_features, conditions), 1.0)
     cond_fake_errD = ops.bce(netD.COND_DNET(fake_features, conditions), 0.0)
@@ -112,6 +116,8 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
 def generator_d_branch(netD, fake_img, sent_emb, local_labels=None, transf_matrices=None, transf_matrices_inv=None):
     """One term of losses.py:187-203: BCE(cond logits of D(fake), 1) [+ BCE(uncond logits, 1)]."""
     features = _call_d(netD, fake_img, local_labels, transf_matrices, transf_matrices_inv)
+    if parallel.enabled():
+        features, sent_emb = parallel.gather_cat(features), parallel.gather_const(sent_emb)
     g_loss = ops.bce(netD.COND_DNET(features, sent_emb), 1.0)
     if netD.UNCOND_DNET is not None:
         g_loss = ops.bce(netD.UNCOND_DNET(features), 1.0) + g_loss
@@ -121,6 +127,13 @@ def generator_d_branch(netD, fake_img, sent_emb, local_labels=None, transf_matri
 def generator_damsm_branch(image_encoder, fake_img, words_embs, sent_emb, match_labels, cap_lens, class_ids, batch_size):
     """losses.py:205-221: Inception features of the last fake image -> DAMSM word and sentence losses (* LAMBDA)."""
     region_features, cnn_code = image_encoder(fake_img)
+    if parallel.enabled():          # DAMSM contrast over the gathered batch
+        region_features, cnn_code = parallel.gather_cat(region_features), parallel.gather_cat(cnn_code)
+        words_embs, sent_emb = parallel.gather_const(words_embs), parallel.gather_const(sent_emb)
+        cap_lens = parallel.gather_const(cap_lens.to(region_features.device))
+        class_ids = parallel.gather_ids(class_ids)
+        batch_size = region_features.size(0)
+        match_labels = torch.arange(batch_size, device=region_features.device)
     w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size)
     w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
     s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)

@@ -66,3 +66,75 @@ def test_flat_bucket_allreduce_world2():
         assert offs == flat.offsets
         torch.testing.assert_close(g, flat.g, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=0, atol=0)      # replicas see identical reduced grads
+
+
+# ------------------------------------------------------------------ global-batch loss mode (attngan/parallel.py)
+def _toy():
+    torch.manual_seed(3)
+    backbone = nn.Sequential(nn.Linear(6, 5), nn.Tanh())          # per-sample feature extractor (replicated)
+    head = nn.Linear(5, 4)                                        # logits head evaluated on the gathered batch
+    return backbone, head
+
+
+def _toy_loss(feat, head):
+    """batch-coupled like DAMSM: a B x B similarity matrix with cross-entropy against the diagonal, plus the
+    "wrong pair" shift of the D losses."""
+    h = head(feat)
+    sim = h @ h.t()
+    ce = nn.functional.cross_entropy(sim, torch.arange(h.shape[0]))
+    wrong = (h[:-1] * h[1:]).sum(1).mean()
+    return ce + 0.1 * wrong
+
+
+def _gb_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    load_pkg()
+    from mogan_amd.attngan import parallel
+    from mogan_amd.attngan.miscc.config import cfg
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg.TRAIN.GLOBAL_BATCH_LOSS = True
+        assert parallel.enabled()
+        backbone, head = _toy()
+        torch.manual_seed(100)
+        x = torch.randn(8, 6)[rank * 4:(rank + 1) * 4]
+        feat = parallel.gather_cat(backbone(x))
+        assert feat.shape[0] == 8
+        ids = parallel.gather_ids([10 * rank + i for i in range(4)])
+        assert list(ids) == [0, 1, 2, 3, 10, 11, 12, 13]
+        loss = _toy_loss(feat, head)
+        loss.backward()
+        gb = torch.cat([p.grad.reshape(-1) for p in backbone.parameters()])
+        gh = torch.cat([p.grad.reshape(-1) for p in head.parameters()])
+        dist.all_reduce(gb)
+        dist.all_reduce(gh)                                         # what the flat-bucket exchange does: sum, then / world
+        q.put((rank, float(loss), gb / world, gh / world))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_global_batch_loss_mode_world2():
+    """Gathered features + local-slice backward (x world) + the usual averaged all-reduce == the single-process
+    gradients of the loss on the whole batch, for the per-sample backbone and for the replicated head."""
+    load_pkg()
+    world, port = 2, 29771 + (os.getpid() % 200)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gb_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    backbone, head = _toy()
+    torch.manual_seed(100)
+    loss = _toy_loss(backbone(torch.randn(8, 6)), head)
+    loss.backward()
+    gb = torch.cat([p.grad.reshape(-1) for p in backbone.parameters()])
+    gh = torch.cat([p.grad.reshape(-1) for p in head.parameters()])
+    for rank, l, rb, rh in res:
+        assert abs(l - float(loss)) < 1e-6
+        torch.testing.assert_close(rb, gb, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rh, gh, rtol=1e-5, atol=1e-6)

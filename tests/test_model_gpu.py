@@ -276,3 +276,33 @@ def test_two_train_steps(use_graph):
             for k, v in net.named_parameters():
                 deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))])
             deltas.check(0.15 if n == "G" else 0.05, what="%s step %d" % (n, step))
+
+
+@pytest.mark.parametrize("global_loss", [False, True])
+def test_two_train_steps_through_rccl(global_loss, monkeypatch):
+    """The N>1 code path on one GPU: process group "nccl" (= RCCL) with world_size 1, flat-bucket all-reduces on the
+    comm stream, and (global_loss) the gathered-batch loss mode of attngan/parallel.py -- with one rank both must
+    reproduce the reference's single-GPU trajectory."""
+    import torch.distributed as dist
+    from mogan_amd.attngan.trainer import TrainEngine
+    monkeypatch.setenv("MOGAN_FORCE_DIST", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29300 + os.getpid() % 500), rank=0, world_size=1)
+    try:
+        cfg.TRAIN.GLOBAL_BATCH_LOSS = global_loss
+        g = golden("step")
+        G, Ds, enc = _build_all()
+        eng = TrainEngine(None, enc, G, Ds, distributed=True, use_graph=False)
+        assert eng.distributed and eng.comm_stream is not None
+        for step in range(2):
+            bt = synthetic.to_device(synthetic.make_batch(4, words_num=5, nef=16, seed=100 + step), DEV)
+            logs = eng.step(bt)
+            torch.cuda.synchronize()
+            p = "s%d_" % step
+            for k in ("errD0", "errD1", "errD2", "kl"):
+                np.testing.assert_allclose(float(logs[k]), float(g[p + k]), rtol=1e-4 * (1 + 9 * step), err_msg=k)
+            np.testing.assert_allclose(float(logs["errG"]), float(g[p + "errG"]), rtol=2e-4 * (1 + 9 * step))
+            close(logs["fake64"], g[p + "fake64"], 2e-4 * (1 + 9 * step), 1e-3)
+    finally:
+        cfg.TRAIN.GLOBAL_BATCH_LOSS = False
+        dist.destroy_process_group()

@@ -38,6 +38,7 @@ class StackGANEngine:
         self.comm_stream = torch.cuda.Stream() if self.distributed else None
         self.use_graph = use_graph
         self._graph, self._static, self.last = None, None, {}
+        self.side = torch.cuda.Stream()          # D(real) runs here, beside the generator forward
 
     def set_lr(self, generator_lr, discriminator_lr):
         """the reference halves both rates every LR_DECAY_EPOCH epochs (S/trainer.py:140-147)."""
@@ -67,21 +68,31 @@ class StackGANEngine:
 
     def device_step(self, b):
         v, netG, netD = self.variant, self.netG, self.netD
-        fake_imgs, mu, logvar = self.generate(b)
         tm, tmi = (b["tm_s2"], b["tmi_s2"]) if self.stage == 2 else (b["tm"], b["tmi"])
+        # Everything that touches D runs on ONE side stream (its weight gradients accumulate straight into the flat
+        # .grad bucket, so they must stay ordered): D(real) does not depend on the generator and starts beside the G
+        # forward; the D update and the G-step forward through the updated D follow on the same stream.
+        cur, side = torch.cuda.current_stream(), self.side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self.optD.zero_grad()
+            real_features = netD(b["real_imgs"], b["label_one_hot"].detach(), tm, tmi)
+        fake_imgs, mu, logvar = self.generate(b)
         cond = mu if v.text else losses.label_condition(b["label_one_hot"], clamp=(v.name == "clevr"))
-        self.optD.zero_grad()
-        errD, errD_real, errD_wrong, errD_fake = losses.discriminator_loss(
-            netD, b["real_imgs"], fake_imgs, b["label_one_hot"], tm, tmi, cond)
-        with ops.wgrad_overlap():
-            errD.backward()
-        self._sync_step(self.optD)
-        # G update through the updated D; D's own weight gradients are not needed (the reference computes
-        # them and drops them at the next zero_grad)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            errD, errD_real, errD_wrong, errD_fake = losses.discriminator_loss(
+                netD, b["real_imgs"], fake_imgs, b["label_one_hot"], tm, tmi, cond, real_features=real_features)
+            with ops.wgrad_overlap():
+                errD.backward()
+            self._sync_step(self.optD)
+            # G update through the updated D; D's own weight gradients are not needed (the reference computes
+            # them and drops them at the next zero_grad)
+            for p in netD.parameters():
+                p.requires_grad_(False)
+            errG = losses.generator_loss(netD, fake_imgs, b["label_one_hot"], tm, tmi, cond)
+        cur.wait_stream(side)
         self.optG.zero_grad()
-        for p in netD.parameters():
-            p.requires_grad_(False)
-        errG = losses.generator_loss(netD, fake_imgs, b["label_one_hot"], tm, tmi, cond)
         out = dict(errD=errD.detach(), errD_real=errD_real, errD_wrong=errD_wrong, errD_fake=errD_fake,
                    errG=errG.detach(), fake=fake_imgs.detach())
         if v.text:

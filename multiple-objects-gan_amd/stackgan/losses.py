@@ -22,12 +22,14 @@ def label_condition(local_label, clamp):
     return cond.clamp(min=0) if clamp else cond
 
 
-def discriminator_loss(netD, real_imgs, fake_imgs, local_label, transf_matrices, transf_matrices_inv, cond):
+def discriminator_loss(netD, real_imgs, fake_imgs, local_label, transf_matrices, transf_matrices_inv, cond,
+                       real_features=None):
     """-> (errD, errD_real, errD_wrong, errD_fake) as 0-dim tensors (the per-tree wrappers call .item()).
     real and fake go through netD as two separate calls: separate BN batch statistics, like the reference."""
     B = real_imgs.size(0)
     cond, fake, local_label = cond.detach(), fake_imgs.detach(), local_label.detach()
-    real_features = netD(real_imgs, local_label, transf_matrices, transf_matrices_inv)
+    if real_features is None:        # (the engine may have run D(real) already, beside the G forward)
+        real_features = netD(real_imgs, local_label, transf_matrices, transf_matrices_inv)
     fake_features = netD(fake, local_label, transf_matrices, transf_matrices_inv)
     errD_real = ops.bce_with_logits(netD.get_cond_logits(real_features, cond), 1.0)
     errD_wrong = ops.bce_with_logits(netD.get_cond_logits(real_features[:B - 1], cond[1:]), 0.0)

@@ -173,3 +173,41 @@ def test_two_train_steps(case, use_graph):
             # (the chaotic second step of coco_s2, see above, doubles that)
             deltas.check((0.30 if chaotic else 0.15) if name == "G" else (0.10 if chaotic else 0.05),
                          what="%s %s step %d" % (case, name, step))
+
+
+def _run_main(pkg, yml_text, tmp_path, name, extra=()):
+    import importlib
+    entry = importlib.import_module("mogan_amd.stackgan.%s.main" % pkg)
+    yml = tmp_path / (name + ".yml")
+    yml.write_text(yml_text)
+    out = tmp_path / name
+    entry.main(["--cfg", str(yml), "--synthetic", "8", "--manualSeed", "3", "--output_dir", str(out)] + list(extra))
+    import glob
+    ckpts = sorted(glob.glob(str(out / "Model" / "checkpoint_*.pth")))
+    assert ckpts, "no checkpoint written"
+    return ckpts[-1]
+
+
+def test_family_train_loops_and_checkpoints(tmp_path):
+    """`main.py --cfg ... ` -> GANTrainer.train() of each tree on synthetic items: LR-decay epoch, save_model in the
+    reference's checkpoint layout (S/miscc/utils.py:162-176), and stage II loading the stage-I generator from a
+    stage-I checkpoint (S/trainer.py:76-108)."""
+    common = "GPU_ID: '0'\nZ_DIM: 100\nWORKERS: 0\nUSE_BBOX_LAYOUT: True\n"
+    train = "TRAIN: {FLAG: True, BATCH_SIZE: 4, MAX_EPOCH: 2, LR_DECAY_EPOCH: 1, SNAPSHOT_INTERVAL: 1}\n"
+    ck = _run_main("clevr", common + train + "GAN: {CONDITION_DIM: 16, DF_DIM: 4, GF_DIM: 4}\n", tmp_path, "clevr")
+    sd = torch.load(ck, map_location="cpu", weights_only=False)
+    assert set(sd) == {"epoch", "netG", "optimG", "netD", "optimD"} and sd["netD"] == {} and sd["epoch"] == 1
+    assert all(torch.isfinite(v).all() for v in sd["netG"].values() if v.is_floating_point())
+    _run_main("multi_mnist", common + train + "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 4}\n", tmp_path, "mnist")
+    s1 = _run_main("coco", common + "STAGE: 1\nIMSIZE: 64\n" + train.replace("}", ", COEFF: {KL: 2.0}}")
+                   + "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 192}\nTEXT: {DIMENSION: 16}\n", tmp_path, "s1",
+                   extra=["--max_epoch", "1"])
+    s2 = _run_main("coco", common + "STAGE: 2\nIMSIZE: 256\nSTAGE1_G: '%s'\n" % s1
+                   + "TRAIN: {FLAG: True, BATCH_SIZE: 2, MAX_EPOCH: 1, LR_DECAY_EPOCH: 1, SNAPSHOT_INTERVAL: 1, COEFF: {KL: 2.0}}\n"
+                   + "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 192, R_NUM: 1}\nTEXT: {DIMENSION: 16}\n", tmp_path, "s2",
+                   extra=["--synthetic", "4"])
+    g1 = torch.load(s1, map_location="cpu", weights_only=False)["netG"]
+    g2 = torch.load(s2, map_location="cpu", weights_only=False)["netG"]
+    # the frozen stage-I generator inside STAGE2_G still holds the stage-I checkpoint's weights
+    assert torch.equal(g2["STAGE1_G.fc.0.weight"], g1["fc.0.weight"])
+    assert not torch.equal(g2["STAGE1_G.fc.1.running_mean"], g1["fc.1.running_mean"])     # its BN buffers keep running

@@ -377,10 +377,11 @@ def main():
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(engine, bt_cpu, engine.encode_batch_for_cpu(batch), B)
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0:                      # the JSON line is the last thing on stdout (RCCL prints its banner there too)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -69,6 +69,21 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
 int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
                        hipStream_t stream);
+
+/* nn.Upsample(scale_factor=2, mode='nearest') + conv3x3(padding 1, no bias) -- every upBlock of the reference
+ * (code/coco/attngan/model.py:48-55, code/coco/stackgan/model.py:16-22) -- evaluated as the TRANSPOSED 4x4
+ * stride-2 pad-1 convolution with kernel K = T w T^t, T = [[0,0,1],[0,1,1],[1,1,0],[1,0,0]]: each phase of the
+ * upsampled grid sees only 2x2 distinct source pixels, so 4 multiply-adds per output pixel replace 9 (same result up
+ * to the fp32 rounding of the pre-summed weights).  x (B,Cin,Hs,Ws), w (Cout,Cin,3,3), y (B,Cout,2Hs,2Ws).
+ * dgrad returns dx at the SOURCE resolution (B,Cin,Hs,Ws) (no mogan_down2_sum).  The workspace must hold
+ * mogan_upconv3x3_ws_bytes(Cout,Cin) for K (dK in wgrad) in front of the split-K scratch of the inner conv. */
+size_t mogan_upconv3x3_ws_bytes(int Cout, int Cin);
+int mogan_upconv3x3_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, void* ws,
+                        size_t ws_bytes, hipStream_t stream);
+int mogan_upconv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, void* ws,
+                          size_t ws_bytes, hipStream_t stream);
+int mogan_upconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout,
+                          int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 /* backward of nearest x2 upsample: dx[b,c,y,x] = sum of the 2x2 block of du (B*C planes of 2H x 2W) */
 int mogan_down2_sum(const float* du, float* dx, int planes, int H, int W, hipStream_t stream);
 

@@ -676,6 +676,101 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
     return run_gemm(CONV_WGRAD, p, 1, (long long)Cout * Cin * KH * KW, ws, ws_bytes, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// nearest-x2 upsample + conv3x3(p1)  ==  the TRANSPOSED 4x4 stride-2 pad-1 convolution with kernel K = T w T^t
+// (T = [[0,0,1],[0,1,1],[1,1,0],[1,0,0]] applied to the rows and to the columns of every 3x3 filter): each output
+// phase (py,px) of the upsampled grid only ever sees 2x2 distinct source pixels, so 4 multiply-adds per output
+// pixel replace 9 (2.25x fewer FLOPs, same result up to the fp32 rounding of the pre-summed weights).
+//   forward  Y = C4^T(X)      -> mogan_conv2d_dgrad of the virtual conv C4 (in = Cout, out = Cin, 4x4 s2 p1)
+//   dgrad    dX = C4(dY)       -> mogan_conv2d_fwd  of C4: the gradient comes out at the SOURCE resolution
+//   wgrad    dK = wgrad_C4(dy4 = X, x4 = dY);  dW = T^t dK T (accumulated into dw)
+// K[ci][co][kh][kw] lives at the head of the caller's workspace.
+namespace {
+__global__ __launch_bounds__(256) void upconv_k4_kernel(const float* __restrict__ w, float* __restrict__ K4, int Cout,
+                                                        int Cin) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one thread per (ci, co)
+    if (i >= (long long)Cout * Cin) return;
+    const int ci = (int)(i / Cout), co = (int)(i - (long long)ci * Cout);
+    const float* s = w + ((size_t)co * Cin + ci) * 9;
+    float f[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) f[a][b] = s[a * 3 + b];
+    float r[4][3];                                                        // rows: [w2, w1+w2, w0+w1, w0]
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { r[0][b] = f[2][b]; r[1][b] = f[1][b] + f[2][b]; r[2][b] = f[0][b] + f[1][b]; r[3][b] = f[0][b]; }
+    float* d = K4 + i * 16;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { d[a * 4 + 0] = r[a][2]; d[a * 4 + 1] = r[a][1] + r[a][2]; d[a * 4 + 2] = r[a][0] + r[a][1]; d[a * 4 + 3] = r[a][0]; }
+}
+// dW[co][ci] (+)= T^t dK[ci][co] T
+__global__ __launch_bounds__(256) void upconv_k4_grad_kernel(const float* __restrict__ dK, float* __restrict__ dw, int Cout,
+                                                             int Cin, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one thread per (co, ci): coalesced dW
+    if (i >= (long long)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
+    const float* s = dK + ((size_t)ci * Cout + co) * 16;
+    float g[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) g[a][b] = s[a * 4 + b];
+    float r[3][4];                                                        // T^t rows: w0 <- k2+k3, w1 <- k1+k2, w2 <- k0+k1
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { r[0][b] = g[2][b] + g[3][b]; r[1][b] = g[1][b] + g[2][b]; r[2][b] = g[0][b] + g[1][b]; }
+    float* d = dw + i * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v0 = r[a][2] + r[a][3], v1 = r[a][1] + r[a][2], v2 = r[a][0] + r[a][1];
+        if (accumulate) { d[a * 3 + 0] += v0; d[a * 3 + 1] += v1; d[a * 3 + 2] += v2; }
+        else { d[a * 3 + 0] = v0; d[a * 3 + 1] = v1; d[a * 3 + 2] = v2; }
+    }
+}
+
+inline size_t upconv_k_bytes(int Cout, int Cin) { return (((size_t)Cout * Cin * 16 * sizeof(float)) + 255) & ~(size_t)255; }
+
+int upconv_make_k(const float* w, void* ws, size_t ws_bytes, int Cout, int Cin, hipStream_t st) {
+    if (!ws || ws_bytes < upconv_k_bytes(Cout, Cin) || Cout <= 0 || Cin <= 0) return MOGAN_ERR_WS;
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(upconv_k4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout, Cin);
+    return 0;
+}
+}  // namespace
+
+size_t mogan_upconv3x3_ws_bytes(int Cout, int Cin) { return upconv_k_bytes(Cout, Cin); }
+
+int mogan_upconv3x3_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, void* ws,
+                        size_t ws_bytes, hipStream_t stream) {
+    int rc = upconv_make_k(w, ws, ws_bytes, Cout, Cin, stream); if (rc) return rc;
+    const size_t kb = upconv_k_bytes(Cout, Cin);
+    // C4: input (B,Cout,2Hs,2Ws) -> output (B,Cin,Hs,Ws); its data gradient maps X to Y
+    return mogan_conv2d_dgrad(x, (const float*)ws, y, B, Cout, 2 * Hs, 2 * Ws, Cin, 4, 4, 2, 1, 1, 0, (char*)ws + kb,
+                              ws_bytes - kb, stream);
+}
+
+int mogan_upconv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, void* ws,
+                          size_t ws_bytes, hipStream_t stream) {
+    int rc = upconv_make_k(w, ws, ws_bytes, Cout, Cin, stream); if (rc) return rc;
+    const size_t kb = upconv_k_bytes(Cout, Cin);
+    return mogan_conv2d_fwd(dy, (const float*)ws, dx, B, Cout, 2 * Hs, 2 * Ws, Cin, 4, 4, 2, 1, 1, 0, (char*)ws + kb,
+                            ws_bytes - kb, stream);
+}
+
+int mogan_upconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout,
+                          int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    const size_t kb = upconv_k_bytes(Cout, Cin);
+    if (!ws || ws_bytes < kb) return MOGAN_ERR_WS;
+    // dK (Cin,Cout,4,4) = weight gradient of C4 with output-gradient X and input dY
+    int rc = mogan_conv2d_wgrad(x, dy, (float*)ws, B, Cout, 2 * Hs, 2 * Ws, Cin, 4, 4, 2, 1, 1, 0, 0, (char*)ws + kb,
+                                ws_bytes - kb, stream);
+    if (rc) return rc;
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(upconv_k4_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)ws,
+                       dw, Cout, Cin, accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
 int mogan_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, long long sAb, long long sAm,
               long long sAk, long long sBb, long long sBk, long long sBn, long long sCb, long long sCm, long long sCn,
               int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {

@@ -26,6 +26,10 @@ SIGNATURES = {
     "mogan_conv2d_fwd": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_wgrad": [P, P, P] + [I] * 12 + [P, Z, P],
+    "mogan_upconv3x3_ws_bytes": [I, I],
+    "mogan_upconv3x3_fwd": [P, P, P, I, I, I, I, I, P, Z, P],
+    "mogan_upconv3x3_dgrad": [P, P, P, I, I, I, I, I, P, Z, P],
+    "mogan_upconv3x3_wgrad": [P, P, P, I, I, I, I, I, I, P, Z, P],
     "mogan_down2_sum": [P, P, I, I, I, P],
     "mogan_bmm": [P, P, P, I, I, I, I] + [L] * 9 + [I, P, Z, P],
     "mogan_bn_ws_bytes": [I, I, I],
@@ -63,7 +67,7 @@ SIGNATURES = {
     "mogan_bilinear_bwd": [P, P, I, I, I, I, I, P],
     "mogan_adam_step": [P, P, P, P, P, L, F, F, F, F, I, P, I, F, F, P],
 }
-_RESTYPE = {"mogan_bn_ws_bytes": Z}
+_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
 _lib = None

@@ -17,6 +17,7 @@
 //   wgrad     = K runs over the pixels of the tile, B = Xs read at [ci][ry*S+kh][rx*S+kw] with (ci,kh,kw) on the lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
@@ -532,7 +533,8 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     const long long tiles = (long long)p.B * p.tiles_x * p.tiles_y * cdiv(p.Cout, bm) * p.npar;
     const int nchunk = p.Cin / CK;
     int nsplit = 1;
-    if (tiles < 384 && nchunk >= 8) nsplit = (int)std::min<long long>(cdiv(512, tiles), nchunk / 4);
+    static const int fwd_target = getenv("MOGAN_DSPLIT_FWD") ? atoi(getenv("MOGAN_DSPLIT_FWD")) : 512;
+    if (tiles < 384 && nchunk >= 8) nsplit = (int)std::min<long long>(cdiv(fwd_target, tiles), nchunk / 4);
     const long long y_numel = (long long)p.B * p.Cout * p.yH * p.yW;
     if (nsplit > 1) {
         const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)y_numel)) : 0;
@@ -566,7 +568,8 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     p.lg_tx = __builtin_ctz(p.tiles_x); p.lg_ty = __builtin_ctz(p.tiles_y);
     const long long blocks = cdiv(p.N, 128) * cdiv(p.Cout, bm);
     const long long w_numel = (long long)p.Cout * p.N;
-    int nsplit = (int)std::min<long long>(cdiv(640, blocks), std::max(1, p.ntiles / 2));
+    static const int wg_target = getenv("MOGAN_DSPLIT_WG") ? atoi(getenv("MOGAN_DSPLIT_WG")) : 640;
+    int nsplit = (int)std::min<long long>(cdiv(wg_target, blocks), std::max(1, p.ntiles / 2));
     if (nsplit > 1) {
         const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)w_numel)) : 0;
         nsplit = fit < 2 ? 1 : (int)std::min<long long>(nsplit, fit);

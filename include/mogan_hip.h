@@ -43,6 +43,10 @@ typedef struct ihipStream_t* hipStream_t;
 #define MOGAN_ACT_SIGMOID 5
 
 int mogan_abi_version(void);
+/* split-K of the implicit-GEMM kernels aims at `blocks` workgroups per launch (default 768 = three per CU for a kernel
+ * that has the GPU to itself; a caller that keeps several streams busy lowers it to 384: fewer slabs to reduce). */
+int mogan_gemm_set_split_target(int blocks);
+
 /* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
 int mogan_gemm_debug_force(int cfg, int split);
 

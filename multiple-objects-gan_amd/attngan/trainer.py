@@ -163,6 +163,8 @@ class TrainEngine:
         imgs[3], z, eps, words_embs, sent_emb, mask, cap_lens, tm, tmi, label_one_hot."""
         netG, netsD = self.netG, self.netsD
         B = b["z"].shape[0]
+        from ..hip import lib
+        lib.call("mogan_gemm_set_split_target", 384 if self.multi_stream else 768)   # see include/mogan_hip.h
         real_labels = b["z"].new_ones(B)
         fake_labels = b["z"].new_zeros(B)
         match_labels = b["match_labels"]

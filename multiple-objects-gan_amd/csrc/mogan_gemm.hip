@@ -102,8 +102,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int zb = blockIdx.z / p.nsplit, sp = blockIdx.z % p.nsplit;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k is given a
+    // CONTIGUOUS range of the tile sequence (n fastest): the blocks that share one A (weight) panel then hit the same L2
+    // instead of fetching it once per XCD.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#if !defined(LAB) || LAB != 9
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const unsigned L = bx + gx * (by + gy * bz);
+        const unsigned k = L & 7u, j = L >> 3, q = total >> 3, r = total & 7u;
+        const unsigned V = k * q + (k < r ? k : r) + j;
+        bx = V % gx; const unsigned t2 = V / gx; by = t2 % gy; bz = t2 / gy;
+    }
+#endif
+    const int m0 = by * BM, n0 = bx * BN;
+    const int zb = bz / p.nsplit, sp = bz % p.nsplit;
     const int kbeg = sp * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -490,6 +503,11 @@ namespace {
 
 // Tile config: least padded MFMA work; ties -> larger tile.  Split-K: fill >= 2 waves of 256 CUs
 // when the tile grid alone cannot, keeping >= 128 of K per split.
+// split-K aims at this many blocks per launch (mogan_gemm_set_split_target): 768 = three per CU when the kernel has the
+// GPU to itself; a caller that keeps several streams busy asks for 384 (fewer slabs to reduce, the other branches fill the
+// chip): +2 % on the multi-stream train step, -7 % on the kernel alone.
+static int g_split_target = 768;
+
 static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, size_t ws_bytes, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return 0;
     int best = 0; double bestw = 1e300;
@@ -504,8 +522,7 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     const long long tiles = cdiv(p.M, bm) * cdiv(p.N, bn) * nz;
     int nsplit = 1;
     const int ktiles = (int)cdiv(p.K, 32);
-    static const int split_target = getenv("MOGAN_SPLIT_TARGET") ? atoi(getenv("MOGAN_SPLIT_TARGET")) : 384;   // blocks aimed at; the
-    // side-stream branches fill the rest of the chip (768 = 3 per CU measured 1.5 % slower in the step, 256 slower too)
+    const int split_target = g_split_target;
     if (tiles < 512 && ktiles >= 8) {             // fewer than two blocks per CU and a K loop worth cutting
         nsplit = (int)cdiv(split_target, tiles);
         nsplit = (int)std::min<long long>(nsplit, ktiles / 4);
@@ -572,6 +589,12 @@ static int conv_geom(GemmP& p, int B, int Cin, int Hs, int Ws, int Cout, int KH,
 }  // namespace
 
 extern "C" {
+
+int mogan_gemm_set_split_target(int blocks) {
+    if (blocks < 64 || blocks > 8192) return MOGAN_ERR_SHAPE;
+    g_split_target = blocks;
+    return 0;
+}
 
 int mogan_gemm_debug_force(int cfg, int split) { g_force_cfg = cfg; g_force_split = split; return 0; }
 

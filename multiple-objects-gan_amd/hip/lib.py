@@ -18,6 +18,7 @@ P, I, F, L, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 # name -> argtypes (all return int unless listed in _RESTYPE); mirrors include/mogan_hip.h
 SIGNATURES = {
     "mogan_abi_version": [],
+    "mogan_gemm_set_split_target": [I],
     "mogan_gemm_debug_force": [I, I],
     "mogan_prof_enable": [I],
     "mogan_prof_collect": [P, I],

@@ -95,6 +95,32 @@ def test_conv2d_fwd_dgrad_wgrad(case, force):
         lib.load().mogan_gemm_debug_force(-1, 0)
 
 
+UP_CASES = [(2, 8, 8, 8, 16), (3, 5, 9, 7, 7), (2, 64, 16, 16, 64), (2, 96, 32, 32, 96), (1, 72, 64, 64, 100),
+            (2, 128, 4, 4, 192)]
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+@pytest.mark.parametrize("as_k4", [True, False])
+def test_upsample_conv3x3_both_formulations(case, as_k4, monkeypatch):
+    """nearest x2 + conv3x3(p1): the transposed 4x4-s2 evaluation (mogan_upconv3x3_*, K = T w T^t) and the
+    fused-upsample 3x3 kernels against the fp64 reference -- forward, data gradient (at the source resolution) and
+    weight gradient incl. accumulation into an existing buffer."""
+    B, Cin, H, W, Cout = case
+    monkeypatch.setattr(ops, "UPCONV4", as_k4)
+    x = T("ux%s" % (case,), (B, Cin, H, W)).requires_grad_(True)
+    w = T("uw%s" % (case,), (Cout, Cin, 3, 3), 0.2).requires_grad_(True)
+    ref = _conv_ref(x, w, 1, (1, 1), 1)
+    g = T("ug%s" % (case,), ref.shape)
+    ref.backward(g.double())
+    xd, wd = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    y = ops.conv2d(xd, wd, None, 1, 1, True)
+    y.backward(g.to(DEV))
+    _check(y, ref, what="fwd"); _check(xd.grad, x.grad, what="dgrad"); _check(wd.grad, w.grad, what="wgrad")
+    acc = wd.grad.clone()
+    ops.conv2d_wgrad(g.to(DEV), xd.detach(), tuple(w.shape), 1, 1, 1, 1, out=acc, accumulate=True)
+    _check(acc, 2 * w.grad, what="wgrad accumulate")
+
+
 def test_conv_bias_and_wgrad_accumulate():
     x = T("cbx", (3, 12, 4, 4)).requires_grad_(True)
     w = T("cbw", (1, 12, 4, 4), 0.2).requires_grad_(True)

@@ -280,13 +280,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = bool(os.environ.get("MOGAN_FORCE_DIST")) and "RANK" in os.environ
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)                       # before the process group: RCCL binds to the current device
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
 
     set_coco_train_defaults()
     B = args.batch

@@ -111,7 +111,6 @@ class TrainEngine:
         self.distributed = bool(distributed) and dist.is_available() and dist.is_initialized() \
             and (dist.get_world_size() > 1 or bool(os.environ.get("MOGAN_FORCE_DIST")))   # env: exercise the RCCL path at N=1
         self.world = dist.get_world_size() if self.distributed else 1
-        self.comm_stream = torch.cuda.Stream() if self.distributed else None
         self.use_graph = use_graph
         self._graph = None
         self._static = None
@@ -121,12 +120,23 @@ class TrainEngine:
         # become parallel branches of the hipGraph.  MOGAN_STREAMS=0 keeps everything on one stream.
         self.multi_stream = os.environ.get("MOGAN_STREAMS", "1") != "0"
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
+        # stream creation order fixes the stream -> hardware-queue map (see ops.precreate_wgrad_stream): branch streams,
+        # then the weight-gradient streams in the order the branches run (D256, D128, D64, generator), communication
+        # streams last -- measured: with the communication streams created in between, the generator's wgrad stream landed
+        # on the main stream's queue and the RCCL path ran 12 % slower before a single byte was exchanged
+        for i in range(len(netsD))[::-1]:
+            ops.precreate_wgrad_stream(self.side[i])
+        ops.precreate_wgrad_stream(torch.cuda.current_stream())
+        self.comm_stream = None          # collectives are issued on the branch streams (see _allreduce_async)
 
     # -- data parallel: sum all-reduce of a flat gradient bucket over RCCL on a side stream ----------
     def _allreduce_async(self, flat):
         if not self.distributed:
             return None
-        return allreduce_flat(flat.g, self.comm_stream)
+        # issued on the branch's own stream: the process group's internal stream orders the collective behind the work
+        # queued on it and the branch continues (Adam) behind the collective; a dedicated communication stream only adds
+        # a stream whose event wait blocks a hardware queue (measured slower)
+        return allreduce_flat(flat.g, None)
 
     def _opt_step(self, flat, pending):
         if pending is not None:
@@ -204,18 +214,28 @@ class TrainEngine:
             # where the generator loss is summed; autograd replays each branch's backward on its own stream.
             parts = {}
 
-            def d_branch(i):
+            def d_head(i):          # D_i: loss on (real, fake), backward -- up to the point where the gradient is complete
                 s = self.side[i]
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
-                    out["errD%d" % i] = self._d_update(i, b, fake_imgs, real_labels, fake_labels, real_feat.get(i))
+                    errD = self._d_loss(i, b, fake_imgs, real_labels, fake_labels, real_feat.get(i))
+                    with ops.wgrad_overlap():
+                        errD.backward()
+                    out["errD%d" % i] = errD.detach()
+
+            def d_tail(i):          # all-reduce, Adam, then the G-step forward through the updated D_i
+                with torch.cuda.stream(self.side[i]):
+                    self._opt_step(self.optDs[i], self._allreduce_async(self.optDs[i]))
                     for p in netsD[i].parameters():          # G step: no weight gradients of the Ds
                         p.requires_grad_(False)
                     kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
                               transf_matrices_inv=b["tmi"]) if i == 0 else {}
                     parts["g_loss%d" % i] = generator_d_branch(netsD[i], fake_imgs[i], b["sent_emb"], **kw)
 
-            d_branch(order[0])
+            # host order: the largest D first (its work starts early), the Inception/DAMSM branch right behind it; the
+            # tails smallest-first -- the collectives of one process group execute in issue order, and D64's / D128's
+            # all-reduce must not queue behind the event of D256's longer backward
+            d_head(order[0])
             s = self.side[nD]
             s.wait_stream(cur)
             with torch.cuda.stream(s):
@@ -223,7 +243,9 @@ class TrainEngine:
                     self.image_encoder, fake_imgs[nD - 1], b["words_embs"], b["sent_emb"], match_labels, b["cap_lens"],
                     b.get("class_ids"), B)
             for i in order[1:]:
-                d_branch(i)
+                d_head(i)
+            for i in order[::-1]:
+                d_tail(i)
             for s in self.side:
                 cur.wait_stream(s)
             self.optG.zero_grad()

@@ -97,7 +97,14 @@ def load():
     return _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of the current torch stream.  torch.cuda.current_stream() costs ~7 us of python per call (3000 calls
+    per train step); the raw-handle query is a single C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -106,8 +113,8 @@ def workspace(device):
     if device.type != "cuda":
         raise MoganHipError("mogan_hip ops need tensors on the GPU (got device %s): there is no CPU "
                             "path in the product" % device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None:
         buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)

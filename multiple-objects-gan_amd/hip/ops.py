@@ -63,6 +63,16 @@ def _wgrad_stream():
     return cur, side
 
 
+def precreate_wgrad_stream(stream):
+    """Create the weight-gradient side stream of `stream` now.  HIP multiplexes streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and two streams that share a queue serialize -- so the engines
+    create their streams in one fixed order (branch streams, their wgrad streams, communication streams last) instead
+    of leaving it to the first backward pass."""
+    if stream.cuda_stream not in _wgrad_streams:
+        _wgrad_streams[stream.cuda_stream] = torch.cuda.Stream()
+    return _wgrad_streams[stream.cuda_stream]
+
+
 def join_wgrad():
     if not _wgrad_streams:
         return

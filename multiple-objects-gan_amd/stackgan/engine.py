@@ -35,7 +35,6 @@ class StackGANEngine:
         self.distributed = bool(distributed) and dist.is_available() and dist.is_initialized() \
             and (dist.get_world_size() > 1 or bool(os.environ.get("MOGAN_FORCE_DIST")))
         self.world = dist.get_world_size() if self.distributed else 1
-        self.comm_stream = torch.cuda.Stream() if self.distributed else None
         self.use_graph = use_graph
         self._graph, self._static, self.last = None, None, {}
         self.side = torch.cuda.Stream()          # D(real) runs here, beside the generator forward
@@ -48,9 +47,8 @@ class StackGANEngine:
 
     # ------------------------------------------------------------------------------------------
     def _sync_step(self, flat):
-        pending = allreduce_flat(flat.g, self.comm_stream) if self.distributed else None
-        if pending is not None:
-            torch.cuda.current_stream().wait_event(pending)
+        if self.distributed:            # on the stream the gradient was produced on (see attngan/trainer.py)
+            allreduce_flat(flat.g, None)
         flat.step(grad_scale=1.0 / self.world)
 
     def generate(self, b):

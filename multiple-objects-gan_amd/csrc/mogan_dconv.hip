@@ -53,12 +53,17 @@ struct DConvP {
 // weight images of chunk c+1 are written into the second buffer *between the MFMA k-steps of chunk c* (one barrier per
 // chunk, no store phase).  PMC on the single-buffer version (96->96 3x3 at 256x256): MFMA pipe busy 76 %, every wave
 // parked 13 % of its cycles at the two barriers around the store phase, and the two blocks of a CU run in lockstep.
-template <int KH, int KW, int S, int WM, int WN, int TM, int TN, int CK, int CW, bool DB>
+// WIDE (stride 1, no fused upsample, W % 4 == 0): halo rows come in as aligned 16-byte quads covering the columns
+// [ox0-4, ox0+CW+4), LDS column c <-> image column ox0-4+c (see dconv_wgrad_kernel).
+template <int KH, int KW, int S, int WM, int WN, int TM, int TN, int CK, int CW, bool DB, bool WIDE>
 __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     constexpr int BM = WM * TM * 32, NTB = WN * TN, PX = NTB * 32, KHW = KH * KW, KC = CK * KHW;
     constexpr int R = PX / CW;
     constexpr int HH = (R - 1) * S + KH, WW = (CW - 1) * S + KW;
-    constexpr int WWP = (WW + 7) & ~7, CPL = HH * WWP;
+    constexpr int QPR = (CW + 8) / 4;                                // quads per halo row (WIDE)
+    constexpr int WWP = WIDE ? 4 * QPR : ((WW + 7) & ~7), CPL = HH * WWP;
+    constexpr int NXQ = WIDE ? (CK * HH * QPR + 255) / 256 : 1;
+    static_assert(!WIDE || S == 1, "WIDE is a stride-1 variant");
     // odd row stride: the A operand read (lane = output channel, stride LDW dwords) then touches 32 distinct banks.
     // PMC with LDW = KC+4 (16-byte rows, b128 stores): 12*lane mod 32 -> 4-way conflicts on every A read, LDS array
     // busy 50 % of the kernel, 69 % of that in conflict cycles.  The price is scalar LDS stores of the weight quads.
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     constexpr int NSTEP = (CK / 2) * KHW, FIRST = NSTEP / 2;      // stores of the next chunk ride on steps >= FIRST
     constexpr int XPS = (NXE + (NSTEP - FIRST) - 1) / (NSTEP - FIRST), WPS = (NWQ + (NSTEP - FIRST) - 1) / (NSTEP - FIRST);
     static_assert(WM * WN == 4 && KC % 4 == 0 && CK % 2 == 0 && PX == 128, "tile");
-    __shared__ float Xs[NBUF * XSZ];
+    __shared__ __attribute__((aligned(16))) float Xs[NBUF * XSZ];
     __shared__ __attribute__((aligned(16))) float Wl[NBUF * WSZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,6 +122,20 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
             xl[i] = e < total ? c * CPL + hy * WWP + col : -1;
         }
     }
+    unsigned qg[NXQ]; int ql[NXQ];
+    if constexpr (WIDE) {
+        const int iy_base = oy0 - pt;
+#pragma unroll
+        for (int i = 0; i < NXQ; ++i) {
+            const int q = tid + 256 * i;
+            const int c = q / (HH * QPR), r = q - c * (HH * QPR);
+            const int hy = r / QPR, qx = r - hy * QPR;
+            const int iy = iy_base + hy, ix = ox0 - 4 + 4 * qx;
+            const bool ok = q < CK * HH * QPR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            qg[i] = ok ? (unsigned)(c * HsWs + iy * p.Ws + ix) : IDX_OOB;
+            ql[i] = q < CK * HH * QPR ? c * CPL + hy * WWP + 4 * qx : -1;
+        }
+    }
     const unsigned x_img = (unsigned)img * p.Cin * HsWs;
     // weights: quad q -> (row, kq): 4 consecutive k of one output channel
     unsigned wg[NWQ]; int wl[NWQ];
@@ -129,15 +148,22 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
         wl[i] = q < BM * (KC / 4) ? row * LDW + 4 * kq : -1;
     }
 
-    float rx[NXE]; f32x4 rw[NWQ];
+    float rx[NXE]; f32x4 rw[NWQ]; f32x4 rxq[NXQ];
     auto load_chunk = [&](int c) {
         const unsigned xb = x_img + (unsigned)c * CK * HsWs, wb = (unsigned)c * KC;
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int i = 0; i < NXQ; ++i) rxq[i] = ldg4(rX, qg[i] == IDX_OOB ? IDX_OOB : qg[i] + xb);
+        } else
 #pragma unroll
         for (int i = 0; i < NXE; ++i) rx[i] = ldg(rX, xg[i] == IDX_OOB ? IDX_OOB : xg[i] + xb);
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) rw[i] = ldg4(rW, wg[i] == IDX_OOB ? IDX_OOB : wg[i] + wb);
     };
-    auto store_x = [&](int i, float* Xd) { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; };
+    auto store_x = [&](int i, float* Xd) {
+        if constexpr (WIDE) { if (i < NXQ && ql[i] >= 0) *(f32x4*)&Xd[ql[i]] = rxq[i]; }
+        else { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; }
+    };
     auto store_w = [&](int i, float* Wd) {
         if (wl[i] >= 0) {
             Wd[wl[i]] = rw[i][0]; Wd[wl[i] + 1] = rw[i][1]; Wd[wl[i] + 2] = rw[i][2]; Wd[wl[i] + 3] = rw[i][3];
@@ -166,7 +192,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     for (int t = 0; t < TN; ++t) {
         const int pb = (wn * TN + t) * 32 + (lane & 31);
         const int ry = pb / CW, rxx = pb - ry * CW;
-        bbase[t] = h * CPL + ry * S * WWP + (S == 2 ? rxx : rxx * S);
+        bbase[t] = h * CPL + ry * S * WWP + (S == 2 ? rxx : rxx * S) + (WIDE ? 4 - pl : 0);
     }
 
     if (c_beg < c_end) {
@@ -224,7 +250,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
                 for (int g = 0; g < NSTEP; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-                    if (g < NXE + NWQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (g < (WIDE ? NXQ : NXE) + NWQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
             __syncthreads();
@@ -279,19 +305,26 @@ struct WGradP {
 // DBW = LDS double buffering: the dY / halo images of pixel-tile t+1 are written into the second buffer between the
 // MFMA k-steps of tile t (one barrier per tile).  Lab numbers that motivated it (96->96 3x3 at 256x256, TFLOP/s):
 // product 87, without the X gather 104, without any global load 113, without the store phase and its two barriers 115.
-template <int KH, int KW, int S, int CW, int WM, int WN, int TM, int TN, bool DBW>
+// WIDE (3x3 s1 p1, no fused upsample, W % 4 == 0): the halo rows are fetched as aligned 16-byte quads covering the
+// columns [ox0-4, ox0+CW+4) -- 10 loads per row instead of 34 dword loads; every quad is entirely inside or outside
+// the image.  LDS column c of a row then holds image column ox0-4+c.
+template <int KH, int KW, int S, int CW, int WM, int WN, int TM, int TN, bool DBW, bool WIDE>
 __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, KHW = KH * KW, PXK = 64, RT = PXK / CW;
-    constexpr int HHW = (RT - 1) * S + KH, WW = (CW - 1) * S + KW, WWP = (WW + 3) & ~3, CPLW = HHW * WWP;
+    constexpr int QPR = (CW + 8) / 4;                                      // quads per halo row (WIDE)
+    constexpr int HHW = (RT - 1) * S + KH, WW = (CW - 1) * S + KW, WWP = WIDE ? 4 * QPR + 4 : ((WW + 3) & ~3);
+    constexpr int CPLW = HHW * WWP, COL0 = WIDE ? 3 : 0;                   // LDS column of image column ox0 - pl
     constexpr int CKW = BN / KHW + 2, LDY = PXK + 4;
-    constexpr int NXE = (CKW * HHW * WW + 255) / 256, NYQ = BM * (PXK / 4) / 256;
+    constexpr int NXE = WIDE ? 1 : (CKW * HHW * WW + 255) / 256, NYQ = BM * (PXK / 4) / 256;
+    constexpr int NXQ = WIDE ? (CKW * HHW * QPR + 255) / 256 : 1;
+    static_assert(!WIDE || (S == 1 && KH == 3 && KW == 3), "WIDE is the 3x3 s1 variant");
     constexpr bool PIPE = (S == 2);
     constexpr int NBUF = DBW ? 2 : 1, YSZ = BM * LDY, XSZ = CKW * CPLW;
     constexpr int NSTEP = PXK / 2, FIRST = NSTEP / 2;
     constexpr int XPS = (NXE + (NSTEP - FIRST) - 1) / (NSTEP - FIRST), YPS = (NYQ + (NSTEP - FIRST) - 1) / (NSTEP - FIRST);
     static_assert(WM * WN == 4 && BN == 128, "tile");
     __shared__ __attribute__((aligned(16))) float Ys[NBUF * YSZ];
-    __shared__ float Xs[NBUF * XSZ];
+    __shared__ __attribute__((aligned(16))) float Xs[NBUF * XSZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -319,6 +352,19 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
         xhy[i] = hy; xhx[i] = hx;
         xl[i] = e < CKW * HHW * WW ? c * CPLW + hy * WWP + hx : -1;
     }
+    unsigned qpre[NXQ]; int qhy[NXQ], qx4[NXQ], ql[NXQ];
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int i = 0; i < NXQ; ++i) {
+            const int q = tid + 256 * i;
+            const int c = q / (HHW * QPR), r = q - c * (HHW * QPR);
+            const int hy = r / QPR, qx = r - hy * QPR;
+            const bool ok = q < CKW * HHW * QPR && ci_first + c < p.Cin;
+            qpre[i] = ok ? (unsigned)((ci_first + c) * HsWs + hy * p.Ws + 4 * qx) : PRE_BAD;
+            qhy[i] = hy; qx4[i] = 4 * qx;
+            ql[i] = q < CKW * HHW * QPR ? c * CPLW + hy * WWP + 4 * qx : -1;
+        }
+    }
     unsigned yg[NYQ]; int yl[NYQ];
 #pragma unroll
     for (int i = 0; i < NYQ; ++i) {
@@ -328,7 +374,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
         yg[i] = m0 + row < p.Cout ? (unsigned)((m0 + row) * p.OH * p.OW + ry * p.OW + rxx) : IDX_OOB;
         yl[i] = row * LDY + p0;
     }
-    float rx[NXE]; f32x4 ry4[NYQ];
+    float rx[NXE]; f32x4 ry4[NYQ]; f32x4 rxq[NXQ];
     auto load_tile = [&](int t) {
         const int tx = t & (p.tiles_x - 1); const int u = t >> p.lg_tx;
         const int ty = u & (p.tiles_y - 1); const int img = u >> p.lg_ty;
@@ -340,6 +386,15 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
         const unsigned sbase = (unsigned)img * p.Cin * HsWs +
             (unsigned)(p.up ? ((iyb + 1) >> 1) * p.Ws + ((ixb + 1) >> 1) : iyb * p.Ws + ixb);
         const bool interior = iyb >= 0 && ixb >= 0 && iyb + HHW <= p.H && ixb + WW <= p.W;
+        if constexpr (WIDE) {
+            // quad columns start at image column ox0 - 4 (16-byte aligned); whole quads are in or out of the row
+            const unsigned qbase = (unsigned)img * p.Cin * HsWs + (unsigned)(iyb * p.Ws + ox0 - 4);
+#pragma unroll
+            for (int i = 0; i < NXQ; ++i) {
+                const bool ok = (unsigned)(iyb + qhy[i]) < (unsigned)p.H && (unsigned)(ox0 - 4 + qx4[i]) < (unsigned)p.W;
+                rxq[i] = ldg4(rX, ok ? qpre[i] + qbase : PRE_BAD);
+            }
+        } else
 #if defined(LAB) && (LAB == 1 || LAB == 3)
 #pragma unroll
         for (int i = 0; i < NXE; ++i) rx[i] = (float)i;
@@ -366,6 +421,10 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
     auto store_x = [&](int i, float* Xd) { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; };
     auto store_y = [&](int i, float* Yd) { *(f32x4*)&Yd[yl[i]] = ry4[i]; };
     auto store_tile = [&](float* Xd, float* Yd) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int i = 0; i < NXQ; ++i) if (ql[i] >= 0) *(f32x4*)&Xd[ql[i]] = rxq[i];
+        } else
 #pragma unroll
         for (int i = 0; i < NXE; ++i) store_x(i, Xd);
 #pragma unroll
@@ -387,7 +446,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
         const int n = n0 + (wn * TN + t) * 32 + (lane & 31);
         const int ci = n / KHW, tap = n - ci * KHW;
         const int kh = tap / KW, kw = tap - kh * KW;
-        bbase[t] = n < p.N ? (ci - ci_first) * CPLW + kh * WWP + kw + h * S : 0;
+        bbase[t] = n < p.N ? (ci - ci_first) * CPLW + kh * WWP + kw + COL0 + h * S : 0;
     }
 
     if (t_beg < t_end) {
@@ -546,13 +605,22 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     // 96-wide tiles double-buffer their LDS images (2 x 36 KB, two blocks per CU still fit in 160 KB); the 128-wide
     // ones (2 x 46 KB would leave one block per CU) keep the single buffer
     constexpr bool DB1 = false;     // single LDS buffer + the issue-order template; DB = true keeps the double-buffered loop
-    if (p.Cw == 32) {
-        if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK, 32, DB1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK, 32, false>), grid, dim3(256), 0, st, p);
-    } else {
-        if (m96) hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 1, 4, 3, 1, CK, 16, DB1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, 2, 2, 2, 2, CK, 16, false>), grid, dim3(256), 0, st, p);
+    const bool wide = S == 1 && p.up == 0 && (p.W % 4) == 0 && (((uintptr_t)p.X) & 15) == 0;
+#define MOGAN_FW(WMv, WNv, TMv, TNv, CWv, DBv, WIDEv) \
+    hipLaunchKernelGGL((dconv_fwd_kernel<KH, KW, S, WMv, WNv, TMv, TNv, CK, CWv, DBv, WIDEv>), grid, dim3(256), 0, st, p)
+    bool done = false;
+    if constexpr (S == 1) {
+        if (wide) {
+            if (p.Cw == 32) { if (m96) MOGAN_FW(1, 4, 3, 1, 32, DB1, true); else MOGAN_FW(2, 2, 2, 2, 32, false, true); }
+            else { if (m96) MOGAN_FW(1, 4, 3, 1, 16, DB1, true); else MOGAN_FW(2, 2, 2, 2, 16, false, true); }
+            done = true;
+        }
     }
+    if (!done) {
+        if (p.Cw == 32) { if (m96) MOGAN_FW(1, 4, 3, 1, 32, DB1, false); else MOGAN_FW(2, 2, 2, 2, 32, false, false); }
+        else { if (m96) MOGAN_FW(1, 4, 3, 1, 16, DB1, false); else MOGAN_FW(2, 2, 2, 2, 16, false, false); }
+    }
+#undef MOGAN_FW
     if (p.nsplit > 1)
         hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(y_numel, 256)), dim3(256), 0, st,
                            (const float*)ws, p.Y, y_numel, y_numel, p.nsplit, p.accumulate);
@@ -581,13 +649,22 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     // (the sched_barriers stop the compiler from running the LDS operand reads ahead of the MFMAs) and 87 = no gain
     // without the pinning; the lab variant without global loads runs at 113, so the loads, not the barriers, cost
     constexpr bool DBW = false;
-    if (cw == 32) {
-        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 1, 4, 3, 1, DBW>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 32, 2, 2, 2, 2, false>), grid, dim3(256), 0, st, p);
-    } else {
-        if (m96) hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 1, 4, 3, 1, DBW>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, 16, 2, 2, 2, 2, false>), grid, dim3(256), 0, st, p);
+    // 16-byte halo loads for the plain 3x3 s1 p1 convolutions (the ResBlock / D 3x3 layers)
+    const bool wide = S == 1 && KH == 3 && p.up == 0 && p.pl == 1 && p.pt == 1 && (p.W % 4) == 0 &&
+                      (((uintptr_t)p.X) & 15) == 0;
+#define MOGAN_WG(CWv, WMv, WNv, TMv, TNv, DBv, WIDEv) \
+    hipLaunchKernelGGL((dconv_wgrad_kernel<KH, KW, S, CWv, WMv, WNv, TMv, TNv, DBv, WIDEv>), grid, dim3(256), 0, st, p)
+    if constexpr (S == 1 && KH == 3) {
+        if (wide) {
+            if (cw == 32) { if (m96) MOGAN_WG(32, 1, 4, 3, 1, false, true); else MOGAN_WG(32, 2, 2, 2, 2, false, true); }
+            else { if (m96) MOGAN_WG(16, 1, 4, 3, 1, false, true); else MOGAN_WG(16, 2, 2, 2, 2, false, true); }
+        }
     }
+    if (!(S == 1 && KH == 3 && wide)) {
+        if (cw == 32) { if (m96) MOGAN_WG(32, 1, 4, 3, 1, DBW, false); else MOGAN_WG(32, 2, 2, 2, 2, false, false); }
+        else { if (m96) MOGAN_WG(16, 1, 4, 3, 1, DBW, false); else MOGAN_WG(16, 2, 2, 2, 2, false, false); }
+    }
+#undef MOGAN_WG
     if (p.nsplit > 1)
         hipLaunchKernelGGL(dconv_reduce_kernel, dim3((unsigned)cdiv(w_numel, 256)), dim3(256), 0, st,
                            (const float*)ws, p.dW, w_numel, w_numel, p.nsplit, p.accumulate);

@@ -280,12 +280,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = bool(os.environ.get("MOGAN_FORCE_DIST")) and "RANK" in os.environ
+    if os.environ.get("MOGAN_ONE_GPU"):                 # control-flow test of the N>1 path on a 1-GPU box (with gloo)
+        local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)                       # before the process group: RCCL binds to the current device
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("MOGAN_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     set_coco_train_defaults()
@@ -344,8 +347,14 @@ def main():
                        1 + (len(engine.side) if engine.multi_stream else 0))},
         "losses": {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.dim() == 0},
     }
-    if rank == 0 and not args.no_roofline:
+    rows = None
+    if not args.no_roofline:
+        # EVERY rank runs these extra steps (they contain the gradient all-reduces: a rank-0-only leg would leave
+        # the collectives unmatched and hang for N>1); rank 0 reports
         rows, eager_ms = roofline_leg(engine, run_step)
+        if world > 1:
+            dist.barrier()
+    if rank == 0 and rows is not None:
         fams = {}
         for r in rows:                                   # kernel families = the three MFMA kernels of csrc/
             f = r["kernel"].split("<")[0]

@@ -91,3 +91,23 @@ def test_sampling_from_a_checkpoint(tmp_path):
     assert len(written) == 4 and all(os.path.isfile(p) for p in written)
     im = np.asarray(Image.open(written[0]))
     assert im.shape == (256, 256, 3) and im.dtype == np.uint8 and im.std() > 0
+
+
+def test_bench_two_ranks_control_flow():
+    """bench.py launched as the driver launches it for N>1 (torch.distributed.run, 2 ranks) -- on this 1-GPU box both
+    ranks share cuda:0 and the process group is gloo (MOGAN_ONE_GPU / MOGAN_DIST_BACKEND), which exercises everything
+    but RCCL itself: matched collectives on every rank in the warm-up, the timed steps AND the roofline leg, the MAX
+    over ranks, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MOGAN_ONE_GPU="1", MOGAN_DIST_BACKEND="gloo", MOGAN_FAST_INIT="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["scaling"] == "weak"
+    assert "roofline" in d and "cpu_baseline" not in d and d["value"] > 0

@@ -657,6 +657,10 @@ int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, in
 int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                      int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    if (g_force_cfg < 0) {          // <= 4 output channels: HBM streaming work, direct VALU kernel
+        rc = mogan_smallc_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(4, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
         rc = mogan_dconv_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
@@ -672,6 +676,10 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
 int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    if (g_force_cfg < 0) {          // <= 4 channels on one side (image heads, first D convolution)
+        rc = mogan_smallc_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(5, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
         rc = mogan_dconv_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);

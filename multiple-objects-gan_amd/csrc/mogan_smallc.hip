@@ -1,0 +1,226 @@
+// mogan_smallc.hip -- direct (VALU) convolution kernels for the layers with <= 4 channels on one side: the image heads
+// of the generators (conv3x3 ngf -> 3, model.py:464-475 / S/model.py:196-198) and the first convolution of every
+// discriminator (conv4x4 s2 3 -> ndf).  On the MFMA kernels these pad 3 channels to a 32-row tile (5-6 TFLOP/s, 0.2-0.5 ms
+// each at 256x256) although they are pure HBM streaming work (200 MB read or written, ~50 us); three of them sit on the
+// critical path of the step (end of the G forward, start of the G backward).
+//
+//   sc_fwd3x3      y (B,COUT<=4,H,W)  = conv3x3 p1 (x (B,Cin,H,W), w)            one thread = one output pixel
+//   sc_dgrad3x3    dx (B,Cin,H,W)     = conv3x3^T (dy (B,COUT<=4,H,W), w)        one thread = one pixel, loops over Cin
+//   sc_dgrad_k4s2  dx (B,CIN<=4,H,W)  = conv4x4s2p1^T (dy (B,Cout,H/2,W/2), w)   one thread = a 2x2 block of input pixels
+// The few-channel operand is staged through LDS with its halo; the weights are read with block-uniform indices, i.e.
+// as scalar loads.  fp32 FMA order: ci (or co) outer, taps inner -- sums of <= 27*Cin terms.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mogan_hip.h"
+#include "mogan_internal.h"
+
+namespace {
+
+constexpr int TR = 8, TC = 32;       // thread tile: 8 rows x 32 columns = 256 threads
+
+template <int COUT>
+__global__ __launch_bounds__(256) void sc_fwd3x3(const float* __restrict__ x, const float* __restrict__ w,
+                                                 float* __restrict__ y, int Cin, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int CK = 8, HH = TR + 2, WW = TC + 2, WP = WW + 1;
+    __shared__ float Xs[CK][HH][WP];
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
+    const int oy = ty * TR + ly, ox = tx * TC + lx;
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * Cin * plane;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        for (int e = tid; e < CK * HH * WW; e += 256) {
+            const int c = e / (HH * WW), r = e - c * (HH * WW);
+            const int hy = r / WW, hx = r - hy * WW;
+            const int iy = ty * TR - 1 + hy, ix = tx * TC - 1 + hx;
+            const bool ok = c0 + c < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            Xs[c][hy][hx] = ok ? xb[(size_t)(c0 + c) * plane + (size_t)iy * W + ix] : 0.f;
+        }
+        __syncthreads();
+        const int nc = min(CK, Cin - c0);
+        for (int c = 0; c < nc; ++c) {
+            const float* wc = w + (size_t)(c0 + c) * 9;            // + co * Cin * 9: block-uniform -> scalar loads
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float v = Xs[c][ly + kh][lx + kw];
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v, wc[(size_t)co * Cin * 9 + kh * 3 + kw], acc[co]);
+                }
+        }
+        __syncthreads();
+    }
+    if (oy < H && ox < W) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) y[((size_t)b * COUT + co) * plane + (size_t)oy * W + ox] = acc[co];
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void sc_dgrad3x3(const float* __restrict__ dy, const float* __restrict__ w,
+                                                   float* __restrict__ dx, int Cin, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int HH = TR + 2, WW = TC + 2, WP = WW + 1;
+    __shared__ float Ys[COUT][HH][WP];
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
+    const int iy = ty * TR + ly, ix = tx * TC + lx;
+    const size_t plane = (size_t)H * W;
+    for (int e = tid; e < COUT * HH * WW; e += 256) {
+        const int c = e / (HH * WW), r = e - c * (HH * WW);
+        const int hy = r / WW, hx = r - hy * WW;
+        const int oy = ty * TR - 1 + hy, ox = tx * TC - 1 + hx;
+        const bool ok = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+        Ys[c][hy][hx] = ok ? dy[((size_t)b * COUT + c) * plane + (size_t)oy * W + ox] : 0.f;
+    }
+    __syncthreads();
+    // dx[iy][ix] = sum_co sum_{kh,kw} dy[iy+1-kh][ix+1-kw] * w[co][ci][kh][kw];  LDS position of dy[iy+1-kh] is ly+2-kh
+    float r[COUT][9];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) r[co][kh * 3 + kw] = Ys[co][ly + 2 - kh][lx + 2 - kw];
+    const bool inside = iy < H && ix < W;
+    float* out = dx + (size_t)b * Cin * plane + (size_t)iy * W + ix;
+    for (int ci = 0; ci < Cin; ++ci) {
+        float s = 0.f;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float* wc = w + ((size_t)co * Cin + ci) * 9;     // block-uniform -> scalar loads
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s = fmaf(r[co][k], wc[k], s);
+        }
+        if (inside) out[(size_t)ci * plane] = s;
+    }
+}
+
+// one thread = the 2x2 block of input pixels (2Y..2Y+1, 2X..2X+1); it needs dy rows Y-1..Y+1, cols X-1..X+1 of every co:
+//   iy = 2Y   (even): kh = 1 -> oy = Y,   kh = 3 -> oy = Y-1        iy = 2Y+1 (odd): kh = 0 -> oy = Y+1, kh = 2 -> oy = Y
+template <int CIN>
+__global__ __launch_bounds__(256) void sc_dgrad_k4s2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                     float* __restrict__ dx, int Cout, int H, int W, int OH, int OW,
+                                                     int tiles_x, int tiles_y) {
+    constexpr int CK = 8, HH = TR + 2, WW = TC + 2, WP = WW + 1;
+    __shared__ float Ys[CK][HH][WP];
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
+    const int Y = ty * TR + ly, X = tx * TC + lx;                  // coordinates on the dy grid
+    const size_t oplane = (size_t)OH * OW;
+    float acc[CIN][2][2];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) acc[ci][0][0] = acc[ci][0][1] = acc[ci][1][0] = acc[ci][1][1] = 0.f;
+    for (int c0 = 0; c0 < Cout; c0 += CK) {
+        for (int e = tid; e < CK * HH * WW; e += 256) {
+            const int c = e / (HH * WW), r = e - c * (HH * WW);
+            const int hy = r / WW, hx = r - hy * WW;
+            const int oy = ty * TR - 1 + hy, ox = tx * TC - 1 + hx;
+            const bool ok = c0 + c < Cout && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+            Ys[c][hy][hx] = ok ? dy[((size_t)b * Cout + c0 + c) * oplane + (size_t)oy * OW + ox] : 0.f;
+        }
+        __syncthreads();
+        const int nc = min(CK, Cout - c0);
+        for (int c = 0; c < nc; ++c) {
+            float d[3][3];                                          // d[a][bb] = dy[Y-1+a][X-1+bb]
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) d[a][bb] = Ys[c][ly + a][lx + bb];
+            const float* wc = w + (size_t)(c0 + c) * CIN * 16;       // block-uniform -> scalar loads
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float* k = wc + ci * 16;
+                // rows: py = 0 (iy even): (kh=1, oy=Y -> a=1), (kh=3, oy=Y-1 -> a=0);  py = 1: (kh=0, a=2), (kh=2, a=1)
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const int kh0 = py ? 0 : 1, a0 = py ? 2 : 1, kh1 = py ? 2 : 3, a1 = py ? 1 : 0;
+                        const int kw0 = px ? 0 : 1, b0 = px ? 2 : 1, kw1 = px ? 2 : 3, b1 = px ? 1 : 0;
+                        float s = acc[ci][py][px];
+                        s = fmaf(d[a0][b0], k[kh0 * 4 + kw0], s);
+                        s = fmaf(d[a0][b1], k[kh0 * 4 + kw1], s);
+                        s = fmaf(d[a1][b0], k[kh1 * 4 + kw0], s);
+                        s = fmaf(d[a1][b1], k[kh1 * 4 + kw1], s);
+                        acc[ci][py][px] = s;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    const size_t plane = (size_t)H * W;
+    if (Y < OH && X < OW) {
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                float* o = dx + ((size_t)b * CIN + ci) * plane + (size_t)(2 * Y + py) * W + 2 * X;
+                *(float2*)o = make_float2(acc[ci][py][0], acc[ci][py][1]);
+            }
+    }
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+// ---- internal entry points (hidden visibility): 1 = handled, 0 = not eligible ------------------------------------
+int mogan_smallc_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                         int stride, int ph, int pw, int up, hipStream_t st) {
+    if (!(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0 && Cout >= 1 && Cout <= 4)) return 0;
+    const int tiles_x = cdiv(Ws, TC), tiles_y = cdiv(Hs, TR);
+    const long long nb = (long long)B * tiles_x * tiles_y;
+    if (nb > 0x7fffffffLL) return 0;
+    dim3 grid((unsigned)nb);
+    switch (Cout) {
+        case 1: hipLaunchKernelGGL(sc_fwd3x3<1>, grid, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, tiles_x, tiles_y); break;
+        case 2: hipLaunchKernelGGL(sc_fwd3x3<2>, grid, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, tiles_x, tiles_y); break;
+        case 3: hipLaunchKernelGGL(sc_fwd3x3<3>, grid, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL(sc_fwd3x3<4>, grid, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, tiles_x, tiles_y); break;
+    }
+    return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+}
+
+int mogan_smallc_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                           int KW, int stride, int ph, int pw, int up, hipStream_t st) {
+    if (up != 0 || ph != 1 || pw != 1) return 0;
+    if (KH == 3 && KW == 3 && stride == 1 && Cout >= 1 && Cout <= 4) {
+        const int tiles_x = cdiv(Ws, TC), tiles_y = cdiv(Hs, TR);
+        const long long nb = (long long)B * tiles_x * tiles_y;
+        if (nb > 0x7fffffffLL) return 0;
+        dim3 grid((unsigned)nb);
+        switch (Cout) {
+            case 1: hipLaunchKernelGGL(sc_dgrad3x3<1>, grid, dim3(256), 0, st, dy, w, dx, Cin, Hs, Ws, tiles_x, tiles_y); break;
+            case 2: hipLaunchKernelGGL(sc_dgrad3x3<2>, grid, dim3(256), 0, st, dy, w, dx, Cin, Hs, Ws, tiles_x, tiles_y); break;
+            case 3: hipLaunchKernelGGL(sc_dgrad3x3<3>, grid, dim3(256), 0, st, dy, w, dx, Cin, Hs, Ws, tiles_x, tiles_y); break;
+            default: hipLaunchKernelGGL(sc_dgrad3x3<4>, grid, dim3(256), 0, st, dy, w, dx, Cin, Hs, Ws, tiles_x, tiles_y); break;
+        }
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+    }
+    if (KH == 4 && KW == 4 && stride == 2 && Cin >= 1 && Cin <= 4 && (Hs % 2) == 0 && (Ws % 2) == 0 &&
+        (((uintptr_t)dx) & 7) == 0) {
+        const int OH = Hs / 2, OW = Ws / 2;
+        const int tiles_x = cdiv(OW, TC), tiles_y = cdiv(OH, TR);
+        const long long nb = (long long)B * tiles_x * tiles_y;
+        if (nb > 0x7fffffffLL) return 0;
+        dim3 grid((unsigned)nb);
+        switch (Cin) {
+            case 1: hipLaunchKernelGGL(sc_dgrad_k4s2<1>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+            case 2: hipLaunchKernelGGL(sc_dgrad_k4s2<2>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+            case 3: hipLaunchKernelGGL(sc_dgrad_k4s2<3>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+            default: hipLaunchKernelGGL(sc_dgrad_k4s2<4>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+        }
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+    }
+    return 0;
+}

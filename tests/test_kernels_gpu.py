@@ -48,6 +48,10 @@ CONV_CASES = [
     (4, 20, 5, 1, 6, (1, 1), 1, (0, 0), 0),        # conv_context (1x1 on (B,cdf,T,1))
     (2, 3, 32, 32, 96, (4, 4), 2, (1, 1), 0),      # first D conv (Cin=3)
     (2, 48, 16, 16, 3, (3, 3), 1, (1, 1), 0),      # img head (Cout=3)
+    (3, 13, 37, 70, 3, (3, 3), 1, (1, 1), 0),      # img head, ragged sizes (direct small-channel kernels)
+    (2, 20, 64, 64, 1, (3, 3), 1, (1, 1), 0),      # multi-mnist img head (Cout=1)
+    (2, 3, 64, 96, 40, (4, 4), 2, (1, 1), 0),      # first D conv, non-square (dgrad = 2x2-block kernel)
+    (2, 1, 32, 32, 24, (4, 4), 2, (1, 1), 0),      # multi-mnist first D conv (Cin=1)
     (2, 10, 17, 17, 12, (1, 7), 1, (0, 3), 0),     # Inception 1x7
     (2, 10, 17, 17, 12, (7, 1), 1, (3, 0), 0),     # Inception 7x1
     (2, 6, 35, 35, 8, (3, 3), 2, (0, 0), 0),       # Inception 3x3 s2 valid (odd size)

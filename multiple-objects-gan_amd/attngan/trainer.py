@@ -118,6 +118,8 @@ class TrainEngine:
         # independent branches of the step (the three D updates; in the G step the three D forwards and the
         # Inception/DAMSM branch) run on side streams so that their many small launches overlap; captured, they
         # become parallel branches of the hipGraph.  MOGAN_STREAMS=0 keeps everything on one stream.
+        self.graph_encoder = os.environ.get("MOGAN_GRAPH_ENCODER", "1") != "0" and not use_graph
+        self._enc_graphs = {}
         self.multi_stream = os.environ.get("MOGAN_STREAMS", "1") != "0"
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
         # stream creation order fixes the stream -> hardware-queue map (see ops.precreate_wgrad_stream): branch streams,
@@ -142,6 +144,23 @@ class TrainEngine:
         if pending is not None:
             torch.cuda.current_stream().wait_event(pending)
         flat.step(grad_scale=1.0 / self.world)
+
+    def _encoder(self, fake_img):
+        """The frozen, eval-mode image encoder as a replayed hipGraph pair (forward / data gradient).  Inception-v3 is
+        ~600 short launches per direction whose host cost (17 ms forward, alone) exceeds their GPU time (5 ms): the
+        branch was host-bound and on the critical path of the step.  It has no state to update (eval BN, no weight
+        gradients), its shapes are static and it lives on one stream, so torch.cuda.make_graphed_callables applies."""
+        enc = self.image_encoder
+        if not self.graph_encoder or not isinstance(enc, torch.nn.Module) or enc.training \
+                or any(p.requires_grad for p in enc.parameters()):
+            return enc
+        key = tuple(fake_img.shape)
+        g = self._enc_graphs.get(key)
+        if g is None:
+            sample = torch.zeros(key, dtype=torch.float32, device=fake_img.device, requires_grad=True)
+            g = torch.cuda.make_graphed_callables(self.image_encoder, (sample,))
+            self._enc_graphs[key] = g
+        return g
 
     def _d_real(self, i, b):
         """zero_grad + D_i(real): independent of the generator, so it can run beside the G forward."""
@@ -240,7 +259,7 @@ class TrainEngine:
             s.wait_stream(cur)
             with torch.cuda.stream(s):
                 parts["w_loss"], parts["s_loss"] = generator_damsm_branch(
-                    self.image_encoder, fake_imgs[nD - 1], b["words_embs"], b["sent_emb"], match_labels, b["cap_lens"],
+                    self._encoder(fake_imgs[nD - 1]), fake_imgs[nD - 1], b["words_embs"], b["sent_emb"], match_labels, b["cap_lens"],
                     b.get("class_ids"), B)
             for i in order[1:]:
                 d_head(i)

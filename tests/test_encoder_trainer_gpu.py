@@ -111,3 +111,31 @@ def test_bench_two_ranks_control_flow():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["scaling"] == "weak"
     assert "roofline" in d and "cpu_baseline" not in d and d["value"] > 0
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+def test_graphed_encoder_matches_eager(parallel, monkeypatch):
+    """The train engine replays the frozen encoder as a hipGraph pair (optionally with the Mixed-block branches captured
+    on parallel streams, inception._parallel): same kernels, so outputs and the image gradient must be identical to
+    the eager, single-stream evaluation."""
+    from mogan_amd.attngan import inception
+    from mogan_amd.attngan.model import CNN_ENCODER
+    monkeypatch.setattr(inception, "PARALLEL_BRANCHES", parallel)
+    cfg.TRAIN.FLAG = True
+    torch.manual_seed(3)
+    enc = CNN_ENCODER(32).to("cuda").eval()
+    for p in enc.parameters():
+        p.requires_grad = False
+    x = (torch.rand(2, 3, 256, 256, device="cuda") * 2 - 1)
+    gf, gc = torch.randn(2, 32, 17, 17, device="cuda"), torch.randn(2, 32, device="cuda")
+    xe = x.clone().requires_grad_(True)
+    f, c = enc(xe)
+    torch.autograd.backward((f, c), (gf, gc))
+    graphed = torch.cuda.make_graphed_callables(enc, (torch.zeros_like(x).requires_grad_(True),))
+    for _ in range(2):                                   # replay twice: static buffers are reused
+        xg = x.clone().requires_grad_(True)
+        f2, c2 = graphed(xg)
+        torch.autograd.backward((f2, c2), (gf, gc))
+        torch.cuda.synchronize()
+        assert torch.equal(f2, f) and torch.equal(c2, c)
+        assert torch.allclose(xg.grad, xe.grad, rtol=0, atol=0) or float((xg.grad - xe.grad).abs().max()) < 1e-6 * float(xe.grad.abs().max())

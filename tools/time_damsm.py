@@ -33,3 +33,6 @@ for _ in range(3): run()
 r = [run() for _ in range(5)]
 m = [sum(x[i] for x in r) / len(r) for i in range(4)]
 print("inception fwd %.2f ms | DAMSM losses fwd %.2f | DAMSM losses bwd %.2f | inception bwd (dgrad to image) %.2f | total %.2f" % (m[0], m[1], m[2], m[3], sum(m)))
+if os.environ.get("LAYERS"):
+    lib.call("mogan_prof_enable", 1); run(); torch.cuda.synchronize()
+    lib.call("mogan_prof_dump", os.path.join(ROOT, "gpurun_out", "layers_inc.csv").encode()); lib.call("mogan_prof_enable", 0)

@@ -66,6 +66,14 @@ int mogan_prof_dump(const char* path);
 int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, int pw, int up, int* OH, int* OW);
 int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                      int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
+/* conv (no upsample) with y = relu?(scale[co]*conv + shift[co]) applied in the kernel epilogue: BasicConv2d of the frozen,
+ * eval-mode Inception trunk (conv -> BN on running statistics -> ReLU; model.py:258-299) in one pass over the output */
+int mogan_conv2d_affine_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,
+                            int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int relu,
+                            void* ws, size_t ws_bytes, hipStream_t stream);
+/* its backward up to the conv: dx = dy * scale[c] * (y > 0), from the saved OUTPUT y (B,C,HW) */
+int mogan_affine_relu_bwd_out(const float* y, const float* dy, const float* scale, float* dx, int B, int C, int HW,
+                              hipStream_t stream);
 /* dx: gradient w.r.t. the conv input in the H x W domain, (B,Cin,H,W); for up=1 follow with mogan_down2_sum */
 int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -37,11 +37,10 @@ class BasicConv2d(nn.Module):
         return self._folded
 
     def forward(self, x):
-        y = self.conv(x)
         if self.training:
-            return self.bn.fused(y, ops.ACT_RELU)
-        scale, shift = self.folded()
-        return ops.affine_act(y, scale, shift, ops.ACT_RELU)
+            return self.bn.fused(self.conv(x), ops.ACT_RELU)
+        scale, shift = self.folded()             # eval: BN folded; affine + ReLU ride in the conv epilogue
+        return ops.conv2d_affine_relu(x, self.conv.weight, scale, shift, self.conv.stride[0], self.conv.padding)
 
 
 _BRANCH_STREAMS = []

@@ -62,6 +62,8 @@ struct GemmP {
     long long slab;         // elements per split slab (workspace) when nsplit > 1
     float* ws;
     int accumulate;         // direct (nsplit==1) store adds to C
+    // optional fused epilogue of CONV_FWD (frozen eval-mode BN + ReLU of the Inception trunk): y = act(scale[m]*y + shift[m])
+    const float* ep_scale; const float* ep_shift; int ep_relu;
     // conv geometry: H,W = conv-input dims (after the optional fused upsample), Hs,Ws = stored dims
     int Bn, Cin, Cout, H, W, Hs, Ws, OH, OW, KH, KW, s, ph, pw, up;
     FastDiv fd_ohw, fd_ow, fd_khw, fd_kw, fd_nk, fd_nkw;
@@ -421,6 +423,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                     float* dst = Cg + cbase + (size_t)m * cms;
                     float v = acc[ta][tb][r];
                     if (addc) v += *dst;
+                    if constexpr (MODE == CONV_FWD) {
+                        if (p.ep_scale != nullptr && p.nsplit == 1) {
+                            v = fmaf(v, p.ep_scale[m], p.ep_shift[m]);
+                            if (p.ep_relu) v = fmaxf(v, 0.f);
+                        }
+                    }
                     *dst = v;
                 }
             }
@@ -431,7 +439,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 // out[i] = (acc ? out[i] : 0) + sum_s ws[s*slab + i]: fixed summation order (deterministic).  One element per
 // thread (small outputs still give hundreds of blocks), 8 independent slab loads in flight per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                            long long n, long long slab, int nsplit, int acc) {
+                                                            long long n, long long slab, int nsplit, int acc,
+                                                            const float* __restrict__ ep_scale,
+                                                            const float* __restrict__ ep_shift, int ep_relu, int ohw,
+                                                            int M) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float* p = ws + i;
@@ -445,6 +456,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; k < nsplit; ++k) s += p[(size_t)k * slab];
+    if (ep_scale != nullptr) {                       // conv output (B, M, ohw): channel of element i
+        const int m = (int)((i / ohw) % M);
+        s = fmaf(s, ep_scale[m], ep_shift[m]);
+        if (ep_relu) s = fmaxf(s, 0.f);
+    }
     out[i] = s;
 }
 
@@ -564,7 +580,8 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     if (p.nsplit > 1) {
         const long long nblk = cdiv(c_numel, 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)ws, p.C,
-                           c_numel, c_numel, p.nsplit, p.accumulate);
+                           c_numel, c_numel, p.nsplit, p.accumulate, mode == CONV_FWD ? p.ep_scale : nullptr, p.ep_shift,
+                           p.ep_relu, p.OH * p.OW, p.M);
     }
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
@@ -670,6 +687,20 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
+}
+
+// conv + per-channel affine (+ ReLU) in the epilogue of the implicit-GEMM kernel (or of its split-K reduction): the
+// BasicConv2d of the frozen Inception trunk = conv, eval-mode BN, ReLU (model.py:258-299) in one pass over the output
+int mogan_conv2d_affine_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,
+                            int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int relu,
+                            void* ws, size_t ws_bytes, hipStream_t stream) {
+    GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0); if (rc) return rc;
+    if (!scale || !shift) return MOGAN_ERR_SHAPE;
+    p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
+    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
+    p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    p.ep_scale = scale; p.ep_shift = shift; p.ep_relu = relu;
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
 }
 

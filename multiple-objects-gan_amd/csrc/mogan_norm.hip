@@ -17,6 +17,16 @@
 
 namespace {
 
+__global__ __launch_bounds__(256) void affine_relu_bwd_out_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                  const float* __restrict__ scale, float* __restrict__ dx,
+                                                                  long long n, int C, int HW) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)((i / HW) % C);
+    dx[i] = y[i] > 0.f ? dy[i] * scale[c] : 0.f;
+}
+
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -433,6 +443,16 @@ int mogan_affine_act_fwd(const float* x, const float* scale, const float* shift,
 int mogan_affine_act_bwd(const float* x, const float* dy, const float* scale, const float* shift, float* dx, int B,
                          int C, int HW, int act, float slope, hipStream_t stream) {
     return affine_impl<true>(x, dy, scale, shift, dx, B, C, HW, act, slope, stream);
+}
+
+// backward of y = relu(scale*conv + shift) given the OUTPUT y: dx = dy * scale[c] * (y > 0)
+int mogan_affine_relu_bwd_out(const float* y, const float* dy, const float* scale, float* dx, int B, int C, int HW,
+                              hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)B * C * HW;
+    hipLaunchKernelGGL(affine_relu_bwd_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, y, dy, scale, dx,
+                       n, C, HW);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 
 }  // extern "C"

@@ -25,6 +25,8 @@ SIGNATURES = {
     "mogan_prof_dump": [ctypes.c_char_p],
     "mogan_conv2d_out_dims": [I, I, I, I, I, I, I, I, P, P],
     "mogan_conv2d_fwd": [P, P, P] + [I] * 11 + [P, Z, P],
+    "mogan_conv2d_affine_fwd": [P, P, P, P, P] + [I] * 11 + [P, Z, P],
+    "mogan_affine_relu_bwd_out": [P, P, P, P, I, I, I, P],
     "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_wgrad": [P, P, P] + [I] * 12 + [P, Z, P],
     "mogan_upconv3x3_ws_bytes": [I, I],

@@ -197,6 +197,43 @@ class Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class ConvAffineReluFn(torch.autograd.Function):
+    """z = relu(scale[c] * conv2d(x, w) + shift[c]) in one launch (the affine + ReLU ride in the conv epilogue or in its
+    split-K reduction): BasicConv2d of the frozen eval-mode Inception trunk (model.py:258-299).  Saves x, w and the
+    OUTPUT z; backward: g = dz * scale * (z > 0), then the ordinary data / weight gradients of the conv."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, stride, ph, pw):
+        x, w = _c(x), _c(w)
+        B, Cin, Hs, Ws = x.shape
+        Cout, _, KH, KW = w.shape
+        OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, 0)
+        z = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        wsp, wsn = workspace(x.device)
+        call("mogan_conv2d_affine_fwd", ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(z), B, Cin, Hs, Ws, Cout, KH, KW,
+             stride, ph, pw, 1, wsp, wsn, stream_ptr())
+        ctx.save_for_backward(x, w, z, scale)
+        ctx.geom = (stride, ph, pw)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, z, scale = ctx.saved_tensors
+        stride, ph, pw = ctx.geom
+        dz = _c(dz)
+        g = torch.empty_like(z)
+        call("mogan_affine_relu_bwd_out", ptr(z), ptr(dz), ptr(scale), ptr(g), z.shape[0], z.shape[1],
+             z.shape[2] * z.shape[3], stream_ptr())
+        dx = conv2d_dgrad(g, w, x.shape, stride, ph, pw, 0) if ctx.needs_input_grad[0] else None
+        dw = conv2d_wgrad(g, x, w.shape, stride, ph, pw, 0) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None, None, None
+
+
+def conv2d_affine_relu(x, w, scale, shift, stride=1, padding=0):
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    return ConvAffineReluFn.apply(x, w, scale, shift, int(stride), int(ph), int(pw))
+
+
 def conv2d(x, w, bias=None, stride=1, padding=0, up=False):
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
     return Conv2dFn.apply(x, w, bias, int(stride), int(ph), int(pw), 1 if up else 0)

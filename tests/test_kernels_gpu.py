@@ -125,6 +125,26 @@ def test_upsample_conv3x3_both_formulations(case, as_k4, monkeypatch):
     _check(acc, 2 * w.grad, what="wgrad accumulate")
 
 
+@pytest.mark.parametrize("case", [(2, 10, 17, 17, 12, (1, 7), 1, (0, 3)), (2, 48, 35, 35, 64, (5, 5), 1, (2, 2)),
+                                  (2, 288, 35, 35, 96, (3, 3), 2, (0, 0)), (3, 768, 8, 8, 192, (1, 1), 1, (0, 0)),
+                                  (2, 6, 9, 11, 5, (3, 3), 1, (1, 1))])
+def test_conv_affine_relu_fused(case):
+    """BasicConv2d of the frozen Inception trunk: conv + eval-BN affine + ReLU in the conv epilogue (direct store and
+    split-K reduction), backward from the saved output."""
+    B, Cin, H, W, Cout, k, s, pad = case
+    x = T("fx%s" % (case,), (B, Cin, H, W)).requires_grad_(True)
+    w = T("fw%s" % (case,), (Cout, Cin) + k, 0.2).requires_grad_(True)
+    scale, shift = T("fs%s" % (case,), (Cout,), 0.5, 1.0), T("fb%s" % (case,), (Cout,), 0.3)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), None, s, pad) * scale.double().view(1, -1, 1, 1)
+                     + shift.double().view(1, -1, 1, 1))
+    g = T("fg%s" % (case,), ref.shape)
+    ref.backward(g.double())
+    xd, wd = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    z = ops.conv2d_affine_relu(xd, wd, scale.to(DEV), shift.to(DEV), s, pad)
+    z.backward(g.to(DEV))
+    _check(z, ref, what="fwd"); _check(xd.grad, x.grad, what="dgrad"); _check(wd.grad, w.grad, what="wgrad")
+
+
 def test_conv_bias_and_wgrad_accumulate():
     x = T("cbx", (3, 12, 4, 4)).requires_grad_(True)
     w = T("cbw", (1, 12, 4, 4), 0.2).requires_grad_(True)

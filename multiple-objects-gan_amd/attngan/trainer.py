@@ -368,6 +368,10 @@ class TrainEngine:
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
+                # the generator's weight gradients may fork their side stream from the capture stream (a depth-1 fork);
+                # the D branches keep theirs in line: a fork of a fork crashes hipStreamEndCapture (ROCm 7.2)
+                ops.CAPTURE_WGRAD_OK.add(torch.cuda.current_stream().cuda_stream)
+                ops.precreate_wgrad_stream(torch.cuda.current_stream())
                 self._graph_out = self.device_step(st)
             self._restore(snap)
         st = self._static

@@ -36,6 +36,7 @@ def _grad_buf(param):
 # (the engines wrap every .backward() in it); leaving the context makes the current stream wait for the side
 # stream, so the all-reduce / Adam / anybody reading .grad afterwards is ordered behind the weight gradients.
 WGRAD_SIDE_STREAM = False
+CAPTURE_WGRAD_OK = set()     # raw handles of streams that may fork a wgrad stream while being captured (depth-1 forks only)
 _WGRAD_ENV = os.environ.get("MOGAN_WGRAD_STREAM", "1") != "0"
 _wgrad_streams = {}
 _wgrad_keep = []         # operands of in-flight side-stream launches; released after the join so the caching
@@ -47,7 +48,10 @@ def wgrad_overlap():
     global WGRAD_SIDE_STREAM
     # not under hipGraph capture: hipStreamEndCapture segfaults (ROCm 7.2) on the nested fork pattern
     # capture stream -> branch stream -> wgrad stream; captured steps keep the weight gradients in line
-    prev, WGRAD_SIDE_STREAM = WGRAD_SIDE_STREAM, _WGRAD_ENV and not torch.cuda.is_current_stream_capturing()
+    ok = _WGRAD_ENV
+    if ok and torch.cuda.is_current_stream_capturing():
+        ok = torch.cuda.current_stream().cuda_stream in CAPTURE_WGRAD_OK
+    prev, WGRAD_SIDE_STREAM = WGRAD_SIDE_STREAM, ok
     try:
         yield
     finally:

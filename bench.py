@@ -74,9 +74,12 @@ def roofline_leg(engine, run_step, steps=2):
     import ctypes
     from mogan_amd.hip import ops
     g, ms_, wg = engine.use_graph, getattr(engine, "multi_stream", False), ops._WGRAD_ENV
+    ge = getattr(engine, "graph_encoder", False)
     engine.use_graph = False
     if hasattr(engine, "multi_stream"):
         engine.multi_stream = False
+    if hasattr(engine, "graph_encoder"):
+        engine.graph_encoder = False            # a replayed graph bypasses the per-launch hooks: launch the encoder eagerly
     ops._WGRAD_ENV = False
     run_step()                                        # eager warm-up (allocator)
     torch.cuda.synchronize()
@@ -92,6 +95,8 @@ def roofline_leg(engine, run_step, steps=2):
     engine.use_graph = g
     if hasattr(engine, "multi_stream"):
         engine.multi_stream = ms_
+    if hasattr(engine, "graph_encoder"):
+        engine.graph_encoder = ge
     ops._WGRAD_ENV = wg
     rows = []
     for i in range(n):

@@ -158,7 +158,8 @@ class TrainEngine:
         g = self._enc_graphs.get(key)
         if g is None:
             sample = torch.zeros(key, dtype=torch.float32, device=fake_img.device, requires_grad=True)
-            g = torch.cuda.make_graphed_callables(self.image_encoder, (sample,))
+            # a plain function, not the module: make_graphed_callables would otherwise patch enc.forward in place
+            g = torch.cuda.make_graphed_callables(lambda x: enc(x), (sample,))
             self._enc_graphs[key] = g
         return g
 

@@ -119,6 +119,7 @@ class TrainEngine:
         # Inception/DAMSM branch) run on side streams so that their many small launches overlap; captured, they
         # become parallel branches of the hipGraph.  MOGAN_STREAMS=0 keeps everything on one stream.
         self.graph_encoder = os.environ.get("MOGAN_GRAPH_ENCODER", "1") != "0" and not use_graph
+        self.early_damsm_bwd = os.environ.get("MOGAN_EARLY_DAMSM_BWD", "1") != "0"
         self._enc_graphs = {}
         self.multi_stream = os.environ.get("MOGAN_STREAMS", "1") != "0"
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
@@ -159,6 +160,10 @@ class TrainEngine:
         if g is None:
             sample = torch.zeros(key, dtype=torch.float32, device=fake_img.device, requires_grad=True)
             # a plain function, not the module: make_graphed_callables would otherwise patch enc.forward in place
+            from ..hip import lib
+            t = os.environ.get("MOGAN_ENC_SPLIT_TARGET")
+            if t:
+                lib.call("mogan_gemm_set_split_target", int(t))
             g = torch.cuda.make_graphed_callables(lambda x: enc(x), (sample,))
             self._enc_graphs[key] = g
         return g
@@ -194,7 +199,8 @@ class TrainEngine:
         netG, netsD = self.netG, self.netsD
         B = b["z"].shape[0]
         from ..hip import lib
-        lib.call("mogan_gemm_set_split_target", 384 if self.multi_stream else 768)   # see include/mogan_hip.h
+        lib.call("mogan_gemm_set_split_target",                                      # see include/mogan_hip.h
+                 int(os.environ.get("MOGAN_SPLIT_TARGET", 384 if self.multi_stream else 768)))
         real_labels = b["z"].new_ones(B)
         fake_labels = b["z"].new_zeros(B)
         match_labels = b["match_labels"]
@@ -258,10 +264,22 @@ class TrainEngine:
             d_head(order[0])
             s = self.side[nD]
             s.wait_stream(cur)
+            damsm_grad = None
             with torch.cuda.stream(s):
-                parts["w_loss"], parts["s_loss"] = generator_damsm_branch(
-                    self._encoder(fake_imgs[nD - 1]), fake_imgs[nD - 1], b["words_embs"], b["sent_emb"], match_labels, b["cap_lens"],
+                # The DAMSM terms depend on the fake image and the frozen encoders only -- not on the Ds -- so their
+                # backward (Inception data gradient, ~6 ms of short launches) does not have to wait for errG_total:
+                # it runs here, beside the D updates, on a detached leaf; its image gradient joins the generator's
+                # backward below as a second root (d errG / d img256 = D256 path + this; two terms, same sum).
+                img = fake_imgs[nD - 1]
+                if self.early_damsm_bwd:
+                    img = img.detach().requires_grad_(True)
+                w_loss, s_loss = generator_damsm_branch(
+                    self._encoder(img), img, b["words_embs"], b["sent_emb"], match_labels, b["cap_lens"],
                     b.get("class_ids"), B)
+                if self.early_damsm_bwd:
+                    damsm_grad, = torch.autograd.grad(w_loss + s_loss, img)
+                    w_loss, s_loss = w_loss.detach(), s_loss.detach()
+                parts["w_loss"], parts["s_loss"] = w_loss, s_loss
             for i in order[1:]:
                 d_head(i)
             for i in order[::-1]:
@@ -295,7 +313,10 @@ class TrainEngine:
         kl_loss = KL_loss(mu, logvar)
         errG_total = errG_total + kl_loss
         with ops.wgrad_overlap():
-            errG_total.backward()
+            if self.multi_stream and damsm_grad is not None:
+                torch.autograd.backward([errG_total, fake_imgs[nD - 1]], [None, damsm_grad])
+            else:
+                errG_total.backward()
         for d in netsD:
             for p in d.parameters():
                 p.requires_grad_(True)

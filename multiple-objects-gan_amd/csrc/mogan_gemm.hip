@@ -729,6 +729,10 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
                        int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
                        hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
+    if (g_force_cfg < 0) {
+        rc = mogan_smallc_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(6, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, Cin * KH * KW, B * p.OH * p.OW, stream);
         rc = mogan_dconv_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);

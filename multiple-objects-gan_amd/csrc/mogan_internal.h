@@ -21,6 +21,9 @@ MOGAN_HIDDEN int mogan_smallc_fwd_try(const float* x, const float* w, float* y, 
                                       int KH, int KW, int stride, int ph, int pw, int up, hipStream_t st);
 MOGAN_HIDDEN int mogan_smallc_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws,
                                         int Cout, int KH, int KW, int stride, int ph, int pw, int up, hipStream_t st);
+MOGAN_HIDDEN int mogan_smallc_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws,
+                                        int Cout, int KH, int KW, int stride, int ph, int pw, int up, int accumulate,
+                                        void* ws, size_t ws_bytes, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_end(int taken, hipStream_t st);
 MOGAN_HIDDEN extern int mogan_use_dconv;

@@ -170,6 +170,94 @@ __global__ __launch_bounds__(256) void sc_dgrad_k4s2(const float* __restrict__ d
     }
 }
 
+
+// dW (COUT<=4,Cin,3,3) = sum over (b, y, x) of dy[b,co,y,x] * x[b,ci,y+kh-1,x+kw-1].  A block owns a band of TR rows of one
+// image and walks its TC-wide tiles; per chunk of CK input channels, thread (c, kh, r) slides along row r of the tile with a
+// 3-wide window of x[c][r+kh-1][.] (one LDS read per pixel) against the COUT dy values of the pixel (LDS broadcasts):
+// 3*COUT FMAs per 1+COUT LDS reads.  The 8 row-threads are summed in LDS, the band's partial (Cin*9*COUT values) goes to
+// the workspace and sc_wgrad_reduce adds the bands in a fixed order (deterministic, no atomics).
+template <int COUT>
+__global__ __launch_bounds__(192) void sc_wgrad3x3(const float* __restrict__ dy, const float* __restrict__ x,
+                                                   float* __restrict__ part, int Cin, int H, int W, int tiles_x,
+                                                   int tiles_y) {
+    constexpr int CK = 8, HH = TR + 2, WW = TC + 2, WP = WW + 1;
+    __shared__ float Xs[CK][HH][WP];
+    __shared__ float Ys[COUT][TR][TC + 1];
+    __shared__ float Rs[CK * 3][TR][3 * COUT + 1];
+    const int ty = blockIdx.x % tiles_y, b = blockIdx.x / tiles_y;        // blockIdx.y = chunk of CK input channels
+    const int tid = threadIdx.x;
+    const int r = tid & 7, kh = (tid >> 3) % 3, c = tid / 24;
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * Cin * plane;
+    const float* yb = dy + (size_t)b * COUT * plane;
+    float* out = part + (size_t)blockIdx.x * Cin * 9 * COUT;
+    {
+        const int c0 = blockIdx.y * CK;
+        float acc[3][COUT];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[kw][co] = 0.f;
+        for (int tx = 0; tx < tiles_x; ++tx) {
+            for (int e = tid; e < CK * HH * WW; e += 192) {
+                const int cc = e / (HH * WW), q = e - cc * (HH * WW);
+                const int hy = q / WW, hx = q - hy * WW;
+                const int iy = ty * TR - 1 + hy, ix = tx * TC - 1 + hx;
+                const bool ok = c0 + cc < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                Xs[cc][hy][hx] = ok ? xb[(size_t)(c0 + cc) * plane + (size_t)iy * W + ix] : 0.f;
+            }
+            for (int e = tid; e < COUT * TR * TC; e += 192) {
+                const int co = e / (TR * TC), q = e - co * (TR * TC);
+                const int py = q / TC, px = q - py * TC;
+                const int oy = ty * TR + py, ox = tx * TC + px;
+                Ys[co][py][px] = (oy < H && ox < W) ? yb[(size_t)co * plane + (size_t)oy * W + ox] : 0.f;
+            }
+            __syncthreads();
+            const float* xr = &Xs[c][r + kh][0];
+            float x0 = xr[0], x1 = xr[1];
+#pragma unroll 8
+            for (int px = 0; px < TC; ++px) {
+                const float x2 = xr[px + 2];
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float d = Ys[co][r][px];
+                    acc[0][co] = fmaf(d, x0, acc[0][co]);
+                    acc[1][co] = fmaf(d, x1, acc[1][co]);
+                    acc[2][co] = fmaf(d, x2, acc[2][co]);
+                }
+                x0 = x1; x1 = x2;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) Rs[c * 3 + kh][r][kw * COUT + co] = acc[kw][co];
+        __syncthreads();
+        for (int e = tid; e < CK * 3 * 3 * COUT; e += 192) {
+            const int g = e / (3 * COUT), v = e - g * (3 * COUT);          // g = cc*3 + kh, v = kw*COUT + co
+            const int cc = g / 3, k = g - cc * 3, kw = v / COUT, co = v - kw * COUT;
+            float s = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < TR; ++rr) s += Rs[g][rr][v];
+            if (c0 + cc < Cin) out[((size_t)co * Cin + c0 + cc) * 9 + k * 3 + kw] = s;
+        }
+    }
+}
+
+// dw[i] = (acc ? dw[i] : 0) + sum_blk part[blk][i]: one wave per output, lane l sums blk = l, l+64, ... in order, then a
+// fixed shuffle tree
+__global__ __launch_bounds__(256) void sc_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int n,
+                                                       int nblk, int accumulate) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * n + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) dw[i] = (accumulate ? dw[i] : 0.f) + s;
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -223,4 +311,25 @@ int mogan_smallc_dgrad_try(const float* dy, const float* w, float* dx, int B, in
         return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
     }
     return 0;
+}
+
+int mogan_smallc_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                           int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+    if (!(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0 && Cout >= 1 && Cout <= 4)) return 0;
+    const int tiles_x = cdiv(Ws, TC), tiles_y = cdiv(Hs, TR);
+    const long long nblk = (long long)B * tiles_y;
+    const int n = Cout * Cin * 9;
+    if (nblk > 65535 || !ws || ws_bytes < (size_t)nblk * n * sizeof(float)) return 0;
+    float* part = (float*)ws;
+    dim3 grid((unsigned)nblk, (unsigned)cdiv(Cin, 8));
+    switch (Cout) {
+        case 1: hipLaunchKernelGGL(sc_wgrad3x3<1>, grid, dim3(192), 0, st, dy, x, part, Cin, Hs, Ws, tiles_x, tiles_y); break;
+        case 2: hipLaunchKernelGGL(sc_wgrad3x3<2>, grid, dim3(192), 0, st, dy, x, part, Cin, Hs, Ws, tiles_x, tiles_y); break;
+        case 3: hipLaunchKernelGGL(sc_wgrad3x3<3>, grid, dim3(192), 0, st, dy, x, part, Cin, Hs, Ws, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL(sc_wgrad3x3<4>, grid, dim3(192), 0, st, dy, x, part, Cin, Hs, Ws, tiles_x, tiles_y); break;
+    }
+    hipLaunchKernelGGL(sc_wgrad_reduce, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, (const float*)part, dw, n, (int)nblk,
+                       accumulate);
+    return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }

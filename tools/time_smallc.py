@@ -16,5 +16,8 @@ for (B, Cin, H, Cout, k, s) in [(16, 48, 256, 3, 3, 1), (16, 48, 128, 3, 3, 1), 
     x = torch.randn(B, Cin, H, H, device=dev); w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
     y = ops.conv2d_forward(x, w, s, 1, 1, 0); dy = torch.randn_like(y)
     tf = t(lambda: ops.conv2d_forward(x, w, s, 1, 1, 0)); td = t(lambda: ops.conv2d_dgrad(dy, w, x.shape, s, 1, 1, 0))
+    g = torch.zeros_like(w)
+    tw = t(lambda: ops.conv2d_wgrad(dy, x, w.shape, s, 1, 1, 0, out=g, accumulate=True))
     mb = (x.numel() + y.numel()) * 4 / 1e6
-    print("B%d %d->%d %dx%d k%d s%d: fwd %.3f ms (%.0f GB/s)  dgrad %.3f ms (%.0f GB/s)" % (B, Cin, Cout, H, H, k, s, tf, mb / tf, td, mb / td))
+    print("B%d %d->%d %dx%d k%d s%d: fwd %.3f ms (%.0f GB/s)  dgrad %.3f ms (%.0f GB/s)  wgrad %.3f ms (%.0f GB/s)"
+          % (B, Cin, Cout, H, H, k, s, tf, mb / tf, td, mb / td, tw, mb / tw))

@@ -163,7 +163,7 @@ class SyntheticTextDataset(_Base):
 
     def __init__(self, length=1024, n_words=synthetic.VOCAB, seed=0):
         self.length, self.n_words, self.seed = length, n_words, seed
-        self.ixtoword = {0: '<end>'}
+        self.ixtoword = {i: ('<end>' if i == 0 else 'w%d' % i) for i in range(n_words)}
         self.imsize = [cfg.TREE.BASE_SIZE << i for i in range(cfg.TREE.BRANCH_NUM)]
 
     def __getitem__(self, index):

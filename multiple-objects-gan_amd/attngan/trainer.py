@@ -468,6 +468,7 @@ class condGANTrainer(object):
         self.data_loader = data_loader
         self.num_batches = len(self.data_loader) if data_loader is not None else 0
         self.distributed, self.use_graph = distributed, use_graph
+        self.log_images = os.environ.get("MOGAN_LOG_IMAGES", "1") != "0"
         # one process per GPU: the local device comes from LOCAL_RANK (torchrun), not from GPU_ID
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
         torch.cuda.set_device(self.device)
@@ -512,6 +513,39 @@ class condGANTrainer(object):
             while len(ckpts) > max_to_keep:
                 os.remove(ckpts[0])
                 ckpts = ckpts[1:]
+
+    def save_img_results(self, netG, noise, sent_emb, words_embs, mask, image_encoder, captions, cap_lens,
+                         gen_iterations, transf_matrices_inv, label_one_hot, name='current'):
+        """trainer.py:206-248: G_<name>_<it>_<i>.png = attention grids of the generator's two attention stages,
+        D_<name>_<it>.png = the DAMSM word-region attention on the 256x256 fake image."""
+        from PIL import Image
+        from .miscc.losses import words_loss
+        from .miscc.vis import build_super_images
+        written = []
+        with torch.no_grad():
+            fake_imgs, attention_maps, _, _ = netG(noise, sent_emb, words_embs, mask, transf_matrices_inv, label_one_hot)
+            for i in range(len(attention_maps)):
+                if len(fake_imgs) > 1:
+                    img, lr_img = fake_imgs[i + 1].detach().cpu(), fake_imgs[i].detach().cpu()
+                else:
+                    img, lr_img = fake_imgs[0].detach().cpu(), None
+                attn_maps = attention_maps[i]
+                res = build_super_images(img, captions, self.ixtoword, attn_maps, attn_maps.size(2), lr_imgs=lr_img,
+                                         batch_size=captions.size(0))
+                if res is not None:
+                    fullpath = '%s/G_%s_%d_%d.png' % (self.image_dir, name, gen_iterations, i)
+                    Image.fromarray(res[0]).save(fullpath)
+                    written.append(fullpath)
+            region_features, _ = image_encoder(fake_imgs[-1].detach())
+            _, _, att_maps = words_loss(region_features.detach(), words_embs.detach(), None, cap_lens, None,
+                                        captions.size(0))
+            res = build_super_images(fake_imgs[-1].detach().cpu(), captions, self.ixtoword, att_maps,
+                                     region_features.size(2), batch_size=captions.size(0))
+            if res is not None:
+                fullpath = '%s/D_%s_%d.png' % (self.image_dir, name, gen_iterations)
+                Image.fromarray(res[0]).save(fullpath)
+                written.append(fullpath)
+        return written
 
     def sampling(self, split_dir, num_samples=30000):
         """trainer.py:387-470: load cfg.TRAIN.NET_G (EMA generator of a checkpoint) and cfg.TRAIN.NET_E (DAMSM text
@@ -567,6 +601,7 @@ class condGANTrainer(object):
         optimizerG, optimizersD = self.define_optimizers(netG, netsD)
         nz = cfg.GAN.Z_DIM
         gen_iterations = 0
+        fixed_noise = None
         for epoch in range(start_epoch, self.max_epoch):
             start_t = time.time()
             logs = {}
@@ -576,9 +611,19 @@ class condGANTrainer(object):
                              class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot,
                              z=torch.randn(captions.shape[0], nz, device=self.device))
                 logs = self.engine.step(batch)
-                gen_iterations += 1
-                if gen_iterations % 1000 == 0:
+                if gen_iterations % 1000 == 0:        # trainer.py:335-346 (the reference never advances its counter,
+                    # so it does this every step; here: every 1000 iterations, first one included)
                     print(' '.join('%s: %.2f' % (k, float(v)) for k, v in logs.items() if v.dim() == 0))
+                    if self.log_images and captions.shape[0] >= 8 and (not self.distributed or dist.get_rank() == 0):
+                        if fixed_noise is None or fixed_noise.shape[0] != captions.shape[0]:
+                            fixed_noise = torch.randn(captions.shape[0], nz, device=self.device)
+                        w, s_, m = self.engine.encode_text(captions, batch["cap_lens_cpu"])
+                        backup_para = copy_G_params(netG)
+                        load_params(netG, optimizerG.ema_params())
+                        self.save_img_results(netG, fixed_noise, s_, w, m, image_encoder, captions, cap_lens, epoch,
+                                              tmi, label_one_hot, name='average')
+                        load_params(netG, backup_para)
+                gen_iterations += 1
             end_t = time.time()
             if logs:
                 errD_total = sum(float(logs["errD%d" % i]) for i in range(len(netsD)))

@@ -1,9 +1,10 @@
 """Train loop shared by the three StackGAN-family trees (code/coco/stackgan/trainer.py:29-306,
 code/clevr/trainer.py:29-196, code/multi-mnist/trainer.py:28-206): network construction + weights_init,
 optional checkpoint loading, halving both learning rates every LR_DECAY_EPOCH epochs, one
-StackGANEngine.step per minibatch, `save_model` snapshots.  The tensorboard scalars and image grids of the
-reference are host-side logging and are not reproduced; losses are printed per epoch
-with the reference's format string."""
+StackGANEngine.step per minibatch, `save_model` snapshots, and every 500 iterations the scalar summaries and the
+sample grids of the reference (logging_utils.py).  The grid shows the fake batch of the step
+itself (the reference runs the generator a second time on the same inputs for it); losses are printed per epoch with
+the reference's format string."""
 import glob
 import os
 import time
@@ -15,6 +16,7 @@ import torch.nn as nn
 from ..attngan.miscc.utils import mkdir_p
 from ..attngan.synthetic import bbox_to_theta, one_hot_labels
 from .engine import StackGANEngine
+from .logging_utils import ScalarWriter, save_img_results
 from .synthetic import _theta64
 
 
@@ -148,7 +150,7 @@ class GANTrainerBase(object):
         generator_lr, discriminator_lr = cfg.TRAIN.GENERATOR_LR, cfg.TRAIN.DISCRIMINATOR_LR
         lr_decay_step = cfg.TRAIN.LR_DECAY_EPOCH
         rank0 = not self.distributed or dist.get_rank() == 0
-        count, epoch, logs = 0, 0, {}
+        count, epoch, logs, writer = 0, 0, {}, None
         print("Start training...")
         for epoch in range(self.max_epoch):
             start_t = time.time()
@@ -160,6 +162,14 @@ class GANTrainerBase(object):
             for i, data in enumerate(data_loader, 0):
                 logs = engine.step(self.prepare_batch(data, stage))
                 count += 1
+                if i % 500 == 0 and rank0 and cfg.TRAIN.FLAG:          # S/trainer.py:237-260
+                    if writer is None:
+                        writer = ScalarWriter(self.log_dir)
+                    for tag, key in (('D_loss', 'errD'), ('D_loss_real', 'errD_real'), ('D_loss_wrong', 'errD_wrong'),
+                                     ('D_loss_fake', 'errD_fake'), ('G_loss', 'errG'), ('KL_loss', 'kl')):
+                        if key in logs:
+                            writer.add_scalar(tag, float(logs[key]), count)
+                    save_img_results(data[0], logs["fake"], epoch, self.image_dir, getattr(cfg, "VIS_COUNT", 64))
             end_t = time.time()
             if logs and rank0:
                 kl = ' Loss_KL: %.4f' % float(logs["kl"]) if "kl" in logs else ''
@@ -173,3 +183,5 @@ class GANTrainerBase(object):
                 save_model(netG, netD, engine.optG, engine.optD, epoch, self.model_dir)
         if rank0:
             save_model(netG, netD, engine.optG, engine.optD, epoch, self.model_dir)
+        if writer is not None:
+            writer.close()

@@ -198,6 +198,14 @@ def test_family_train_loops_and_checkpoints(tmp_path):
     sd = torch.load(ck, map_location="cpu", weights_only=False)
     assert set(sd) == {"epoch", "netG", "optimG", "netD", "optimD"} and sd["netD"] == {} and sd["epoch"] == 1
     assert all(torch.isfinite(v).all() for v in sd["netG"].values() if v.is_floating_point())
+    # S/trainer.py:237-260: scalar summaries + sample grids on iteration 0 of each epoch (i % 500 == 0)
+    import json
+    from PIL import Image
+    rows = [json.loads(l) for l in open(str(tmp_path / "clevr" / "Log" / "scalars.jsonl"))]
+    assert {r["tag"] for r in rows} == {"D_loss", "D_loss_real", "D_loss_wrong", "D_loss_fake", "G_loss"}
+    assert sorted({r["step"] for r in rows}) == [1, 3] and all(np.isfinite(r["value"]) for r in rows)
+    for f in ("real_samples.png", "fake_samples_epoch_000.png", "fake_samples_epoch_001.png"):
+        assert Image.open(str(tmp_path / "clevr" / "Image" / f)).size == (4 * 66 + 2, 66 + 2)
     _run_main("multi_mnist", common + train + "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 4}\n", tmp_path, "mnist")
     s1 = _run_main("coco", common + "STAGE: 1\nIMSIZE: 64\n" + train.replace("}", ", COEFF: {KL: 2.0}}")
                    + "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 192}\nTEXT: {DIMENSION: 16}\n", tmp_path, "s1",

@@ -38,7 +38,7 @@ from mogan_amd.hip import lib  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 MODES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bmm", "dconv_fwd", "dconv_dgrad", "dconv_wgrad")
-TILES = ("128x128", "96x128", "128x32", "32x128", "64x64")
+TILES = ("128x128", "96x128", "128x32", "32x128", "64x64", "128x64", "64x128")
 
 
 def make_device_batch(B, seed, device):
@@ -89,8 +89,11 @@ def roofline_leg(engine, run_step, steps=2):
         run_step()
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3 / steps
-    buf = (ctypes.c_double * (5 * 32))()
-    n = lib.load().mogan_prof_collect(ctypes.cast(buf, ctypes.c_void_p), 32)
+    buf = (ctypes.c_double * (5 * 64))()
+    n = lib.load().mogan_prof_collect(ctypes.cast(buf, ctypes.c_void_p), 64)
+    if os.environ.get("MOGAN_LAYERS_CSV"):          # per-launch list of one more step (input of tools/tune_gemm.py)
+        run_step(); torch.cuda.synchronize()
+        lib.call("mogan_prof_dump", os.environ["MOGAN_LAYERS_CSV"].encode())
     lib.call("mogan_prof_enable", 0)
     engine.use_graph = g
     if hasattr(engine, "multi_stream"):

@@ -47,6 +47,14 @@ int mogan_abi_version(void);
  * that has the GPU to itself; a caller that keeps several streams busy lowers it to 384: fewer slabs to reduce). */
 int mogan_gemm_set_split_target(int blocks);
 
+/* Tuned dispatch of the implicit-GEMM kernel: for the GEMM (mode 0 conv fwd / 1 conv dgrad / 2 conv wgrad / 3 bmm; M, N, K,
+ * nz = batch or parity classes, exactly as the kernel sees them) use tile config `cfg` (0..4) and split-K factor `split`
+ * instead of the heuristic.  Entries come from timing every (cfg, split) pair on the device (tools/tune_gemm.py ->
+ * multiple-objects-gan_amd/hip/tuned_gemm_gfx950.csv); the host registers them once after loading the library.
+ * mogan_gemm_tune_clear() drops all entries.  Results do not depend on the entry (same sums per split, fixed order). */
+int mogan_gemm_tune_set(int mode, int M, int N, int K, int nz, int cfg, int split);
+int mogan_gemm_tune_clear(void);
+
 /* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
 int mogan_gemm_debug_force(int cfg, int split);
 

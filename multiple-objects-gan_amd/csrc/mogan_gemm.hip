@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <algorithm>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------ host dispatch
 struct Cfg { int wm, wn, tm, tn; };
-static const Cfg kCfgs[] = {{2, 2, 2, 2}, {1, 4, 3, 1}, {4, 1, 1, 1}, {1, 4, 1, 1}, {2, 2, 1, 1}};
-enum { NCFG = 5 };
+static const Cfg kCfgs[] = {{2, 2, 2, 2}, {1, 4, 3, 1}, {4, 1, 1, 1}, {1, 4, 1, 1}, {2, 2, 1, 1}, {2, 2, 2, 1}, {2, 2, 1, 2}};
+enum { NCFG = 7, NCFG_HEUR = 5 };     // 128x64 and 64x128 are only reached through the tuned table / the test hook
 
 template <int MODE, bool AVEC>
 static void launch_cfg2(int c, dim3 grid, hipStream_t st, const GemmP& p) {
@@ -476,6 +477,8 @@ static void launch_cfg2(int c, dim3 grid, hipStream_t st, const GemmP& p) {
         case 1: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 3, 1, AVEC>), grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL((gemm_kernel<MODE, 4, 1, 1, 1, AVEC>), grid, dim3(256), 0, st, p); break;
         case 3: hipLaunchKernelGGL((gemm_kernel<MODE, 1, 4, 1, 1, AVEC>), grid, dim3(256), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 2, 1, AVEC>), grid, dim3(256), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 1, 2, AVEC>), grid, dim3(256), 0, st, p); break;
         default: hipLaunchKernelGGL((gemm_kernel<MODE, 2, 2, 1, 1, AVEC>), grid, dim3(256), 0, st, p); break;
     }
 }
@@ -524,14 +527,28 @@ namespace {
 // chip): +2 % on the multi-stream train step, -7 % on the kernel alone.
 static int g_split_target = 768;
 
+// tuned dispatch (mogan_gemm_tune_set): key = the GEMM as run_gemm sees it
+struct TuneKey { int mode, M, N, K, nz; bool operator==(const TuneKey& o) const { return mode == o.mode && M == o.M && N == o.N && K == o.K && nz == o.nz; } };
+struct TuneHash { size_t operator()(const TuneKey& k) const {
+    size_t h = (size_t)k.mode * 1000003u; h = h * 31 + (size_t)k.M; h = h * 1000003u + (size_t)k.N; h = h * 31 + (size_t)k.K;
+    return h * 7 + (size_t)k.nz; } };
+static std::unordered_map<TuneKey, std::pair<int, int>, TuneHash> g_tuned;
+static std::mutex g_tuned_mu;
+
 static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, size_t ws_bytes, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return 0;
     int best = 0; double bestw = 1e300;
-    for (int c = 0; c < NCFG; ++c) {
+    for (int c = 0; c < NCFG_HEUR; ++c) {
         const int bm = kCfgs[c].wm * kCfgs[c].tm * 32, bn = kCfgs[c].wn * kCfgs[c].tn * 32;
         double w = (double)cdiv(p.M, bm) * bm * (double)cdiv(p.N, bn) * bn;
         w *= (bm * bn >= 96 * 128) ? 1.0 : (bm * bn >= 64 * 64 ? 1.08 : 1.15);   // small tiles: less reuse
         if (w < bestw * 0.999) { bestw = w; best = c; }
+    }
+    int tuned_split = 0;
+    if (g_force_cfg < 0 && g_force_split <= 0 && !g_tuned.empty()) {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        auto it = g_tuned.find(TuneKey{mode, p.M, p.N, p.K, nz});
+        if (it != g_tuned.end()) { best = it->second.first; tuned_split = it->second.second; }
     }
     if (g_force_cfg >= 0) best = g_force_cfg;
     const int bm = kCfgs[best].wm * kCfgs[best].tm * 32, bn = kCfgs[best].wn * kCfgs[best].tn * 32;
@@ -544,6 +561,7 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
         nsplit = (int)std::min<long long>(nsplit, ktiles / 4);
         if (nsplit < 1) nsplit = 1;
     }
+    if (tuned_split > 0) nsplit = std::min(tuned_split, std::max(1, ktiles));
     if (g_force_split > 0) nsplit = std::min(g_force_split, ktiles);
     if (nsplit > 1) {
         const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)c_numel)) : 0;
@@ -610,6 +628,19 @@ extern "C" {
 int mogan_gemm_set_split_target(int blocks) {
     if (blocks < 64 || blocks > 8192) return MOGAN_ERR_SHAPE;
     g_split_target = blocks;
+    return 0;
+}
+
+int mogan_gemm_tune_set(int mode, int M, int N, int K, int nz, int cfg, int split) {
+    if (mode < 0 || mode > 3 || cfg < 0 || cfg >= NCFG || split < 1 || M <= 0 || N <= 0 || K <= 0 || nz <= 0) return MOGAN_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(g_tuned_mu);
+    g_tuned[TuneKey{mode, M, N, K, nz}] = std::make_pair(cfg, split);
+    return 0;
+}
+
+int mogan_gemm_tune_clear(void) {
+    std::lock_guard<std::mutex> lk(g_tuned_mu);
+    g_tuned.clear();
     return 0;
 }
 

@@ -20,6 +20,8 @@ SIGNATURES = {
     "mogan_abi_version": [],
     "mogan_gemm_set_split_target": [I],
     "mogan_gemm_debug_force": [I, I],
+    "mogan_gemm_tune_set": [I, I, I, I, I, I, I],
+    "mogan_gemm_tune_clear": [],
     "mogan_prof_enable": [I],
     "mogan_prof_collect": [P, I],
     "mogan_prof_dump": [ctypes.c_char_p],
@@ -96,7 +98,28 @@ def load():
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, I)
         _lib = lib
+        _register_tuned(lib)
     return _lib
+
+
+TUNED_CSV = os.environ.get("MOGAN_TUNED_CSV") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                            "tuned_gemm_gfx950.csv")
+
+
+def _register_tuned(lib):
+    """Tuned (tile config, split-K) choices of the implicit-GEMM kernel for the GEMMs of the benchmark configurations
+    (tools/tune_gemm.py, measured on MI355X).  MOGAN_TUNED=0 leaves the heuristic alone."""
+    if os.environ.get("MOGAN_TUNED", "1") == "0" or not os.path.isfile(TUNED_CSV):
+        return 0
+    n = 0
+    with open(TUNED_CSV) as f:
+        for line in f:
+            if line.startswith("#") or line.startswith("mode") or not line.strip():
+                continue
+            v = [int(x) for x in line.split(",")[:7]]
+            if lib.mogan_gemm_tune_set(*v) == 0:
+                n += 1
+    return n
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

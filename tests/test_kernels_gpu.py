@@ -77,7 +77,7 @@ def _conv_ref(x, w, stride, pad, up):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("force", [(-1, 0), (0, 3), (1, 1), (2, 2), (3, 1), (4, 5)])
+@pytest.mark.parametrize("force", [(-1, 0), (0, 3), (1, 1), (2, 2), (3, 1), (4, 5), (5, 2), (6, 3)])
 def test_conv2d_fwd_dgrad_wgrad(case, force):
     B, Cin, H, W, Cout, k, s, pad, up = case
     lib.load().mogan_gemm_debug_force(*force)

@@ -16,10 +16,10 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for (B, Cin, H, Cout) in [(2, 16, 8, 8), (2, 24, 32, 100), (16, 96, 128, 192), (16, 96, 128, 96), (16, 96, 64, 192), (16, 96, 64, 96), (16, 192, 64, 96)]:
+for (B, Cin, H, Cout) in [(2, 16, 8, 16), (2, 32, 32, 100), (16, 96, 128, 192), (16, 96, 128, 96), (16, 96, 64, 192), (16, 96, 64, 96), (16, 192, 64, 96)]:
     W = max(H, 32)
     x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
-    U = torch.empty(16, Cin, Cout, device=dev); y = torch.empty(B, Cout, H, W, device=dev)
+    U = torch.zeros(16 * Cin * ((Cout + 95) // 96) * 96, device=dev); y = torch.empty(B, Cout, H, W, device=dev)
     st = lib.stream_ptr()
     def wino():
         assert L.mogan_lab_wino_weights(w.data_ptr(), U.data_ptr(), Cout, Cin, 0, st) == 0
@@ -31,7 +31,7 @@ for (B, Cin, H, Cout) in [(2, 16, 8, 8), (2, 24, 32, 100), (16, 96, 128, 192), (
     errd = (yd.double() - ref).abs().max().item() / ref.abs().max().item()
     # dgrad through the same kernel: flip
     dy = torch.randn(B, Cout, H, W, device=dev)
-    dx = torch.empty(B, Cin, H, W, device=dev); U2 = torch.empty(16, Cout, Cin, device=dev)
+    dx = torch.empty(B, Cin, H, W, device=dev); U2 = torch.zeros(16 * Cout * ((Cin + 95) // 96) * 96, device=dev)
     L.mogan_lab_wino_weights(w.data_ptr(), U2.data_ptr(), Cout, Cin, 1, st)
     rc = L.mogan_lab_wino_fwd(dy.data_ptr(), U2.data_ptr(), dx.data_ptr(), B, Cout, H, W, Cin, st)
     refd = torch.nn.functional.conv_transpose2d(dy.double(), w.double(), None, 1, 1)

@@ -104,7 +104,14 @@ def roofline_leg(engine, run_step, steps=2):
     rows = []
     for i in range(n):
         m, c, launches, flops, ms = buf[5 * i:5 * i + 5]
-        name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)]) if m < 4 else ("dconv_wgrad_kernel" if int(m) == 6 else "dconv_fwd_kernel<%s>" % MODES[int(m)][6:])
+        if m < 4:
+            name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)])
+        elif int(m) == 6:
+            name = "dconv_wgrad_kernel"
+        elif int(c) == 1:       # fused Winograd F(2x2,3x3): flops = the 16/36 of the direct multiplies it executes
+            name = "wino_fwd_kernel<%s>" % MODES[int(m)][6:]
+        else:
+            name = "dconv_fwd_kernel<%s>" % MODES[int(m)][6:]
         rows.append(dict(kernel=name,
                          launches_per_step=launches / steps, gflop_per_step=flops / steps / 1e9,
                          ms_per_step=ms / steps, tflops=(flops / 1e12) / (ms / 1e3) if ms > 0 else 0.0))

@@ -709,6 +709,13 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
         rc = mogan_smallc_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
+    if (g_force_cfg < 0) {          // 3x3 s1 p1 at >= 32 channels: fused Winograd F(2x2,3x3), 2.25x fewer multiplies
+        // (recorded flops = the multiplies the kernel executes: 16 per 2x2 outputs instead of 36)
+        mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
+        rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 0, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(4, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
         rc = mogan_dconv_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
@@ -740,6 +747,12 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     if (g_force_cfg < 0) {          // <= 4 channels on one side (image heads, first D convolution)
         rc = mogan_smallc_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
+    if (g_force_cfg < 0) {
+        mogan_prof_begin(5, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
+        rc = mogan_wino_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 1, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
     if (mogan_use_dconv && g_force_cfg < 0) {

@@ -12,6 +12,7 @@
 // row transform M A is local to a wave, the column transform A^t (.) goes through LDS (one pass per output column parity).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
 
@@ -246,25 +247,31 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" {
+// ---- internal entry points (hidden visibility): 1 = handled, 0 = not eligible, < 0 = error -----------------------------
+// dgrad = 0: y (B,Cout,H,W) = conv3x3 s1 p1 (x (B,Cin,H,W), w (Cout,Cin,3,3))
+// dgrad = 1: dx (B,Cin,H,W) = conv3x3^T (dy (B,Cout,H,W), w): the same kernel over dY with the rotated / transposed filters
+// The transformed weights (ceil(Kout/96)*96 * 16 * Kin floats) are rebuilt per call at the head of the workspace: the
+// weights change every step, the transform is one thread per (co, ci).
+static int g_wino = -1;
 
-// lab entry points (not part of include/mogan_hip.h): U = ceil(Kout/96)*96 * 16 * Kin floats (ZEROED by the caller when Kout
-// is not a multiple of 96) from w (Cout, Cin, 3, 3); y = conv3x3 p1 (x)
-int mogan_lab_wino_weights(const float* w, float* U, int Cout, int Cin, int flip, hipStream_t st) {
+int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                   int stride, int ph, int pw, int up, int dgrad, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_wino || !(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0)) return 0;
+    const int Kin = dgrad ? Cout : Cin, Kout = dgrad ? Cin : Cout;       // channels the kernel reduces over / produces
+    if ((Kin % (2 * CK)) || Kin < 32 || Kout < 64 || (H % (2 * TROWS)) || (W % (2 * TCOLS))) return 0;
+    if ((((uintptr_t)out) & 7) != 0) return 0;
+    const long long mbs = (Kout + BM - 1) / BM;
+    const size_t ubytes = (size_t)mbs * BM * 16 * Kin * sizeof(float);
+    if ((long long)B * Kin * H * W >= (1ll << 30) || (long long)B * Kout * H * W >= (1ll << 30) || ubytes >= (1ull << 31))
+        return 0;
+    if (!ws || ws_bytes < ubytes) return 0;
+    float* U = (float*)ws;
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, flip);
-    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
-}
-
-int mogan_lab_wino_fwd(const float* x, const float* U, float* y, int B, int Cin, int H, int W, int Cout, hipStream_t st) {
-    if ((Cin % (2 * CK)) || (H % (2 * TROWS)) || (W % (2 * TCOLS))) return MOGAN_ERR_SHAPE;
-    const long long mbs = (Cout + BM - 1) / BM;
-    if ((long long)B * Cin * H * W >= (1ll << 30) || mbs * 16 * Cin * BM >= (1ll << 30)) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad);
     const int tiles_x = W / (2 * TCOLS), tiles_y = H / (2 * TROWS);
-    dim3 grid((unsigned)(B * tiles_x * tiles_y), (unsigned)((Cout + BM - 1) / BM));
-    hipLaunchKernelGGL(wino_fwd_kernel, grid, dim3(512), 0, st, x, U, y, Cin, H, W, Cout, tiles_x, tiles_y,
-                       4u * B * Cin * H * W, (unsigned)(4 * mbs * 16 * Cin * BM));
-    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+    dim3 grid((unsigned)(B * tiles_x * tiles_y), (unsigned)mbs);
+    hipLaunchKernelGGL(wino_fwd_kernel, grid, dim3(512), 0, st, in, (const float*)U, out, Kin, H, W, Kout, tiles_x, tiles_y,
+                       (unsigned)(4ull * B * Kin * H * W), (unsigned)ubytes);
+    return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }
-
-}  // extern "C"

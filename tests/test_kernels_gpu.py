@@ -58,8 +58,14 @@ CONV_CASES = [
     (2, 6, 12, 12, 8, (5, 5), 1, (2, 2), 0),       # Inception 5x5
     (1, 96, 32, 32, 96, (3, 3), 1, (1, 1), 0),     # 96-wide tile config
     (2, 160, 8, 8, 130, (3, 3), 1, (1, 1), 0),     # 128x128 tiles with ragged edges + long K
+    # fused Winograd F(2x2,3x3) (3x3 s1 p1, Cin % 16 == 0, >= 64 output channels, H % 4 == 0, W % 32 == 0): fwd and dgrad
+    (2, 32, 8, 32, 64, (3, 3), 1, (1, 1), 0),      # one tile column, two chunks
+    (3, 48, 12, 64, 100, (3, 3), 1, (1, 1), 0),    # ragged M (100 = 96 + 4), odd chunk pairs, image borders everywhere
+    (1, 96, 32, 32, 192, (3, 3), 1, (1, 1), 0),    # ResBlock widths
+    (2, 64, 16, 96, 64, (3, 3), 1, (1, 1), 0),     # dgrad also Winograd (Cout % 16 == 0, Cin >= 64)
     # shapes that take the direct (halo-tile) kernel when no tile config is forced (>= 64 channels each side)
-    (2, 64, 32, 32, 72, (3, 3), 1, (1, 1), 0),     # 3x3 s1, Cw=32, ragged M
+    (2, 64, 32, 32, 72, (3, 3), 1, (1, 1), 0),     # 3x3 s1, Cw=32, ragged M (forward: Winograd; dgrad: direct, 72 % 16 != 0)
+    (2, 72, 32, 32, 64, (3, 3), 1, (1, 1), 0),     # Cin % 16 != 0: forward stays on the direct kernel (Cw=32, 16-byte halo loads)
     (2, 64, 16, 16, 64, (3, 3), 1, (1, 1), 1),     # upBlock: 16x16 -> 32x32
     (3, 64, 16, 16, 100, (3, 3), 1, (1, 1), 0),    # Cw=16, R=8; 96-wide M tile + ragged M
     (1, 64, 64, 128, 64, (3, 3), 1, (1, 1), 0),    # non-square

@@ -18,12 +18,14 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("gemm_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel")
+KEEP = ("gemm_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel", "wino_fwd_kernel")
 
 
 def short(name):
     m = re.search(r"(gemm_kernel|dconv_fwd_kernel|dconv_wgrad_kernel)<([^>]*)>", name)
-    return "%s<%s>" % (m.group(1), m.group(2)) if m else None
+    if m:
+        return "%s<%s>" % (m.group(1), m.group(2))
+    return "wino_fwd_kernel<>" if "wino_fwd_kernel" in name else None
 
 
 def load(path, counter):

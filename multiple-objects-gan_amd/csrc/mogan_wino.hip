@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
 
@@ -75,58 +76,60 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 
 __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__ X, const float* __restrict__ U,
                                                        float* __restrict__ Y, int Cin, int H, int W, int Cout, int tiles_x,
-                                                       int tiles_y, unsigned x_bytes, unsigned u_bytes) {
+                                                       int tiles_y, int ntile, int nimg, unsigned x_bytes, unsigned u_bytes) {
     constexpr int XSZ = CK * XR * XCP, VSZ = 16 * CK * NT;
     __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ + 4];      // + a dump slot for the idle staging lanes
     __shared__ __attribute__((aligned(16))) float Vs[2 * VSZ];
     __shared__ __attribute__((aligned(16))) float Ts[8 * BM * NT];      // epilogue exchange
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y; const int img = t / tiles_y;
-    const int mb = blockIdx.y, m0 = mb * BM;
-    const int oy0 = ty * 2 * TROWS, ox0 = tx * 2 * TCOLS;
     const int plane = H * W;
     const int nchunk = Cin / CK;
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U, (short)0, (int)u_bytes, 0x00020000);
 
-    // 8 waves: wave w owns the two positions xi = 2w, 2w+1 (row w>>1 of the 4x4 grid, columns 2(w&1), 2(w&1)+1)
-    f32x16 acc[2][3];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][a][r] = 0.f;
-
+    // staging plan, tile independent part: element e = tid + 512 i of the 8 x 6 x 34 halo
     constexpr int NXE = (CK * XR * XC + 511) / 512;         // 4
-    int xl[NXE]; unsigned xg[NXE];
+    int xl[NXE], xhy[NXE], xhx[NXE]; unsigned xc[NXE];
 #pragma unroll
     for (int i = 0; i < NXE; ++i) {
         const int e = tid + 512 * i;
         const int c = e / (XR * XC), r = e - c * (XR * XC);
         const int hy = r / XC, hx = r - hy * XC;
-        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        const bool ok = e < CK * XR * XC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         xl[i] = e < CK * XR * XC ? c * (XR * XCP) + hy * XCP + hx : -1;
-        xg[i] = ok ? (unsigned)(img * Cin + c) * plane + (unsigned)(iy * W + ix) : 0x30000000u;   // *4 >= 2 GiB: reads 0
+        xhy[i] = e < CK * XR * XC ? hy - 1 : -0x10000; xhx[i] = hx - 1;
+        xc[i] = (unsigned)c * plane;
     }
-    const unsigned ubase = (unsigned)((mb * 8 + wave) * nchunk) * (6 * 64 * 4) + (unsigned)lane * 4;
     const int th = tid >> 8, tc = (tid >> 5) & 7, tt = tid & 31, tty = tt >> 4, ttx = tt & 15;
 
-    float rx[NXE];
-    auto load_x = [&](int c0) {
+    // per tile: (mb, img, ty, tx) with tx fastest; xg = global element index of this thread's halo elements at chunk 0
+    unsigned xg[NXE]; unsigned ubase; int m0, img, oy0, ox0;
+    auto plan = [&](int tile, unsigned (&g)[NXE], unsigned& ub, int& m0_, int& img_, int& oy_, int& ox_) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y; t /= tiles_y;
+        img_ = t % nimg; const int mb = t / nimg;
+        m0_ = mb * BM; oy_ = ty * 2 * TROWS; ox_ = tx * 2 * TCOLS;
 #pragma unroll
-        for (int i = 0; i < NXE; ++i) rx[i] = ldgx(rX, xg[i] + (unsigned)c0 * plane, true);
+        for (int i = 0; i < NXE; ++i) {
+            const int iy = oy_ + xhy[i], ix = ox_ + xhx[i];
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            g[i] = ok ? (unsigned)(img_ * Cin) * plane + xc[i] + (unsigned)(iy * W + ix) : 0x30000000u;   // reads 0
+        }
+        ub = (unsigned)((mb * 8 + wave) * nchunk) * (6 * 64 * 4) + (unsigned)lane * 4;
     };
-    auto store_x = [&](float* Xd, int dump) {
+
+    float rx[NXE], rx1[NXE];
+    auto load_x = [&](float (&r)[NXE], const unsigned (&g)[NXE], int c0) {
 #pragma unroll
-        for (int i = 0; i < NXE; ++i) Xd[xl[i] >= 0 ? xl[i] : dump] = rx[i];
+        for (int i = 0; i < NXE; ++i) r[i] = ldgx(rX, g[i] + (unsigned)c0 * plane, true);
     };
-    auto load_a = [&](f32x4 (&au)[6], int chunk) {
+    auto store_x = [&](const float (&r)[NXE], float* Xd, int dump) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) au[i] = ldgx4(rU, ubase + (unsigned)(chunk * 6 + i) * 256u, true);
+        for (int i = 0; i < NXE; ++i) Xd[xl[i] >= 0 ? xl[i] : dump] = r[i];
+    };
+    auto load_a = [&](f32x4 (&au)[6], unsigned ub, int chunk) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) au[i] = ldgx4(rU, ub + (unsigned)(chunk * 6 + i) * 256u, true);
     };
     auto transform = [&](const float* Xc, float* Vd) {      // rows 2th, 2th+1 of V = B^t d B for (channel tc, tile tt)
         float ra[4], rb[4], rc[4];
@@ -155,6 +158,9 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
             pv[3 * CK * NT] = u[i][1] - u[i][3];
         }
     };
+
+    // 8 waves: wave w owns the two positions xi = 2w, 2w+1 (row w>>1 of the 4x4 grid, columns 2(w&1), 2(w&1)+1)
+    f32x16 acc[2][3];
     // one chunk: MFMAs on (A registers, Vs[cur]); in their shadow: A(c+1) -> registers, X(c+2) -> Xs[cur], transform
     // X(c+1) -> Vs[nxt], load X(c+3).  One barrier per chunk.
     auto step = [&](int c, int cur, const f32x4 (&ac)[6], f32x4 (&an)[6]) {
@@ -165,9 +171,9 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int kk = 0; kk < CK / 2; ++kk) bv[j][kk] = Vc[((wave * 2 + j) * CK + 2 * kk + h) * NT + l31];
-        load_a(an, c + 1);
-        store_x(Xs + cur * XSZ, 2 * XSZ - cur * XSZ);
-        load_x((c + 3) * CK);
+        load_a(an, ubase, c + 1);
+        store_x(rx, Xs + cur * XSZ, 2 * XSZ - cur * XSZ);
+        load_x(rx, xg, (c + 3) * CK);
         transform(Xs + nxt * XSZ, Vs + nxt * VSZ);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -191,60 +197,78 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
         __syncthreads();
     };
 
+    // Persistent blocks (one per CU): the first loads of the NEXT tile (X chunks 0 and 1, the weights of chunk 0) are issued
+    // before the epilogue of the current one, so no tile but the first waits for global memory before its first MFMA, and
+    // there is no block launch gap between tiles.
     f32x4 a0[6], a1[6];
-    load_x(0);
-    load_a(a0, 0);
-    store_x(Xs, 2 * XSZ);
-    load_x(CK);
-    __syncthreads();
-    transform(Xs, Vs);
-    store_x(Xs + XSZ, XSZ);
-    load_x(2 * CK);
-    __syncthreads();
-    for (int c = 0; c < nchunk; c += 2) {                   // nchunk is even (host)
-        step(c, 0, a0, a1);
-        step(c + 1, 1, a1, a0);
+    int tile = blockIdx.x;
+    if (tile < ntile) {
+        plan(tile, xg, ubase, m0, img, oy0, ox0);
+        load_x(rx, xg, 0); load_x(rx1, xg, CK); load_a(a0, ubase, 0);
     }
-
-    // ---- output transform.  Row i = wave>>1 of M: T_i[b] = sum_j M[i][j] A[j][b] with A^t = [[1,1,1,0],[0,1,-1,-1]] is split
-    // over the wave pair (columns {0,1} / {2,3}): every wave writes its partial, then Y[a][b] = sum_i A^t[a][i] T_i[b].
-    float yreg[6][2][2];
-    const int wj = wave & 1;
+    for (; tile < ntile; tile += gridDim.x) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        if (b) __syncthreads();
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = wj == 0 ? (b == 0 ? acc[0][a][r] + acc[1][a][r] : acc[1][a][r])
-                                        : (b == 0 ? acc[0][a][r] : -acc[0][a][r] - acc[1][a][r]);
-                Ts[(wave * BM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * NT + l31] = p;
-            }
+                for (int r = 0; r < 16; ++r) acc[j][a][r] = 0.f;
+        store_x(rx, Xs, 2 * XSZ);
+        store_x(rx1, Xs + XSZ, XSZ);
+        load_x(rx, xg, 2 * CK);
         __syncthreads();
+        transform(Xs, Vs);
+        __syncthreads();
+        for (int c = 0; c < nchunk; c += 2) {                   // nchunk is even (host)
+            step(c, 0, a0, a1);
+            step(c + 1, 1, a1, a0);
+        }
+        const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
+        if (tile + (int)gridDim.x < ntile) {
+            plan(tile + gridDim.x, xg, ubase, m0, img, oy0, ox0);
+            load_x(rx, xg, 0); load_x(rx1, xg, CK); load_a(a0, ubase, 0);
+        }
+
+        // ---- output transform.  Row i = wave>>1 of M: T_i[b] = sum_j M[i][j] A[j][b] with A^t = [[1,1,1,0],[0,1,-1,-1]] is
+        // split over the wave pair (columns {0,1} / {2,3}): every wave writes its partial, then Y[a][b] = sum_i A^t[a][i] T_i[b].
+        float yreg[6][2][2];
+        const int wj = wave & 1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b) __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = wj == 0 ? (b == 0 ? acc[0][a][r] + acc[1][a][r] : acc[1][a][r])
+                                            : (b == 0 ? acc[0][a][r] : -acc[0][a][r] - acc[1][a][r]);
+                    Ts[(wave * BM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * NT + l31] = p;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int idx = tid + 512 * q;
+                float tq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tq[i] = Ts[(2 * i) * BM * NT + idx] + Ts[(2 * i + 1) * BM * NT + idx];
+                yreg[q][0][b] = tq[0] + tq[1] + tq[2];
+                yreg[q][1][b] = tq[1] - tq[2] - tq[3];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int idx = tid + 512 * q;
-            float tq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tq[i] = Ts[(2 * i) * BM * NT + idx] + Ts[(2 * i + 1) * BM * NT + idx];
-            yreg[q][0][b] = tq[0] + tq[1] + tq[2];
-            yreg[q][1][b] = tq[1] - tq[2] - tq[3];
+            const int m = idx >> 5, tl = idx & 31;
+            const int oy = coy0 + 2 * (tl >> 4), ox = cox0 + 2 * (tl & 15);
+            if (cm0 + m < Cout && oy < H && ox < W) {
+                float* o = Y + ((size_t)(cimg * Cout + cm0 + m) * H + oy) * W + ox;
+                *(float2*)o = make_float2(yreg[q][0][0], yreg[q][0][1]);
+                *(float2*)(o + W) = make_float2(yreg[q][1][0], yreg[q][1][1]);
+            }
         }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int idx = tid + 512 * q;
-        const int m = idx >> 5, tile = idx & 31;
-        const int oy = oy0 + 2 * (tile >> 4), ox = ox0 + 2 * (tile & 15);
-        if (m0 + m < Cout && oy < H && ox < W) {
-            float* o = Y + ((size_t)(img * Cout + m0 + m) * H + oy) * W + ox;
-            *(float2*)o = make_float2(yreg[q][0][0], yreg[q][0][1]);
-            *(float2*)(o + W) = make_float2(yreg[q][1][0], yreg[q][1][1]);
-        }
+        // (the next tile's store_x / transform touch Xs / Vs only; Ts is rewritten after two more barriers)
     }
 }
-
 
 // ------------------------------------------------------------------------------------------ weight gradient
 // dW = G^t [ sum over tiles (A dY A^t) .* (B^t d B) ] G: per position xi a GEMM dU_xi[co][ci] = sum_tiles Q_xi[co][tile]
@@ -474,16 +498,28 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     if ((((uintptr_t)out) & 7) != 0) return 0;
     const long long mbs = (Kout + BM - 1) / BM;
     const size_t ubytes = (size_t)mbs * BM * 16 * Kin * sizeof(float);
-    if ((long long)B * Kin * H * W >= (1ll << 30) || (long long)B * Kout * H * W >= (1ll << 30) || ubytes >= (1ull << 31))
+    // 32-bit byte offsets: input < 2 GiB, and the "reads as zero" sentinel (0xC0000000 bytes) plus a per-image channel
+    // offset must neither land inside the buffer nor wrap
+    if ((long long)B * Kin * H * W >= (1ll << 29) || (long long)Kin * H * W >= (1ll << 26) ||
+        (long long)B * Kout * H * W >= (1ll << 30) || ubytes >= (1ull << 31))
         return 0;
     if (!ws || ws_bytes < ubytes) return 0;
     float* U = (float*)ws;
     const long long n = (long long)Cout * Cin;
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad);
     const int tiles_x = W / (2 * TCOLS), tiles_y = H / (2 * TROWS);
-    dim3 grid((unsigned)(B * tiles_x * tiles_y), (unsigned)mbs);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const long long ntile = (long long)B * tiles_x * tiles_y * mbs;
+    if (ntile >= (1ll << 30)) return 0;
+    // persistent: one 8-wave block per CU walks the tiles
+    dim3 grid((unsigned)std::min<long long>(ntile, ncu));
     hipLaunchKernelGGL(wino_fwd_kernel, grid, dim3(512), 0, st, in, (const float*)U, out, Kin, H, W, Kout, tiles_x, tiles_y,
-                       (unsigned)(4ull * B * Kin * H * W), (unsigned)ubytes);
+                       (int)ntile, B, (unsigned)(4ull * B * Kin * H * W), (unsigned)ubytes);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }
 

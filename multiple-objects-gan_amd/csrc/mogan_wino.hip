@@ -448,20 +448,23 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const float* __restrict
 }
 
 // dW[co][ci] (+)= G^t (sum_sp dU[sp][.][co][ci]) G,  G^t = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
-__global__ __launch_bounds__(256) void wino_wgrad_finish(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+__global__ __launch_bounds__(64) void wino_wgrad_finish(const float* __restrict__ part, float* __restrict__ dw, int Cout,
                                                          int Cin, int nsplit, int accumulate) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
     const long long n = (long long)Cout * Cin;
     if (i >= n) return;
     float u[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            float s = 0.f;
-            for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * 16 + a * 4 + b) * n + i];
-            u[a][b] = s;
-        }
+        for (int b = 0; b < 4; ++b) u[a][b] = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {                   // 16 independent loads in flight per split, fixed order
+        const float* ps = part + (size_t)sp * 16 * n + i;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u[a][b] += ps[(size_t)(a * 4 + b) * n];
+    }
     float t[3][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -527,10 +530,8 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
 int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                          int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
-    // OFF by default: correct (kernel tests pass with it on) but not yet faster than the direct kernel -- 93 vs 97 TFLOP/s
-    // (direct-equivalent) on 96 -> 192 at 128x128, 47 vs 92 at 64x64: the K-split partials are 16 x Cout x Cin per block
-    // (100 MB per launch at 510 blocks) and wino_wgrad_finish walks them serially.  MOGAN_WINO_WGRAD=1 enables it.
-    static const int wg_on = getenv("MOGAN_WINO_WGRAD") ? atoi(getenv("MOGAN_WINO_WGRAD")) : 0;
+    // MOGAN_WINO_WGRAD=0 falls back to the direct kernel (2 = timing aid: main kernel without the finish pass)
+    static const int wg_on = getenv("MOGAN_WINO_WGRAD") ? atoi(getenv("MOGAN_WINO_WGRAD")) : 1;
     if (!g_wino || !wg_on || !(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0)) return 0;
     if (Cin < 32 || Cout < 64 || (H % 2) || (W % (2 * WCT)) || (W % 2)) return 0;
     if ((((uintptr_t)dy) & 7) != 0) return 0;
@@ -549,7 +550,8 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
     hipLaunchKernelGGL(wino_wgrad_kernel, grid, dim3(512), 0, st, dy, x, (float*)ws, Cin, H, W, Cout, nchunk, cps,
                        (unsigned)(4ull * B * Cout * H * W), (unsigned)(4ull * B * Cin * H * W));
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino_wgrad_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, Cout,
+    if (wg_on != 2)     // (2 = timing aid: main kernel only)
+    hipLaunchKernelGGL(wino_wgrad_finish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const float*)ws, dw, Cout,
                        Cin, nsplit, accumulate);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }

@@ -538,7 +538,10 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
     if ((long long)B * Cin * H * W >= (1ll << 30) || (long long)B * Cout * H * W >= (1ll << 30)) return 0;
     const int nchunk = B * (H / 2) * (W / (2 * WCT));
     const int tiles_mn = ((Cout + BM - 1) / BM) * ((Cin + WBN - 1) / WBN);
-    int nsplit = 512 / tiles_mn;                            // one 8-wave block per CU: at most two full rounds of 256
+    // one 8-wave block per CU and ONE round of blocks: the K-split partials (16 x Cout x Cin floats per split) are what the
+    // finish pass has to read back (256 blocks: 156 / 137 TF direct-equivalent at 128x128 / 64x64; 512: 147 / 117)
+    static const int wg_blocks = getenv("MOGAN_WINO_WG_BLOCKS") ? atoi(getenv("MOGAN_WINO_WG_BLOCKS")) : 256;
+    int nsplit = wg_blocks / tiles_mn;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nchunk / 8) nsplit = nchunk / 8 > 0 ? nchunk / 8 : 1;
     const size_t slab = (size_t)16 * Cout * Cin * sizeof(float);

@@ -124,3 +124,18 @@ def test_synthetic_batch_contract():
     assert bool((b["label_one_hot"][absent][:, 80] == 1).all())                      # -1 -> class 80
     np.testing.assert_array_equal(b["tmi"][absent][0].numpy(), np.array([[-1, 0, -4], [0, -1, -4]], np.float32))
     np.testing.assert_array_equal(b["class_ids"], np.arange(16))
+
+
+def test_tuned_gemm_table_is_well_formed():
+    """hip/tuned_gemm_gfx950.csv (tools/tune_all.sh): one `mode,M,N,K,nz,cfg,split,...` line per tuned GEMM; the loader
+    hands the first seven integers to mogan_gemm_tune_set, which rejects anything outside these ranges."""
+    import os
+    path = os.path.join(ROOT, "multiple-objects-gan_amd", "hip", "tuned_gemm_gfx950.csv")
+    rows = [l.split(",") for l in open(path) if l.strip() and not l.startswith("#")]
+    assert len(rows) > 100
+    seen = set()
+    for r in rows:
+        mode, M, N, K, nz, cfg, split = (int(x) for x in r[:7])
+        assert 0 <= mode <= 3 and M > 0 and N > 0 and K > 0 and nz >= 1 and 0 <= cfg < 7 and 1 <= split <= 64
+        assert (mode, M, N, K, nz) not in seen
+        seen.add((mode, M, N, K, nz))

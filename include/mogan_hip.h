@@ -55,6 +55,10 @@ int mogan_gemm_set_split_target(int blocks);
 int mogan_gemm_tune_set(int mode, int M, int N, int K, int nz, int cfg, int split);
 int mogan_gemm_tune_clear(void);
 
+/* test hook: the 4x4-s2 Winograd kernel is only taken from `n` 2x2-output tiles on (default 1024, -1 restores it); the
+ * kernel tests lower it to cover small shapes */
+int mogan_wino22_debug_min_tiles(int n);
+
 /* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
 int mogan_gemm_debug_force(int cfg, int split);
 

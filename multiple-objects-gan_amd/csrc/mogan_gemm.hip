@@ -716,6 +716,12 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
+    if (g_force_cfg < 0) {          // 4x4 s2 p1: fused Winograd F(2x2,2x2) on the four input phases (9 instead of 16 multiplies)
+        mogan_prof_begin(4, 2, (9.0 / 16.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
+        rc = mogan_wino22_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(4, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
         rc = mogan_dconv_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);

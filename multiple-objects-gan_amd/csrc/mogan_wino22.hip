@@ -1,0 +1,303 @@
+// mogan_wino22.hip -- Winograd F(2x2, 2x2) for the 4x4 stride-2 pad-1 convolutions (every down-convolution of the
+// discriminators, model.py:587-613).  A 4x4 s2 convolution is the sum over the four input phases (p,q) of a 2x2 stride-1
+// convolution of the phase image x_pq[i][j] = x[2i+p-1][2j+q-1] with the filter g_pq[a][b] = w[2a+p][2b+q]; each of those is
+// evaluated as  Y = A^t [ (G g G^t) .* (B^t d B) ] A  on 3x3 tiles (9 multiplies per 2x2 outputs instead of 16):
+//   B^t = [[1,-1,0],[0,1,0],[0,-1,1]]   G = [[1,0],[1,1],[0,1]]   A^t = [[1,1,0],[0,1,1]]       (only +-1: exact adds)
+// so the whole convolution is 9 GEMMs  M_xi[co][tile] = sum_{ci,p,q} U_xi[co][ci,p,q] V_xi[ci,p,q][tile]  with K = 4 Cin.
+//
+// One kernel, same structure as mogan_wino.hip: a block (12 waves) owns 128 output channels x 32 tiles (2x2 outputs each,
+// consecutive in (image, tile row, tile column) order -- any even output size, a block may span several small images) for a
+// range of K-chunks (4 input channels x 4 phases = 16 k); the 9 x 4 (position, m-tile) units are dealt three per wave.
+// Per chunk every tile's 6x6 input window goes to LDS (Xs[ci][6][6][tile]), 512 threads transform one (k-channel, tile)
+// patch each into Vs[xi][k][tile], and the weights -- pre-transformed by wino22_weight_kernel into the order the MFMA lanes
+// consume them -- come straight from global memory into registers, one chunk ahead.  LDS images double buffered, one barrier
+// per chunk, persistent blocks.  Output transform through LDS (Ts[xi][m][tile], aliased with the staging buffers).  With
+// nsplit > 1 (deep layers: few tiles, long K) every K-split writes its partial output to a workspace slab and
+// wino22_reduce sums the slabs in order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include "../../include/mogan_hip.h"
+#include "mogan_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CI = 4, KC = 4 * CI, NT = 32, BM = 128, NWAVE = 12, NTHR = 64 * NWAVE;
+constexpr int XSZ = CI * 36 * NT, VSZ = 9 * KC * NT, TSZ = 9 * BM * NT;
+
+__device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, unsigned idx) {          // idx 0x30000000 -> 0.f
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4u, 0, 0));
+}
+__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, unsigned idx) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, idx * 4u, 0, 0));
+}
+
+// U2[mb][wave][chunk][i = 0..5][lane][e = 0..3], v = uu*8 + kk = 4i + e: the A operand of unit u = 3*wave + uu (position
+// xi = u >> 2, m-tile u & 3) at k-step kk for lane (h, l31) = U_xi[co = mb*128 + 32*(u&3) + l31][k = 2kk + h], k = ci*4 + 2p + q.
+__global__ __launch_bounds__(256) void wino22_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
+                                                            int Cin) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
+    const float* g = w + i * 16;
+    const int nchunk = Cin / CI;
+    const int mb = co / BM, m = co - mb * BM, mt = m >> 5, l31 = m & 31;
+    const int chunk = ci / CI, cl = ci - chunk * CI;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float g00 = g[p * 4 + q], g01 = g[p * 4 + 2 + q], g10 = g[(2 + p) * 4 + q], g11 = g[(2 + p) * 4 + 2 + q];
+            const float t[3][2] = {{g00, g01}, {g00 + g10, g01 + g11}, {g10, g11}};
+            const int k = cl * 4 + p * 2 + q, kk = k >> 1, h = k & 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float u3[3] = {t[a][0], t[a][0] + t[a][1], t[a][1]};
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int unit = (a * 3 + b) * 4 + mt, wv = unit / 3, uu = unit - wv * 3;
+                    const int v = uu * 8 + kk;
+                    U[((((size_t)(mb * NWAVE + wv) * nchunk + chunk) * 6 + (v >> 2)) * 64 + h * 32 + l31) * 4 + (v & 3)] = u3[b];
+                }
+            }
+        }
+}
+
+struct W22P {
+    const float* X; const float* U; float* Y; float* ws;
+    int Cin, H, W, Cout, OH, OW, B;
+    int ntile, ntb, mbs, nsplit, cps, nchunk, nitem;
+    long long slab;
+    unsigned x_bytes, u_bytes;
+};
+
+__global__ __launch_bounds__(NTHR) void wino22_fwd_kernel(const W22P p) {
+    __shared__ __attribute__((aligned(16))) float raw[TSZ];             // Ts; the staging images alias its head
+    float* const Xs = raw;                                              // [2][CI][6][6][tile]
+    float* const Vs = raw + 2 * XSZ;                                    // [2][xi][k][tile]
+    float* const Ts = raw;
+    static_assert(2 * XSZ + 2 * VSZ <= TSZ, "staging fits under Ts");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int plane = p.H * p.W, oplane = p.OH * p.OW;
+    const int tx_n = p.OW >> 1, ty_n = p.OH >> 1, tpi = tx_n * ty_n;    // tiles per row / column / image
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, (short)0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, (short)0, (int)p.u_bytes, 0x00020000);
+
+    // staging role: element e = tid + NTHR*i (i < 6) of Xs = (rest = e >> 5 -> ci, r6, c6; tile = e & 31 = tid & 31)
+    constexpr int NXE = XSZ / NTHR;                                     // 6
+    static_assert(NXE * NTHR == XSZ, "staging divides");
+    // transform role (tid < 512): k-channel kc = tid >> 5 = ci*4 + 2p + q, tile = tid & 31
+    const int kc = (tid >> 5) & 15, kci = kc >> 2, kp = (kc >> 1) & 1, kq = kc & 1;
+    const bool xform = tid < 16 * NT;
+    // MFMA role: units 3*wave + uu
+    int uxi[3], umt[3];
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) { const int u = 3 * wave + uu; uxi[uu] = u >> 2; umt[uu] = u & 3; }
+
+    // per work item: (mb, tile block tb, split sp)
+    unsigned xg[NXE]; unsigned ubase; int c_beg = 0, c_end = 0, m0 = 0, tb = 0, sp = 0;
+    auto plan = [&](int item) {
+        sp = item % p.nsplit; const int t2 = item / p.nsplit;
+        tb = t2 % p.ntb; const int mb = t2 / p.ntb;
+        m0 = mb * BM;
+        c_beg = sp * p.cps; c_end = min(p.nchunk, c_beg + p.cps);
+        const int tile = tb * NT + (tid & 31);
+        const bool tok = tile < p.ntile;
+        const int img = tile / tpi, rem = tile - img * tpi;
+        const int ty = rem / tx_n, tx = rem - ty * tx_n;
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const int rest = (tid >> 5) + (NTHR / 32) * i;              // (ci, r6, c6) of this thread's i-th element
+            const int ci = rest / 36, r = rest - ci * 36, r6 = r / 6, c6 = r - r6 * 6;
+            const int iy = 4 * ty - 1 + r6, ix = 4 * tx - 1 + c6;
+            const bool ok = tok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            xg[i] = ok ? (unsigned)(img * p.Cin + ci) * plane + (unsigned)(iy * p.W + ix) : 0x30000000u;
+        }
+        ubase = (unsigned)((mb * NWAVE + wave) * p.nchunk) * (6 * 64 * 4) + (unsigned)lane * 4;
+    };
+
+    float rx[NXE], rx1[NXE];
+    auto load_x = [&](float (&r)[NXE], int chunk) {
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) r[i] = ldg1(rX, xg[i] == 0x30000000u ? 0x30000000u : xg[i] + (unsigned)(chunk * CI) * plane);
+    };
+    auto store_x = [&](const float (&r)[NXE], float* Xd) {
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) Xd[tid + NTHR * i] = r[i];
+    };
+    auto load_a = [&](f32x4 (&au)[6], int chunk) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) au[i] = ldg4(rU, ubase + (unsigned)(chunk * 6 + i) * 256u);
+    };
+    auto transform = [&](const float* Xc, float* Vd) {      // V = B^t d B of the phase (kp,kq) of channel kci, this tile
+        if (xform) {
+            const float* px = Xc + (kci * 36 + kp * 6 + kq) * NT + (tid & 31);
+            float d[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) d[i][j] = px[((2 * i) * 6 + 2 * j) * NT];
+            float t[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { t[0][j] = d[0][j] - d[1][j]; t[1][j] = d[1][j]; t[2][j] = d[2][j] - d[1][j]; }
+            float* pv = Vd + kc * NT + (tid & 31);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                pv[(i * 3 + 0) * KC * NT] = t[i][0] - t[i][1];
+                pv[(i * 3 + 1) * KC * NT] = t[i][1];
+                pv[(i * 3 + 2) * KC * NT] = t[i][2] - t[i][1];
+            }
+        }
+    };
+
+    f32x16 acc[3];
+    auto step = [&](int c, int cur, const f32x4 (&ac)[6], f32x4 (&an)[6]) {
+        const int nxt = cur ^ 1;
+        const float* Vc = Vs + cur * VSZ;
+        const float* vb[3];
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu) vb[uu] = Vc + (uxi[uu] * KC + h) * NT + l31;
+        load_a(an, c + 1);
+        store_x(rx, Xs + cur * XSZ);                        // X(c+2)
+        load_x(rx, c + 3);
+        transform(Xs + nxt * XSZ, Vs + nxt * VSZ);          // X(c+1) -> V(c+1)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int uu = 0; uu < 3; ++uu) {
+                const int v = uu * 8 + kk;
+                acc[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[v >> 2][v & 3], vb[uu][2 * kk * NT], acc[uu], 0, 0, 0);
+            }
+        __syncthreads();
+    };
+
+    f32x4 a0[6], a1[6];
+    int item = blockIdx.x;
+    if (item < p.nitem) {
+        plan(item);
+        load_x(rx, c_beg); load_x(rx1, c_beg + 1); load_a(a0, c_beg);
+    }
+    for (; item < p.nitem; item += gridDim.x) {
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[uu][r] = 0.f;
+        __syncthreads();                                    // the previous item's epilogue reads of Ts are done
+        store_x(rx, Xs);
+        store_x(rx1, Xs + XSZ);
+        load_x(rx, c_beg + 2);
+        __syncthreads();
+        transform(Xs, Vs);
+        __syncthreads();
+        for (int c = c_beg; c < c_end; c += 2) {            // (c_end - c_beg) is even (host)
+            step(c, 0, a0, a1);
+            step(c + 1, 1, a1, a0);
+        }
+        const int cm0 = m0, ctb = tb, csp = sp;
+        if (item + (int)gridDim.x < p.nitem) {
+            plan(item + gridDim.x);
+            load_x(rx, c_beg); load_x(rx1, c_beg + 1); load_a(a0, c_beg);
+        }
+        // ---- output transform: M (9 positions) -> Ts -> Y = A^t M A, A^t = [[1,1,0],[0,1,1]]
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ts[(uxi[uu] * BM + umt[uu] * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * NT + l31] = acc[uu][r];
+        __syncthreads();
+        float* __restrict__ Yd = p.nsplit > 1 ? p.ws + (size_t)csp * p.slab : p.Y;
+        for (int idx = tid; idx < BM * NT; idx += NTHR) {
+            const int m = idx >> 5, tl = idx & 31;
+            float M[9];
+#pragma unroll
+            for (int x = 0; x < 9; ++x) M[x] = Ts[x * BM * NT + idx];
+            const int tile = ctb * NT + tl;
+            if (cm0 + m < p.Cout && tile < p.ntile) {
+                const int img = tile / tpi, rem = tile - img * tpi;
+                const int ty = rem / tx_n, tx = rem - ty * tx_n;
+                float* o = Yd + ((size_t)(img * p.Cout + cm0 + m)) * oplane + (size_t)(2 * ty) * p.OW + 2 * tx;
+                *(float2*)o = make_float2(M[0] + M[1] + M[3] + M[4], M[1] + M[2] + M[4] + M[5]);
+                *(float2*)(o + p.OW) = make_float2(M[3] + M[4] + M[6] + M[7], M[4] + M[5] + M[7] + M[8]);
+            }
+        }
+    }
+}
+
+// y[i] = sum_s ws[s*slab + i] (fixed order)
+__global__ __launch_bounds__(256) void wino22_reduce(const float* __restrict__ ws, float* __restrict__ y, long long n,
+                                                     long long slab, int nsplit) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = *(const f32x4*)(ws + i);
+    for (int k = 1; k < nsplit; ++k) s += *(const f32x4*)(ws + (size_t)k * slab + i);
+    *(f32x4*)(y + i) = s;
+}
+
+}  // namespace
+
+static int g_w22_min_tiles = -1;
+extern "C" int mogan_wino22_debug_min_tiles(int n) { g_w22_min_tiles = n; return 0; }
+
+// ---- internal entry point (hidden visibility): 1 = handled, 0 = not eligible, < 0 = error ----------------------------
+// y (B,Cout,H/2,W/2) = conv4x4 s2 p1 (x (B,Cin,H,W), w (Cout,Cin,4,4)).  Workspace: the transformed weights
+// (ceil(Cout/128)*128 * 36 * Cin floats) followed by nsplit output slabs when the K range is split.
+int mogan_wino22_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                         int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+    static const int on = getenv("MOGAN_WINO22") ? atoi(getenv("MOGAN_WINO22")) : 1;
+    if (!on || !(KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0)) return 0;
+    if ((Cin % (2 * CI)) || Cin < 64 || Cout < 96 || (H % 4) || (W % 4)) return 0;
+    if ((((uintptr_t)y) & 15) != 0) return 0;
+    const int OH = H / 2, OW = W / 2;
+    const long long mbs = (Cout + BM - 1) / BM;
+    const size_t ubytes = (size_t)mbs * BM * 36 * Cin * sizeof(float);
+    const long long ynum = (long long)B * Cout * OH * OW;
+    if ((long long)B * Cin * H * W >= (1ll << 29) || (long long)Cin * H * W >= (1ll << 26) || ynum >= (1ll << 30) ||
+        ubytes >= (1ull << 31))
+        return 0;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    W22P p{};
+    p.ntile = B * (OH / 2) * (OW / 2);
+    // The transformed weights are 36/16 of the raw ones and are rebuilt per call (write + read of 36 x Cout x Cin floats): that
+    // only pays when every weight meets many tiles.  Measured at B = 16 (TFLOP/s direct-equivalent, this kernel vs the
+    // implicit GEMM): 4096 tiles 156 vs 90, 1024 tiles 135 vs 99 / 105 vs 88, 256 tiles 73 vs 98 / 28 vs 88.
+    if (g_w22_min_tiles < 0) g_w22_min_tiles = getenv("MOGAN_WINO22_MIN_TILES") ? atoi(getenv("MOGAN_WINO22_MIN_TILES")) : 1024;
+    if (p.ntile < g_w22_min_tiles) return 0;
+    p.ntb = (p.ntile + NT - 1) / NT; p.mbs = (int)mbs; p.nchunk = Cin / CI;
+    const long long blocks = (long long)p.ntb * mbs;
+    // K-split: the persistent grid runs ceil(items / ncu) rounds; pick the split count whose last round is fullest
+    // (a partial round costs a whole one), a little in favour of fewer splits (partial slabs to write and reduce)
+    int nsplit = 1; double best = 1e30;
+    for (int s = 1; s <= 16 && s <= std::max(1, p.nchunk / 8); ++s) {
+        const double items = (double)blocks * s, rounds = (double)((blocks * s + ncu - 1) / ncu);
+        const double cost = rounds * ncu / items * (1.0 + 0.03 * (s - 1));
+        if (cost < best - 1e-9) { best = cost; nsplit = s; }
+    }
+    const size_t ubytes_al = (ubytes + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < ubytes_al) return 0;
+    if (nsplit > 1) {
+        const size_t fit = (ws_bytes - ubytes_al) / ((size_t)ynum * sizeof(float));
+        if (fit < 2) nsplit = 1; else nsplit = (int)std::min<size_t>(nsplit, fit);
+    }
+    int cps = (p.nchunk + nsplit - 1) / nsplit; cps += cps & 1;         // even chunk count per split
+    nsplit = (p.nchunk + cps - 1) / cps;
+    p.nsplit = nsplit; p.cps = cps; p.nitem = (int)(blocks * nsplit); p.slab = ynum;
+    p.X = x; p.U = (const float*)ws; p.Y = y; p.ws = (float*)((char*)ws + ubytes_al);
+    p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.B = B;
+    p.x_bytes = (unsigned)(4ull * B * Cin * H * W); p.u_bytes = (unsigned)ubytes;
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wino22_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout, Cin);
+    hipLaunchKernelGGL(wino22_fwd_kernel, dim3((unsigned)std::min<long long>(p.nitem, ncu)), dim3(NTHR), 0, st, p);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(wino22_reduce, dim3((unsigned)((ynum / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, y,
+                           ynum, ynum, nsplit);
+    return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+}

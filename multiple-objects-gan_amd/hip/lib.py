@@ -20,6 +20,7 @@ SIGNATURES = {
     "mogan_abi_version": [],
     "mogan_gemm_set_split_target": [I],
     "mogan_gemm_debug_force": [I, I],
+    "mogan_wino22_debug_min_tiles": [I],
     "mogan_gemm_tune_set": [I, I, I, I, I, I, I],
     "mogan_gemm_tune_clear": [],
     "mogan_prof_enable": [I],

@@ -63,6 +63,11 @@ CONV_CASES = [
     (3, 48, 12, 64, 100, (3, 3), 1, (1, 1), 0),    # ragged M (100 = 96 + 4), odd chunk pairs, image borders everywhere
     (1, 96, 32, 32, 192, (3, 3), 1, (1, 1), 0),    # ResBlock widths
     (2, 64, 16, 96, 64, (3, 3), 1, (1, 1), 0),     # dgrad also Winograd (Cout % 16 == 0, Cin >= 64)
+    # fused Winograd F(2x2,2x2) for 4x4 s2 p1 (Cin % 8 == 0, >= 64 in / 96 out channels, H, W % 4 == 0): forward
+    (4, 72, 8, 8, 130, (4, 4), 2, (1, 1), 0),      # 4x4 outputs: a block spans 8 images; ragged M (130 = 128 + 2)
+    (2, 64, 16, 24, 100, (4, 4), 2, (1, 1), 0),    # non-square, partly filled tile block, M < 128
+    (1, 128, 64, 64, 128, (4, 4), 2, (1, 1), 0),   # several tile blocks of one image
+    (16, 256, 8, 8, 192, (4, 4), 2, (1, 1), 0),    # few tiles, long K: the K range is split (partial slabs + reduce)
     # shapes that take the direct (halo-tile) kernel when no tile config is forced (>= 64 channels each side)
     (2, 64, 32, 32, 72, (3, 3), 1, (1, 1), 0),     # 3x3 s1, Cw=32, ragged M (forward: Winograd; dgrad: direct, 72 % 16 != 0)
     (2, 72, 32, 32, 64, (3, 3), 1, (1, 1), 0),     # Cin % 16 != 0: forward stays on the direct kernel (Cw=32, 16-byte halo loads)
@@ -87,6 +92,7 @@ def _conv_ref(x, w, stride, pad, up):
 def test_conv2d_fwd_dgrad_wgrad(case, force):
     B, Cin, H, W, Cout, k, s, pad, up = case
     lib.load().mogan_gemm_debug_force(*force)
+    lib.load().mogan_wino22_debug_min_tiles(1)          # small shapes through the 4x4-s2 Winograd kernel too
     try:
         x = T("cx%s" % (case,), (B, Cin, H, W)).requires_grad_(True)
         w = T("cw%s" % (case,), (Cout, Cin) + k, 0.2).requires_grad_(True)
@@ -103,6 +109,7 @@ def test_conv2d_fwd_dgrad_wgrad(case, force):
         _check(wd.grad, w.grad, what="wgrad")
     finally:
         lib.load().mogan_gemm_debug_force(-1, 0)
+        lib.load().mogan_wino22_debug_min_tiles(-1)
 
 
 UP_CASES = [(2, 8, 8, 8, 16), (3, 5, 9, 7, 7), (2, 64, 16, 16, 64), (2, 96, 32, 32, 96), (1, 72, 64, 64, 100),

@@ -761,6 +761,12 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
+    if (g_force_cfg < 0) {
+        mogan_prof_begin(5, 2, (9.0 / 16.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
+        rc = mogan_wino22_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(5, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
         rc = mogan_dconv_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);

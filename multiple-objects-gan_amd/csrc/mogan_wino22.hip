@@ -67,6 +67,40 @@ __global__ __launch_bounds__(256) void wino22_weight_kernel(const float* __restr
         }
 }
 
+// data-gradient weights: for output phase (py,px) the 2x2 filter g[a][b] = w[co][ci][3-2a-py][3-2b-px], M = ci, K = co
+// (16 co per chunk, k = co % 16).  Same lane order as above, the four phases stored one after the other:
+// U2[phase][mb(ci)][wave][chunk(co)][i][lane][e].
+__global__ __launch_bounds__(256) void wino22_weight_dg_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
+                                                               int Cin) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
+    const float* g = w + i * 16;
+    const int nchunk = Cout / KC, mbs = (Cin + BM - 1) / BM;
+    const int mb = ci / BM, m = ci - mb * BM, mt = m >> 5, l31 = m & 31;
+    const int chunk = co / KC, k = co - chunk * KC, kk = k >> 1, h = k & 1;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const float g00 = g[(3 - py) * 4 + 3 - px], g01 = g[(3 - py) * 4 + 1 - px];
+            const float g10 = g[(1 - py) * 4 + 3 - px], g11 = g[(1 - py) * 4 + 1 - px];
+            const float t[3][2] = {{g00, g01}, {g00 + g10, g01 + g11}, {g10, g11}};
+            const int phase = py * 2 + px;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float u3[3] = {t[a][0], t[a][0] + t[a][1], t[a][1]};
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int unit = (a * 3 + b) * 4 + mt, wv = unit / 3, uu = unit - wv * 3;
+                    const int v = uu * 8 + kk;
+                    U[((((size_t)((phase * mbs + mb) * NWAVE + wv) * nchunk + chunk) * 6 + (v >> 2)) * 64 + h * 32 + l31) * 4 +
+                      (v & 3)] = u3[b];
+                }
+            }
+        }
+}
+
 struct W22P {
     const float* X; const float* U; float* Y; float* ws;
     int Cin, H, W, Cout, OH, OW, B;
@@ -75,7 +109,13 @@ struct W22P {
     unsigned x_bytes, u_bytes;
 };
 
-__global__ __launch_bounds__(NTHR) void wino22_fwd_kernel(const W22P p) {
+// DG = false: forward.  X = conv input (B,Cin,H,W), K channels = (ci, phase), window 6x6 at (4ty-1, 4tx-1).
+// DG = true : data gradient, one output phase (py,px) per work item: dX[2y+py][2x+px] is a plain 2x2 stride-1 convolution of
+//             dY with the taps w[3-2a-py][3-2b-px].  X = dY (B,Cout,OH,OW), K channels = co (16 per chunk), window 3x3 at
+//             (2ty-1+py, 2tx-1+px) on the phase grid (OH x OW positions), M = ci; p.Cin / p.H / p.W are the K-channel count
+//             and the dims of X, p.Cout / p.OH / p.OW the M count and the dims of the phase grid.
+template <bool DG>
+__global__ __launch_bounds__(NTHR) void wino22_kernel(const W22P p) {
     __shared__ __attribute__((aligned(16))) float raw[TSZ];             // Ts; the staging images alias its head
     float* const Xs = raw;                                              // [2][CI][6][6][tile]
     float* const Vs = raw + 2 * XSZ;                                    // [2][xi][k][tile]
@@ -99,10 +139,11 @@ __global__ __launch_bounds__(NTHR) void wino22_fwd_kernel(const W22P p) {
     for (int uu = 0; uu < 3; ++uu) { const int u = 3 * wave + uu; uxi[uu] = u >> 2; umt[uu] = u & 3; }
 
     // per work item: (mb, tile block tb, split sp)
-    unsigned xg[NXE]; unsigned ubase; int c_beg = 0, c_end = 0, m0 = 0, tb = 0, sp = 0;
+    unsigned xg[NXE]; unsigned ubase; int c_beg = 0, c_end = 0, m0 = 0, tb = 0, sp = 0, ph = 0;
     auto plan = [&](int item) {
         sp = item % p.nsplit; const int t2 = item / p.nsplit;
-        tb = t2 % p.ntb; const int mb = t2 / p.ntb;
+        tb = t2 % p.ntb; const int t3 = t2 / p.ntb;
+        const int mb = t3 % p.mbs; ph = t3 / p.mbs;          // (forward: one "phase" item class)
         m0 = mb * BM;
         c_beg = sp * p.cps; c_end = min(p.nchunk, c_beg + p.cps);
         const int tile = tb * NT + (tid & 31);
@@ -111,19 +152,25 @@ __global__ __launch_bounds__(NTHR) void wino22_fwd_kernel(const W22P p) {
         const int ty = rem / tx_n, tx = rem - ty * tx_n;
 #pragma unroll
         for (int i = 0; i < NXE; ++i) {
-            const int rest = (tid >> 5) + (NTHR / 32) * i;              // (ci, r6, c6) of this thread's i-th element
-            const int ci = rest / 36, r = rest - ci * 36, r6 = r / 6, c6 = r - r6 * 6;
-            const int iy = 4 * ty - 1 + r6, ix = 4 * tx - 1 + c6;
+            const int rest = (tid >> 5) + (NTHR / 32) * i;              // (channel, row, column) of this thread's i-th element
+            int ci, iy, ix;
+            if constexpr (DG) {
+                ci = rest / 9; const int r = rest - ci * 9, r3 = r / 3, c3 = r - r3 * 3;
+                iy = 2 * ty - 1 + (ph >> 1) + r3; ix = 2 * tx - 1 + (ph & 1) + c3;
+            } else {
+                ci = rest / 36; const int r = rest - ci * 36, r6 = r / 6, c6 = r - r6 * 6;
+                iy = 4 * ty - 1 + r6; ix = 4 * tx - 1 + c6;
+            }
             const bool ok = tok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             xg[i] = ok ? (unsigned)(img * p.Cin + ci) * plane + (unsigned)(iy * p.W + ix) : 0x30000000u;
         }
-        ubase = (unsigned)((mb * NWAVE + wave) * p.nchunk) * (6 * 64 * 4) + (unsigned)lane * 4;
+        ubase = (unsigned)(((ph * p.mbs + mb) * NWAVE + wave) * p.nchunk) * (6 * 64 * 4) + (unsigned)lane * 4;
     };
 
     float rx[NXE], rx1[NXE];
     auto load_x = [&](float (&r)[NXE], int chunk) {
 #pragma unroll
-        for (int i = 0; i < NXE; ++i) r[i] = ldg1(rX, xg[i] == 0x30000000u ? 0x30000000u : xg[i] + (unsigned)(chunk * CI) * plane);
+        for (int i = 0; i < NXE; ++i) r[i] = ldg1(rX, xg[i] == 0x30000000u ? 0x30000000u : xg[i] + (unsigned)(chunk * (DG ? KC : CI)) * plane);
     };
     auto store_x = [&](const float (&r)[NXE], float* Xd) {
 #pragma unroll
@@ -135,12 +182,20 @@ __global__ __launch_bounds__(NTHR) void wino22_fwd_kernel(const W22P p) {
     };
     auto transform = [&](const float* Xc, float* Vd) {      // V = B^t d B of the phase (kp,kq) of channel kci, this tile
         if (xform) {
-            const float* px = Xc + (kci * 36 + kp * 6 + kq) * NT + (tid & 31);
             float d[3][3];
+            if constexpr (DG) {
+                const float* px = Xc + (kc * 9) * NT + (tid & 31);
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) d[i][j] = px[((2 * i) * 6 + 2 * j) * NT];
+                    for (int j = 0; j < 3; ++j) d[i][j] = px[(i * 3 + j) * NT];
+            } else {
+                const float* px = Xc + (kci * 36 + kp * 6 + kq) * NT + (tid & 31);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) d[i][j] = px[((2 * i) * 6 + 2 * j) * NT];
+            }
             float t[3][3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) { t[0][j] = d[0][j] - d[1][j]; t[1][j] = d[1][j]; t[2][j] = d[2][j] - d[1][j]; }
@@ -197,7 +252,7 @@ __global__ __launch_bounds__(NTHR) void wino22_fwd_kernel(const W22P p) {
             step(c, 0, a0, a1);
             step(c + 1, 1, a1, a0);
         }
-        const int cm0 = m0, ctb = tb, csp = sp;
+        const int cm0 = m0, ctb = tb, csp = sp, cph = ph;
         if (item + (int)gridDim.x < p.nitem) {
             plan(item + gridDim.x);
             load_x(rx, c_beg); load_x(rx1, c_beg + 1); load_a(a0, c_beg);
@@ -219,9 +274,18 @@ __global__ __launch_bounds__(NTHR) void wino22_fwd_kernel(const W22P p) {
             if (cm0 + m < p.Cout && tile < p.ntile) {
                 const int img = tile / tpi, rem = tile - img * tpi;
                 const int ty = rem / tx_n, tx = rem - ty * tx_n;
-                float* o = Yd + ((size_t)(img * p.Cout + cm0 + m)) * oplane + (size_t)(2 * ty) * p.OW + 2 * tx;
-                *(float2*)o = make_float2(M[0] + M[1] + M[3] + M[4], M[1] + M[2] + M[4] + M[5]);
-                *(float2*)(o + p.OW) = make_float2(M[3] + M[4] + M[6] + M[7], M[4] + M[5] + M[7] + M[8]);
+                const float y00 = M[0] + M[1] + M[3] + M[4], y01 = M[1] + M[2] + M[4] + M[5];
+                const float y10 = M[3] + M[4] + M[6] + M[7], y11 = M[4] + M[5] + M[7] + M[8];
+                if constexpr (DG) {     // phase-grid position (2ty+a, 2tx+b) -> dX[2(2ty+a) + py][2(2tx+b) + px]
+                    const int WX = 2 * p.OW;
+                    float* o = Yd + ((size_t)(img * p.Cout + cm0 + m)) * (4 * (size_t)oplane) +
+                               (size_t)(4 * ty + (cph >> 1)) * WX + 4 * tx + (cph & 1);
+                    o[0] = y00; o[2] = y01; o[2 * WX] = y10; o[2 * WX + 2] = y11;
+                } else {
+                    float* o = Yd + ((size_t)(img * p.Cout + cm0 + m)) * oplane + (size_t)(2 * ty) * p.OW + 2 * tx;
+                    *(float2*)o = make_float2(y00, y01);
+                    *(float2*)(o + p.OW) = make_float2(y10, y11);
+                }
             }
         }
     }
@@ -295,9 +359,66 @@ int mogan_wino22_fwd_try(const float* x, const float* w, float* y, int B, int Ci
     p.x_bytes = (unsigned)(4ull * B * Cin * H * W); p.u_bytes = (unsigned)ubytes;
     const long long n = (long long)Cout * Cin;
     hipLaunchKernelGGL(wino22_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout, Cin);
-    hipLaunchKernelGGL(wino22_fwd_kernel, dim3((unsigned)std::min<long long>(p.nitem, ncu)), dim3(NTHR), 0, st, p);
+    hipLaunchKernelGGL(wino22_kernel<false>, dim3((unsigned)std::min<long long>(p.nitem, ncu)), dim3(NTHR), 0, st, p);
     if (nsplit > 1)
         hipLaunchKernelGGL(wino22_reduce, dim3((unsigned)((ynum / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, y,
                            ynum, ynum, nsplit);
+    return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+}
+
+// dx (B,Cin,H,W) = data gradient of conv4x4 s2 p1 for dy (B,Cout,H/2,W/2): four output phases, one work-item class each
+int mogan_wino22_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                           int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+    static const int on = getenv("MOGAN_WINO22") ? atoi(getenv("MOGAN_WINO22")) : 1;
+    static const int dg_on = getenv("MOGAN_WINO22_DGRAD") ? atoi(getenv("MOGAN_WINO22_DGRAD")) : 1;
+    if (!on || !dg_on || !(KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0)) return 0;
+    if ((Cout % (2 * KC)) || Cout < 64 || Cin < 96 || (H % 4) || (W % 4)) return 0;
+    const int OH = H / 2, OW = W / 2;
+    // measured (B = 16, TFLOP/s direct-equivalent): 144 vs 99 and 107 vs 99 at 16x16 phase grids (there the alternative is the
+    // implicit GEMM), but 123 vs 121 / 107 vs 111 at 32x32 / 64x64, where the direct 2x2-phase kernel runs: only take the former
+    static const int max_ow = getenv("MOGAN_WINO22_DGRAD_MAXOW") ? atoi(getenv("MOGAN_WINO22_DGRAD_MAXOW")) : 16;
+    if (g_w22_min_tiles != 1 && OW > max_ow) return 0;          // (the kernel tests lower min_tiles to 1 and take everything)
+    const long long mbs = (Cin + BM - 1) / BM;
+    const size_t ubytes = (size_t)4 * mbs * BM * 9 * Cout * sizeof(float);
+    const long long xnum = (long long)B * Cin * H * W;
+    if ((long long)B * Cout * OH * OW >= (1ll << 29) || (long long)Cout * OH * OW >= (1ll << 26) || xnum >= (1ll << 30) ||
+        ubytes >= (1ull << 31))
+        return 0;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    W22P p{};
+    p.ntile = B * (OH / 2) * (OW / 2);
+    if (g_w22_min_tiles < 0) g_w22_min_tiles = getenv("MOGAN_WINO22_MIN_TILES") ? atoi(getenv("MOGAN_WINO22_MIN_TILES")) : 1024;
+    if (p.ntile < g_w22_min_tiles) return 0;
+    p.ntb = (p.ntile + NT - 1) / NT; p.mbs = (int)mbs; p.nchunk = Cout / KC;
+    const long long blocks = (long long)p.ntb * mbs * 4;
+    int nsplit = 1; double best = 1e30;
+    for (int s = 1; s <= 16 && s <= std::max(1, p.nchunk / 8); ++s) {
+        const double items = (double)blocks * s, rounds = (double)((blocks * s + ncu - 1) / ncu);
+        const double cost = rounds * ncu / items * (1.0 + 0.03 * (s - 1));
+        if (cost < best - 1e-9) { best = cost; nsplit = s; }
+    }
+    const size_t ubytes_al = (ubytes + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < ubytes_al) return 0;
+    if (nsplit > 1) {
+        const size_t fit = (ws_bytes - ubytes_al) / ((size_t)xnum * sizeof(float));
+        if (fit < 2) nsplit = 1; else nsplit = (int)std::min<size_t>(nsplit, fit);
+    }
+    int cps = (p.nchunk + nsplit - 1) / nsplit; cps += cps & 1;
+    nsplit = (p.nchunk + cps - 1) / cps;
+    p.nsplit = nsplit; p.cps = cps; p.nitem = (int)(blocks * nsplit); p.slab = xnum;
+    p.X = dy; p.U = (const float*)ws; p.Y = dx; p.ws = (float*)((char*)ws + ubytes_al);
+    p.Cin = Cout; p.H = OH; p.W = OW; p.Cout = Cin; p.OH = OH; p.OW = OW; p.B = B;    // K channels / dims of dY, M = ci, phase grid
+    p.x_bytes = (unsigned)(4ull * B * Cout * OH * OW); p.u_bytes = (unsigned)ubytes;
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wino22_weight_dg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout, Cin);
+    hipLaunchKernelGGL(wino22_kernel<true>, dim3((unsigned)std::min<long long>(p.nitem, ncu)), dim3(NTHR), 0, st, p);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(wino22_reduce, dim3((unsigned)((xnum / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, dx,
+                           xnum, xnum, nsplit);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }

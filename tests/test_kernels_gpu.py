@@ -68,6 +68,7 @@ CONV_CASES = [
     (2, 64, 16, 24, 100, (4, 4), 2, (1, 1), 0),    # non-square, partly filled tile block, M < 128
     (1, 128, 64, 64, 128, (4, 4), 2, (1, 1), 0),   # several tile blocks of one image
     (16, 256, 8, 8, 192, (4, 4), 2, (1, 1), 0),    # few tiles, long K: the K range is split (partial slabs + reduce)
+    (3, 104, 12, 20, 64, (4, 4), 2, (1, 1), 0),    # data gradient through it (Cout % 32 == 0, Cin >= 96): ragged M = 104, non-square
     # shapes that take the direct (halo-tile) kernel when no tile config is forced (>= 64 channels each side)
     (2, 64, 32, 32, 72, (3, 3), 1, (1, 1), 0),     # 3x3 s1, Cw=32, ragged M (forward: Winograd; dgrad: direct, 72 % 16 != 0)
     (2, 72, 32, 32, 64, (3, 3), 1, (1, 1), 0),     # Cin % 16 != 0: forward stays on the direct kernel (Cw=32, 16-byte halo loads)

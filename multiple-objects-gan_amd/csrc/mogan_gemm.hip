@@ -712,7 +712,7 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
     if (g_force_cfg < 0) {          // 3x3 s1 p1 at >= 32 channels: fused Winograd F(2x2,3x3), 2.25x fewer multiplies
         // (recorded flops = the multiplies the kernel executes: 16 per 2x2 outputs instead of 36)
         mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
-        rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 0, ws, ws_bytes, stream);
+        rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 0, nullptr, nullptr, 0, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
@@ -741,6 +741,12 @@ int mogan_conv2d_affine_fwd(const float* x, const float* w, const float* scale, 
                             void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0); if (rc) return rc;
     if (!scale || !shift) return MOGAN_ERR_SHAPE;
+    if (g_force_cfg < 0) {          // the trunk's 3x3 s1 layers on well-filled grids (147x147, 71x71): fused Winograd
+        mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
+        rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0, 0, scale, shift, relu, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
@@ -757,7 +763,7 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
     }
     if (g_force_cfg < 0) {
         mogan_prof_begin(5, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
-        rc = mogan_wino_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 1, ws, ws_bytes, stream);
+        rc = mogan_wino_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 1, nullptr, nullptr, 0, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }

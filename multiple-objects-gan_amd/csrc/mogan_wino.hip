@@ -74,9 +74,13 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+// (H, W) = input dims, (OH, OW) = output dims = (H, W) + 2 pad - 2 (pad 0 / 1 / 2; ragged tiles are masked), optional fused
+// per-channel epilogue y = act(scale[co] * y + shift[co]) (the frozen BN + ReLU of the Inception trunk)
 __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__ X, const float* __restrict__ U,
-                                                       float* __restrict__ Y, int Cin, int H, int W, int Cout, int tiles_x,
-                                                       int tiles_y, int ntile, int nimg, unsigned x_bytes, unsigned u_bytes) {
+                                                       float* __restrict__ Y, int Cin, int H, int W, int Cout, int OH, int OW,
+                                                       int pad, int tiles_x, int tiles_y, int ntile, int nimg,
+                                                       const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
+                                                       int ep_relu, unsigned x_bytes, unsigned u_bytes) {
     constexpr int XSZ = CK * XR * XCP, VSZ = 16 * CK * NT;
     __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ + 4];      // + a dump slot for the idle staging lanes
     __shared__ __attribute__((aligned(16))) float Vs[2 * VSZ];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
         const int c = e / (XR * XC), r = e - c * (XR * XC);
         const int hy = r / XC, hx = r - hy * XC;
         xl[i] = e < CK * XR * XC ? c * (XR * XCP) + hy * XCP + hx : -1;
-        xhy[i] = e < CK * XR * XC ? hy - 1 : -0x10000; xhx[i] = hx - 1;
+        xhy[i] = e < CK * XR * XC ? hy - pad : -0x10000; xhx[i] = hx - pad;
         xc[i] = (unsigned)c * plane;
     }
     const int th = tid >> 8, tc = (tid >> 5) & 7, tt = tid & 31, tty = tt >> 4, ttx = tt & 15;
@@ -260,10 +264,28 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
             const int idx = tid + 512 * q;
             const int m = idx >> 5, tl = idx & 31;
             const int oy = coy0 + 2 * (tl >> 4), ox = cox0 + 2 * (tl & 15);
-            if (cm0 + m < Cout && oy < H && ox < W) {
-                float* o = Y + ((size_t)(cimg * Cout + cm0 + m) * H + oy) * W + ox;
-                *(float2*)o = make_float2(yreg[q][0][0], yreg[q][0][1]);
-                *(float2*)(o + W) = make_float2(yreg[q][1][0], yreg[q][1][1]);
+            if (cm0 + m < Cout && oy < OH && ox < OW) {
+                float v[2][2] = {{yreg[q][0][0], yreg[q][0][1]}, {yreg[q][1][0], yreg[q][1][1]}};
+                if (ep_scale != nullptr) {
+                    const float sc = ep_scale[cm0 + m], sh = ep_shift[cm0 + m];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            v[a][b] = fmaf(v[a][b], sc, sh);
+                            if (ep_relu) v[a][b] = fmaxf(v[a][b], 0.f);
+                        }
+                }
+                float* o = Y + ((size_t)(cimg * Cout + cm0 + m) * OH + oy) * OW + ox;
+                const bool y1 = oy + 1 < OH;
+                if ((OW & 1) == 0) {                          // ox is even: both columns inside, 8-byte aligned
+                    *(float2*)o = make_float2(v[0][0], v[0][1]);
+                    if (y1) *(float2*)(o + OW) = make_float2(v[1][0], v[1][1]);
+                } else {
+                    const bool x1 = ox + 1 < OW;
+                    o[0] = v[0][0]; if (x1) o[1] = v[0][1];
+                    if (y1) { o[OW] = v[1][0]; if (x1) o[OW + 1] = v[1][1]; }
+                }
             }
         }
         // (the next tile's store_x / transform touch Xs / Vs only; Ts is rewritten after two more barriers)
@@ -493,24 +515,30 @@ __global__ __launch_bounds__(64) void wino_wgrad_finish(const float* __restrict_
 static int g_wino = -1;
 
 int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
-                   int stride, int ph, int pw, int up, int dgrad, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift, int ep_relu,
+                   void* ws, size_t ws_bytes, hipStream_t st) {
     if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
-    if (!g_wino || !(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0)) return 0;
+    if (!g_wino || !(KH == 3 && KW == 3 && stride == 1 && ph == pw && (ph == 0 || ph == 1) && up == 0)) return 0;
     const int Kin = dgrad ? Cout : Cin, Kout = dgrad ? Cin : Cout;       // channels the kernel reduces over / produces
-    if ((Kin % (2 * CK)) || Kin < 32 || Kout < 64 || (H % (2 * TROWS)) || (W % (2 * TCOLS))) return 0;
-    if ((((uintptr_t)out) & 7) != 0) return 0;
+    // conv: (H, W) -> (H + 2p - 2); its data gradient runs over dY (the smaller grid) with pad 2 - p and produces (H, W)
+    const int cH = H + 2 * ph - 2, cW = W + 2 * pw - 2;
+    const int iH = dgrad ? cH : H, iW = dgrad ? cW : W, oH = dgrad ? H : cH, oW = dgrad ? W : cW, pad = dgrad ? 2 - ph : ph;
+    if (cH < 2 || cW < 2 || (Kin % (2 * CK)) || Kin < 32 || Kout < 64) return 0;
+    if (((oW & 1) == 0) && (((uintptr_t)out) & 7) != 0) return 0;
+    const int tiles_x = (oW + 2 * TCOLS - 1) / (2 * TCOLS), tiles_y = (oH + 2 * TROWS - 1) / (2 * TROWS);
+    // ragged grids waste part of every 4 x 32 tile: below 70 % filling the direct kernels win
+    if ((double)oW * oH < 0.7 * (double)tiles_x * 2 * TCOLS * tiles_y * 2 * TROWS) return 0;
     const long long mbs = (Kout + BM - 1) / BM;
     const size_t ubytes = (size_t)mbs * BM * 16 * Kin * sizeof(float);
     // 32-bit byte offsets: input < 2 GiB, and the "reads as zero" sentinel (0xC0000000 bytes) plus a per-image channel
     // offset must neither land inside the buffer nor wrap
-    if ((long long)B * Kin * H * W >= (1ll << 29) || (long long)Kin * H * W >= (1ll << 26) ||
-        (long long)B * Kout * H * W >= (1ll << 30) || ubytes >= (1ull << 31))
+    if ((long long)B * Kin * iH * iW >= (1ll << 29) || (long long)Kin * iH * iW >= (1ll << 26) ||
+        (long long)B * Kout * oH * oW >= (1ll << 30) || ubytes >= (1ull << 31))
         return 0;
     if (!ws || ws_bytes < ubytes) return 0;
     float* U = (float*)ws;
     const long long n = (long long)Cout * Cin;
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad);
-    const int tiles_x = W / (2 * TCOLS), tiles_y = H / (2 * TROWS);
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
@@ -521,8 +549,9 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     if (ntile >= (1ll << 30)) return 0;
     // persistent: one 8-wave block per CU walks the tiles
     dim3 grid((unsigned)std::min<long long>(ntile, ncu));
-    hipLaunchKernelGGL(wino_fwd_kernel, grid, dim3(512), 0, st, in, (const float*)U, out, Kin, H, W, Kout, tiles_x, tiles_y,
-                       (int)ntile, B, (unsigned)(4ull * B * Kin * H * W), (unsigned)ubytes);
+    hipLaunchKernelGGL(wino_fwd_kernel, grid, dim3(512), 0, st, in, (const float*)U, out, Kin, iH, iW, Kout, oH, oW, pad,
+                       tiles_x, tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu, (unsigned)(4ull * B * Kin * iH * iW),
+                       (unsigned)ubytes);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }
 

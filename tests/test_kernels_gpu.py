@@ -63,6 +63,8 @@ CONV_CASES = [
     (3, 48, 12, 64, 100, (3, 3), 1, (1, 1), 0),    # ragged M (100 = 96 + 4), odd chunk pairs, image borders everywhere
     (1, 96, 32, 32, 192, (3, 3), 1, (1, 1), 0),    # ResBlock widths
     (2, 64, 16, 96, 64, (3, 3), 1, (1, 1), 0),     # dgrad also Winograd (Cout % 16 == 0, Cin >= 64)
+    (2, 32, 30, 61, 64, (3, 3), 1, (1, 1), 0),     # ragged grid (odd width: scalar stores), pad 1
+    (2, 80, 29, 63, 96, (3, 3), 1, (0, 0), 0),     # valid convolution (Inception 4a): forward pad 0, data gradient pad 2
     # fused Winograd F(2x2,2x2) for 4x4 s2 p1 (Cin % 8 == 0, >= 64 in / 96 out channels, H, W % 4 == 0): forward
     (4, 72, 8, 8, 130, (4, 4), 2, (1, 1), 0),      # 4x4 outputs: a block spans 8 images; ragged M (130 = 128 + 2)
     (2, 64, 16, 24, 100, (4, 4), 2, (1, 1), 0),    # non-square, partly filled tile block, M < 128

@@ -801,6 +801,12 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
+    if (g_force_cfg < 0) {
+        mogan_prof_begin(6, 2, (9.0 / 16.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, Cin * KH * KW, B * p.OH * p.OW, stream);
+        rc = mogan_wino22_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);
+        mogan_prof_end(rc == 1, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(6, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, Cin * KH * KW, B * p.OH * p.OW, stream);
         rc = mogan_dconv_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);

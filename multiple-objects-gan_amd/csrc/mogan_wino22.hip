@@ -301,6 +301,192 @@ __global__ __launch_bounds__(256) void wino22_reduce(const float* __restrict__ w
     *(f32x4*)(y + i) = s;
 }
 
+
+// ------------------------------------------------------------------------------------------ weight gradient
+// dg_pq = G^t [ sum over tiles (A dY A^t) .* (B^t d_pq B) ] G per input phase: nine GEMMs dU_xi[co][k] = sum_tiles Q_xi[co][tile]
+// V_xi[k][tile], k = (ci, p, q), with the tiles on K.  A block (12 waves) owns 128 co x 64 k (16 ci x 4 phases) for all nine
+// positions -- 72 (position, m-tile, n-tile) units, six per wave -- and walks a contiguous range of K-chunks of 8 tiles.  Per
+// chunk: dY (128 co x 8 tiles x 2x2, from global straight into the threads that transform it) -> Qs[xi][tile][co]; the 6x6
+// windows of 16 input channels -> Xs -> Vs[xi][tile][k]; double buffered, one barrier per chunk.  Partial dU per K-split go
+// to the workspace; wino22_wgrad_finish sums them in order and applies G^t (.) G.
+constexpr int WT = 8, WBM = 128, WBN = 64, WCI = WBN / 4, LDQ2 = WBM + 4, LDV2 = WBN + 4;
+
+__global__ __launch_bounds__(NTHR) void wino22_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                            float* __restrict__ part, int Cin, int H, int W, int Cout,
+                                                            int nchunk, int cps, unsigned y_bytes, unsigned x_bytes) {
+    constexpr int QSZ = 9 * WT * LDQ2, VSZ2 = 9 * WT * LDV2, XSZ2 = WCI * 36 * WT;
+    __shared__ __attribute__((aligned(16))) float Qs[2 * QSZ];
+    __shared__ __attribute__((aligned(16))) float Vs[2 * VSZ2];
+    __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int n0c = blockIdx.x * WCI, m0 = blockIdx.y * WBM, sp = blockIdx.z;
+    const int k_beg = sp * cps, k_end = min(nchunk, k_beg + cps);
+    const int OH = H >> 1, OW = W >> 1, plane = H * W, oplane = OH * OW;
+    const int tx_n = OW >> 1, tpi = tx_n * (OH >> 1);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, (short)0, (int)y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)x_bytes, 0x00020000);
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    // unit u of this wave: (xi, mt) pair = 3*wave + (u >> 1), n-tile = u & 1
+    int uq[3], uv[3];                       // LDS row bases of the three (xi, mt) pairs: A at Qs[xi*WT rows] + mt*32, B at Vs[xi*WT rows]
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+        const int pair = 3 * wave + pr, xi = pair >> 2, mt = pair & 3;
+        uq[pr] = xi * WT * LDQ2 + mt * 32 + l31 + h * LDQ2;
+        uv[pr] = xi * WT * LDV2 + l31 + h * LDV2;
+    }
+
+    const int tl = tid & 7;                 // tile of the chunk this thread serves in every staging role
+    constexpr int NXE = XSZ2 / NTHR;        // 6 window elements per thread
+    static_assert(NXE * NTHR == XSZ2, "staging divides");
+    float rx[NXE]; float2 ry[2][2];
+    int t_img = 0, t_ty = 0, t_tx = 0; bool t_ok = false;
+    auto tile_of = [&](int k) {
+        const int tile = k * WT + tl;
+        t_ok = k < k_end;
+        t_img = tile / tpi; const int rem = tile - t_img * tpi;
+        t_ty = rem / tx_n; t_tx = rem - t_ty * tx_n;
+    };
+    auto load_y = [&](int k) {              // dY 2x2 of (co = p >> 3, this tile) for p = tid, tid + 768
+        tile_of(k);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int pp = tid + NTHR * r, co = pp >> 3;
+            const bool ok = t_ok && pp < WBM * WT && m0 + co < Cout;
+            const unsigned g = (unsigned)(t_img * Cout + m0 + co) * oplane + (unsigned)((2 * t_ty) * OW + 2 * t_tx);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+                ry[r][rr] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rY, ok ? (g + rr * OW) * 4u : 0xFFFFFFF8u, 0, 0));
+        }
+    };
+    auto load_x = [&](int k) {              // element e = tid + 768 i: rest = e >> 3 -> (ci, r6, c6)
+        tile_of(k);
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const int rest = (tid >> 3) + (NTHR / 8) * i;
+            const int ci = rest / 36, r = rest - ci * 36, r6 = r / 6, c6 = r - r6 * 6;
+            const int iy = 4 * t_ty - 1 + r6, ix = 4 * t_tx - 1 + c6;
+            const bool ok = t_ok && n0c + ci < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            rx[i] = ldg1(rX, ok ? (unsigned)(t_img * Cin + n0c + ci) * plane + (unsigned)(iy * W + ix) : 0x30000000u);
+        }
+    };
+    auto store_x = [&](float* Xd) {
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) Xd[tid + NTHR * i] = rx[i];
+    };
+    auto transform_q = [&](float* Qd) {     // Q = A d A^t, A = [[1,0],[1,1],[0,1]]
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int pp = tid + NTHR * r, co = pp >> 3;
+            if (pp < WBM * WT) {
+                const float d00 = ry[r][0].x, d01 = ry[r][0].y, d10 = ry[r][1].x, d11 = ry[r][1].y;
+                const float R[3][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d10, d11}};
+                float* q = &Qd[tl * LDQ2 + co];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    q[(i * 3 + 0) * WT * LDQ2] = R[i][0];
+                    q[(i * 3 + 1) * WT * LDQ2] = R[i][0] + R[i][1];
+                    q[(i * 3 + 2) * WT * LDQ2] = R[i][1];
+                }
+            }
+        }
+    };
+    const int vk = tid >> 3, vci = vk >> 2, vp = (vk >> 1) & 1, vq = vk & 1;     // V role (tid < 512): k = ci*4 + 2p + q
+    auto transform_v = [&](const float* Xc, float* Vd) {
+        if (tid < WBN * WT) {
+            const float* px = Xc + (vci * 36 + vp * 6 + vq) * WT + tl;
+            float d[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) d[i][j] = px[((2 * i) * 6 + 2 * j) * WT];
+            float t[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { t[0][j] = d[0][j] - d[1][j]; t[1][j] = d[1][j]; t[2][j] = d[2][j] - d[1][j]; }
+            float* pv = Vd + tl * LDV2 + vk;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                pv[(i * 3 + 0) * WT * LDV2] = t[i][0] - t[i][1];
+                pv[(i * 3 + 1) * WT * LDV2] = t[i][1];
+                pv[(i * 3 + 2) * WT * LDV2] = t[i][2] - t[i][1];
+            }
+        }
+    };
+
+    if (k_beg < k_end) {
+        load_y(k_beg); load_x(k_beg);
+        store_x(Xs);
+        load_x(k_beg + 1);
+        __syncthreads();
+        transform_q(Qs); transform_v(Xs, Vs);
+        load_y(k_beg + 1);
+        store_x(Xs + XSZ2);
+        load_x(k_beg + 2);
+        __syncthreads();
+        for (int k = k_beg; k < k_end; ++k) {
+            const int cur = (k - k_beg) & 1, nxt = cur ^ 1;
+            const float* Qc = Qs + cur * QSZ;
+            const float* Vc = Vs + cur * VSZ2;
+            transform_q(Qs + nxt * QSZ);                        // dY(k+1)
+            load_y(k + 2);
+            store_x(Xs + cur * XSZ2);                           // X(k+2)
+            load_x(k + 3);
+            transform_v(Xs + nxt * XSZ2, Vs + nxt * VSZ2);      // X(k+1) -> V(k+1)
+#pragma unroll
+            for (int kk = 0; kk < WT / 2; ++kk)
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) {
+                    const float a = Qc[uq[pr] + 2 * kk * LDQ2];
+                    const float b0 = Vc[uv[pr] + 2 * kk * LDV2], b1 = Vc[uv[pr] + 2 * kk * LDV2 + 32];
+                    acc[pr * 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[pr * 2], 0, 0, 0);
+                    acc[pr * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[pr * 2 + 1], 0, 0, 0);
+                }
+            __syncthreads();
+        }
+    }
+    // partial dU[sp][xi][co][4*Cin]
+    const int N4 = 4 * Cin;
+    float* out = part + (size_t)sp * 9 * Cout * N4;
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+        const int pair = 3 * wave + pr, xi = pair >> 2, mt = pair & 3;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = 4 * n0c + nt * 32 + l31;
+                if (m < Cout && n < N4) out[((size_t)xi * Cout + m) * N4 + n] = acc[pr * 2 + nt][r];
+            }
+    }
+}
+
+// dW[co][ci][2a+p][2b+q] (+)= (G^t dU_pq G)[a][b],  G^t = [[1,1,0],[0,1,1]]
+__global__ __launch_bounds__(64) void wino22_wgrad_finish(const float* __restrict__ part, float* __restrict__ dw, int Cout,
+                                                          int Cin, int nsplit, int accumulate) {
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x;          // (co, ci, p, q): i = (co*Cin + ci)*4 + 2p + q
+    const long long n = (long long)Cout * Cin * 4;
+    if (i >= n) return;
+    float u[9];
+#pragma unroll
+    for (int x = 0; x < 9; ++x) u[x] = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* ps = part + (size_t)s * 9 * n + i;
+#pragma unroll
+        for (int x = 0; x < 9; ++x) u[x] += ps[(size_t)x * n];
+    }
+    const int pq = (int)(i & 3), p = pq >> 1, q = pq & 1;
+    float* d = dw + (i >> 2) * 16;
+    const float g00 = u[0] + u[1] + u[3] + u[4], g01 = u[1] + u[2] + u[4] + u[5];
+    const float g10 = u[3] + u[4] + u[6] + u[7], g11 = u[4] + u[5] + u[7] + u[8];
+    float* d00 = d + p * 4 + q; float* d01 = d + p * 4 + 2 + q; float* d10 = d + (2 + p) * 4 + q; float* d11 = d + (2 + p) * 4 + 2 + q;
+    *d00 = (accumulate ? *d00 : 0.f) + g00; *d01 = (accumulate ? *d01 : 0.f) + g01;
+    *d10 = (accumulate ? *d10 : 0.f) + g10; *d11 = (accumulate ? *d11 : 0.f) + g11;
+}
+
 }  // namespace
 
 static int g_w22_min_tiles = -1;
@@ -420,5 +606,47 @@ int mogan_wino22_dgrad_try(const float* dy, const float* w, float* dx, int B, in
     if (nsplit > 1)
         hipLaunchKernelGGL(wino22_reduce, dim3((unsigned)((xnum / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, dx,
                            xnum, xnum, nsplit);
+    return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+}
+
+// dw (Cout,Cin,4,4) (+)= weight gradient of conv4x4 s2 p1; workspace: nsplit * 36 * Cout * Cin floats
+int mogan_wino22_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                           int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    static const int on = getenv("MOGAN_WINO22") ? atoi(getenv("MOGAN_WINO22")) : 1;
+    static const int wg_on = getenv("MOGAN_WINO22_WGRAD") ? atoi(getenv("MOGAN_WINO22_WGRAD")) : 1;
+    if (!on || !wg_on || !(KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0)) return 0;
+    if ((Cin % WCI) || Cin < 64 || Cout < 96 || (H % 4) || (W % 4)) return 0;
+    if ((((uintptr_t)dy) & 7) != 0) return 0;
+    const int OH = H / 2, OW = W / 2;
+    const long long ntile = (long long)B * (OH / 2) * (OW / 2);
+    if (g_w22_min_tiles < 0) g_w22_min_tiles = getenv("MOGAN_WINO22_MIN_TILES") ? atoi(getenv("MOGAN_WINO22_MIN_TILES")) : 1024;
+    if (ntile < g_w22_min_tiles || (ntile % WT) != 0) return 0;
+    if ((long long)B * Cin * H * W >= (1ll << 29) || (long long)B * Cout * OH * OW >= (1ll << 29)) return 0;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const int nchunk = (int)(ntile / WT);
+    const int tiles_mn = ((Cout + WBM - 1) / WBM) * (Cin / WCI);
+    // K-split: fill the last round of 12-wave blocks (one per CU); every split costs a partial dU (36 x Cout x Cin floats)
+    int nsplit = 1; double best = 1e30;
+    for (int sx = 1; sx <= 64 && sx <= std::max(1, nchunk / 4); ++sx) {
+        const double items = (double)tiles_mn * sx, rounds = (double)((tiles_mn * sx + ncu - 1) / ncu);
+        const double cost = rounds * ncu / items * (1.0 + 0.04 * (sx - 1));
+        if (cost < best - 1e-9) { best = cost; nsplit = sx; }
+    }
+    const size_t slab = (size_t)36 * Cout * Cin * sizeof(float);
+    if (!ws || ws_bytes < slab) return 0;
+    if ((size_t)nsplit * slab > ws_bytes) nsplit = (int)(ws_bytes / slab);
+    const int cps = (nchunk + nsplit - 1) / nsplit;
+    nsplit = (nchunk + cps - 1) / cps;
+    dim3 grid((unsigned)(Cin / WCI), (unsigned)((Cout + WBM - 1) / WBM), (unsigned)nsplit);
+    hipLaunchKernelGGL(wino22_wgrad_kernel, grid, dim3(NTHR), 0, st, dy, x, (float*)ws, Cin, H, W, Cout, nchunk, cps,
+                       (unsigned)(4ull * B * Cout * OH * OW), (unsigned)(4ull * B * Cin * H * W));
+    const long long n = (long long)Cout * Cin * 4;
+    hipLaunchKernelGGL(wino22_wgrad_finish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const float*)ws, dw, Cout, Cin,
+                       nsplit, accumulate);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }

@@ -193,6 +193,17 @@ class TrainEngine:
         return errD.detach()
 
     # -- the reference loop body -------------------------------------------------------------------
+    def _phase(self, name):
+        """MOGAN_PHASE_TIMES=1: device-synchronised wall time per phase of the step (diagnostic; serialises the phases)."""
+        if not os.environ.get("MOGAN_PHASE_TIMES"):
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        if getattr(self, "_ph_last", None) is not None:
+            self._ph = getattr(self, "_ph", {})
+            self._ph[self._ph_name] = self._ph.get(self._ph_name, 0.0) + (now - self._ph_last) * 1e3
+        self._ph_last, self._ph_name = now, name
+
     def device_step(self, b):
         """trainer.py:291-342 given the text embeddings; `b` holds device tensors:
         imgs[3], z, eps, words_embs, sent_emb, mask, cap_lens, tm, tmi, label_one_hot."""
@@ -221,6 +232,7 @@ class TrainEngine:
                     real_feat[i] = self._d_real(i, b)
             if ready is not None:
                 cur0.wait_event(ready)
+        self._phase("text+Gfwd")
         if "words_embs" not in b:        # trainer.py:281-289 (eager path: after the fork above)
             b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
         fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"],
@@ -261,6 +273,7 @@ class TrainEngine:
             # host order: the largest D first (its work starts early), the Inception/DAMSM branch right behind it; the
             # tails smallest-first -- the collectives of one process group execute in issue order, and D64's / D128's
             # all-reduce must not queue behind the event of D256's longer backward
+            self._phase("D heads + Inception")
             d_head(order[0])
             s = self.side[nD]
             s.wait_stream(cur)
@@ -282,10 +295,12 @@ class TrainEngine:
                 parts["w_loss"], parts["s_loss"] = w_loss, s_loss
             for i in order[1:]:
                 d_head(i)
+            self._phase("D tails + G-step D fwd")
             for i in order[::-1]:
                 d_tail(i)
             for s in self.side:
                 cur.wait_stream(s)
+            self._phase("G backward")
             self.optG.zero_grad()
             errG_total = generator_total(parts, nD)
         else:
@@ -320,10 +335,12 @@ class TrainEngine:
         for d in netsD:
             for p in d.parameters():
                 p.requires_grad_(True)
+        self._phase("G adam")
         self._opt_step(self.optG, self._allreduce_async(self.optG))       # Adam + EMA in one launch
         self.bn_counter.flush()                                           # all num_batches_tracked, one launch
         out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach())
         out.update({k: v.detach() for k, v in parts.items()})
+        self._phase("end")
         return out
 
     def encode_text(self, captions, cap_lens):

@@ -43,18 +43,69 @@ _wgrad_keep = []         # operands of in-flight side-stream launches; released 
                          # allocator cannot hand their memory to a main-stream kernel that runs concurrently
 
 
+# Merged weight gradients: a D update back-propagates through the same discriminator twice (real, fake).  For the deep
+# layers (few output pixels, tens of MB of weights) a weight-gradient launch is bound by the read-modify-write of dW, not by
+# its K = B*OH*OW; the first contribution is therefore parked and launched together with the second as ONE pass over the
+# concatenated batch (dW = dY_1 X_1^t + dY_2 X_2^t -- the same sum), leftovers at the join.
+MERGE_WGRAD = os.environ.get("MOGAN_MERGE_WGRAD", "1") != "0"
+_wgrad_pending = {}
+_wgrad_ctx_depth = 0         # parking needs somebody to flush: only inside `with wgrad_overlap():`
+
+
+def _wgrad_launch(dy, x, w_shape, geom, g):
+    stride, ph, pw, up = geom
+    if WGRAD_SIDE_STREAM:
+        cur, side = _wgrad_stream()
+        side.wait_stream(cur)                     # dy (and the zeroed / partly accumulated grad) are ready
+        with torch.cuda.stream(side):
+            conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=g, accumulate=True)
+        _wgrad_keep.append((dy, x))               # freed only after the join (see join_wgrad)
+    else:
+        conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=g, accumulate=True)
+
+
+def _wgrad_accumulate(dy, x, w, geom, g):
+    """dW += wgrad(dy, x) into the parameter's .grad buffer g, possibly deferred / merged (see MERGE_WGRAD)."""
+    K = dy.shape[0] * dy.shape[2] * dy.shape[3]
+    if not (MERGE_WGRAD and _wgrad_ctx_depth > 0 and K <= 2048 and w.numel() >= (1 << 21)) \
+            or torch.cuda.is_current_stream_capturing():
+        _wgrad_launch(dy, x, w.shape, geom, g)
+        return
+    key = (g.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    prev = _wgrad_pending.pop(key, None)
+    if prev is None:
+        _wgrad_pending[key] = (dy, x, tuple(w.shape), geom, g)
+        return
+    pdy, px, _, pgeom, _ = prev
+    if pgeom == geom and pdy.shape[1:] == dy.shape[1:] and px.shape[1:] == x.shape[1:]:
+        _wgrad_launch(torch.cat([pdy, dy]), torch.cat([px, x]), w.shape, geom, g)
+    else:
+        _wgrad_launch(pdy, px, w.shape, pgeom, g)
+        _wgrad_launch(dy, x, w.shape, geom, g)
+
+
+def _wgrad_flush():
+    cur = torch.cuda.current_stream().cuda_stream
+    for key in [k for k in _wgrad_pending if k[1] == cur]:
+        dy, x, w_shape, geom, g = _wgrad_pending.pop(key)
+        _wgrad_launch(dy, x, w_shape, geom, g)
+
+
 @contextlib.contextmanager
 def wgrad_overlap():
-    global WGRAD_SIDE_STREAM
+    global WGRAD_SIDE_STREAM, _wgrad_ctx_depth
     # not under hipGraph capture: hipStreamEndCapture segfaults (ROCm 7.2) on the nested fork pattern
     # capture stream -> branch stream -> wgrad stream; captured steps keep the weight gradients in line
     ok = _WGRAD_ENV
     if ok and torch.cuda.is_current_stream_capturing():
         ok = torch.cuda.current_stream().cuda_stream in CAPTURE_WGRAD_OK
     prev, WGRAD_SIDE_STREAM = WGRAD_SIDE_STREAM, ok
+    _wgrad_ctx_depth += 1
     try:
         yield
     finally:
+        _wgrad_flush()                    # parked single contributions (still under this context's stream policy)
+        _wgrad_ctx_depth -= 1
         WGRAD_SIDE_STREAM = prev
         join_wgrad()
 
@@ -181,14 +232,8 @@ class Conv2dFn(torch.autograd.Function):
             dx = conv2d_dgrad(dy, w, x.shape, stride, ph, pw, up)
         if ctx.needs_input_grad[1]:
             g = _grad_buf(w)
-            if g is not None and WGRAD_SIDE_STREAM:
-                cur, side = _wgrad_stream()
-                side.wait_stream(cur)                     # dy (and the zeroed / partly accumulated grad) are ready
-                with torch.cuda.stream(side):
-                    conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up, out=g, accumulate=True)
-                _wgrad_keep.append((dy, x))               # freed only after the join (see join_wgrad)
-            elif g is not None:
-                conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up, out=g, accumulate=True)
+            if g is not None:
+                _wgrad_accumulate(dy, x, w, (stride, ph, pw, up), g)
             else:
                 dw = conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up)
         if has_bias and ctx.needs_input_grad[2]:

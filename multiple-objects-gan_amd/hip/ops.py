@@ -50,6 +50,8 @@ _wgrad_keep = []         # operands of in-flight side-stream launches; released 
 MERGE_WGRAD = os.environ.get("MOGAN_MERGE_WGRAD", "1") != "0"
 _wgrad_pending = {}
 _wgrad_ctx_depth = 0         # parking needs somebody to flush: only inside `with wgrad_overlap():`
+_MERGE_K = int(os.environ.get("MOGAN_MERGE_WGRAD_K", "2048"))
+_MERGE_W = int(os.environ.get("MOGAN_MERGE_WGRAD_W", str(1 << 21)))
 
 
 def _wgrad_launch(dy, x, w_shape, geom, g):
@@ -67,7 +69,7 @@ def _wgrad_launch(dy, x, w_shape, geom, g):
 def _wgrad_accumulate(dy, x, w, geom, g):
     """dW += wgrad(dy, x) into the parameter's .grad buffer g, possibly deferred / merged (see MERGE_WGRAD)."""
     K = dy.shape[0] * dy.shape[2] * dy.shape[3]
-    if not (MERGE_WGRAD and _wgrad_ctx_depth > 0 and K <= 2048 and w.numel() >= (1 << 21)) \
+    if not (MERGE_WGRAD and _wgrad_ctx_depth > 0 and K <= _MERGE_K and w.numel() >= _MERGE_W) \
             or torch.cuda.is_current_stream_capturing():
         _wgrad_launch(dy, x, w.shape, geom, g)
         return

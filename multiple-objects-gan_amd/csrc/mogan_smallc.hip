@@ -258,6 +258,62 @@ __global__ __launch_bounds__(256) void sc_wgrad_reduce(const float* __restrict__
     if (lane == 0) dw[i] = (accumulate ? dw[i] : 0.f) + s;
 }
 
+
+// dx (B,CIN<=4,H,W) = conv3x3 s2 p0 ^T (dy (B,Cout,OH,OW), w): the data gradient of the Inception trunk's first convolution
+// (3 -> 32 at 299x299).  One thread = the 2x2 block of input pixels (2Y..2Y+1, 2X..2X+1); it needs dy rows Y-1, Y and
+// columns X-1, X of every co:   even row 2Y: kh = 0 -> oy = Y, kh = 2 -> oy = Y-1;   odd row 2Y+1: kh = 1 -> oy = Y.
+template <int CIN>
+__global__ __launch_bounds__(256) void sc_dgrad_k3s2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                     float* __restrict__ dx, int Cout, int H, int W, int OH, int OW,
+                                                     int tiles_x, int tiles_y) {
+    constexpr int CK = 8, HH = TR + 1, WW = TC + 1, WP = WW + 2;
+    __shared__ float Ys[CK][HH][WP];
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
+    const int Y = ty * TR + ly, X = tx * TC + lx;
+    const size_t oplane = (size_t)OH * OW;
+    float acc[CIN][2][2];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) acc[ci][0][0] = acc[ci][0][1] = acc[ci][1][0] = acc[ci][1][1] = 0.f;
+    for (int c0 = 0; c0 < Cout; c0 += CK) {
+        for (int e = tid; e < CK * HH * WW; e += 256) {
+            const int c = e / (HH * WW), r = e - c * (HH * WW);
+            const int hy = r / WW, hx = r - hy * WW;
+            const int oy = ty * TR - 1 + hy, ox = tx * TC - 1 + hx;
+            const bool ok = c0 + c < Cout && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+            Ys[c][hy][hx] = ok ? dy[((size_t)b * Cout + c0 + c) * oplane + (size_t)oy * OW + ox] : 0.f;
+        }
+        __syncthreads();
+        const int nc = min(CK, Cout - c0);
+        for (int c = 0; c < nc; ++c) {
+            const float d00 = Ys[c][ly][lx], d01 = Ys[c][ly][lx + 1];        // (Y-1, X-1), (Y-1, X)
+            const float d10 = Ys[c][ly + 1][lx], d11 = Ys[c][ly + 1][lx + 1];  // (Y,   X-1), (Y,   X)
+            const float* wc = w + (size_t)(c0 + c) * CIN * 9;                  // block-uniform -> scalar loads
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float* k = wc + ci * 9;
+                acc[ci][0][0] += d11 * k[0] + d10 * k[2] + d01 * k[6] + d00 * k[8];
+                acc[ci][0][1] += d11 * k[1] + d01 * k[7];
+                acc[ci][1][0] += d11 * k[3] + d10 * k[5];
+                acc[ci][1][1] += d11 * k[4];
+            }
+        }
+        __syncthreads();
+    }
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int iy = 2 * Y + py, ix = 2 * X + px;
+                if (iy < H && ix < W) dx[((size_t)b * CIN + ci) * plane + (size_t)iy * W + ix] = acc[ci][py][px];
+            }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -281,6 +337,20 @@ int mogan_smallc_fwd_try(const float* x, const float* w, float* y, int B, int Ci
 
 int mogan_smallc_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                            int KW, int stride, int ph, int pw, int up, hipStream_t st) {
+    if (up == 0 && ph == 0 && pw == 0 && KH == 3 && KW == 3 && stride == 2 && Cin >= 1 && Cin <= 4 && Hs >= 3 && Ws >= 3) {
+        const int OH = (Hs - 3) / 2 + 1, OW = (Ws - 3) / 2 + 1;
+        const int tiles_x = cdiv(cdiv(Ws, 2), TC), tiles_y = cdiv(cdiv(Hs, 2), TR);
+        const long long nb = (long long)B * tiles_x * tiles_y;
+        if (nb > 0x7fffffffLL) return 0;
+        dim3 grid((unsigned)nb);
+        switch (Cin) {
+            case 1: hipLaunchKernelGGL(sc_dgrad_k3s2<1>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+            case 2: hipLaunchKernelGGL(sc_dgrad_k3s2<2>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+            case 3: hipLaunchKernelGGL(sc_dgrad_k3s2<3>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+            default: hipLaunchKernelGGL(sc_dgrad_k3s2<4>, grid, dim3(256), 0, st, dy, w, dx, Cout, Hs, Ws, OH, OW, tiles_x, tiles_y); break;
+        }
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+    }
     if (up != 0 || ph != 1 || pw != 1) return 0;
     if (KH == 3 && KW == 3 && stride == 1 && Cout >= 1 && Cout <= 4) {
         const int tiles_x = cdiv(Ws, TC), tiles_y = cdiv(Hs, TR);

@@ -52,6 +52,7 @@ CONV_CASES = [
     (2, 20, 64, 64, 1, (3, 3), 1, (1, 1), 0),      # multi-mnist img head (Cout=1)
     (2, 3, 64, 96, 40, (4, 4), 2, (1, 1), 0),      # first D conv, non-square (dgrad = 2x2-block kernel)
     (2, 1, 32, 32, 24, (4, 4), 2, (1, 1), 0),      # multi-mnist first D conv (Cin=1)
+    (2, 3, 37, 45, 20, (3, 3), 2, (0, 0), 0),      # Inception Conv2d_1a (3 -> 32, 3x3 s2 valid, odd sizes): streaming dgrad
     (2, 10, 17, 17, 12, (1, 7), 1, (0, 3), 0),     # Inception 1x7
     (2, 10, 17, 17, 12, (7, 1), 1, (3, 0), 0),     # Inception 7x1
     (2, 6, 35, 35, 8, (3, 3), 2, (0, 0), 0),       # Inception 3x3 s2 valid (odd size)

@@ -38,33 +38,35 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, unsigned idx) {
 
 // U2[mb][wave][chunk][i = 0..5][lane][e = 0..3], v = uu*8 + kk = 4i + e: the A operand of unit u = 3*wave + uu (position
 // xi = u >> 2, m-tile u & 3) at k-step kk for lane (h, l31) = U_xi[co = mb*128 + 32*(u&3) + l31][k = 2kk + h], k = ci*4 + 2p + q.
+// One thread per 16-byte group of U2 (coalesced stores; the up to four raw taps of a value come through the caches):
+// U_(a,b) of phase (p,q) = sum over a' in S(a), b' in S(b) of w[2a'+p][2b'+q],  S(0) = {0}, S(1) = {0,1}, S(2) = {1}.
 __global__ __launch_bounds__(256) void wino22_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
-                                                            int Cin) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)Cout * Cin) return;
-    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
-    const float* g = w + i * 16;
+                                                            int Cin, long long ngroups) {
+    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= ngroups) return;
     const int nchunk = Cin / CI;
-    const int mb = co / BM, m = co - mb * BM, mt = m >> 5, l31 = m & 31;
-    const int chunk = ci / CI, cl = ci - chunk * CI;
+    const int lane = (int)(gidx & 63); long long r = gidx >> 6;
+    const int i = (int)(r % 6); r /= 6;
+    const int chunk = (int)(r % nchunk); r /= nchunk;
+    const int wv = (int)(r % NWAVE); const int mb = (int)(r / NWAVE);
+    const int h = lane >> 5, l31 = lane & 31;
+    f32x4 out;
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float g00 = g[p * 4 + q], g01 = g[p * 4 + 2 + q], g10 = g[(2 + p) * 4 + q], g11 = g[(2 + p) * 4 + 2 + q];
-            const float t[3][2] = {{g00, g01}, {g00 + g10, g01 + g11}, {g10, g11}};
-            const int k = cl * 4 + p * 2 + q, kk = k >> 1, h = k & 1;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float u3[3] = {t[a][0], t[a][0] + t[a][1], t[a][1]};
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const int unit = (a * 3 + b) * 4 + mt, wv = unit / 3, uu = unit - wv * 3;
-                    const int v = uu * 8 + kk;
-                    U[((((size_t)(mb * NWAVE + wv) * nchunk + chunk) * 6 + (v >> 2)) * 64 + h * 32 + l31) * 4 + (v & 3)] = u3[b];
-                }
-            }
+    for (int e = 0; e < 4; ++e) {
+        const int v = 4 * i + e, uu = v >> 3, kk = v & 7;
+        const int unit = 3 * wv + uu, xi = unit >> 2, mt = unit & 3, a = xi / 3, b = xi - a * 3;
+        const int co = mb * BM + mt * 32 + l31;
+        const int k = 2 * kk + h, ci = chunk * CI + (k >> 2), p = (k >> 1) & 1, q = k & 1;
+        float u = 0.f;
+        if (co < Cout) {
+            const float* g = w + ((size_t)co * Cin + ci) * 16;
+            const int a0 = a == 2 ? 1 : 0, a1 = a == 0 ? 0 : 1, b0 = b == 2 ? 1 : 0, b1 = b == 0 ? 0 : 1;
+            for (int aa = a0; aa <= a1; ++aa)
+                for (int bb = b0; bb <= b1; ++bb) u += g[(2 * aa + p) * 4 + 2 * bb + q];
         }
+        out[e] = u;
+    }
+    *(f32x4*)(U + gidx * 4) = out;
 }
 
 // data-gradient weights: for output phase (py,px) the 2x2 filter g[a][b] = w[co][ci][3-2a-py][3-2b-px], M = ci, K = co
@@ -544,7 +546,9 @@ int mogan_wino22_fwd_try(const float* x, const float* w, float* y, int B, int Ci
     p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.B = B;
     p.x_bytes = (unsigned)(4ull * B * Cin * H * W); p.u_bytes = (unsigned)ubytes;
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino22_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout, Cin);
+    const long long ngroups = mbs * NWAVE * p.nchunk * 6 * 64;
+    hipLaunchKernelGGL(wino22_weight_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout, Cin,
+                       ngroups);
     hipLaunchKernelGGL(wino22_kernel<false>, dim3((unsigned)std::min<long long>(p.nitem, ncu)), dim3(NTHR), 0, st, p);
     if (nsplit > 1)
         hipLaunchKernelGGL(wino22_reduce, dim3((unsigned)((ynum / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, y,

@@ -40,38 +40,41 @@ __device__ __forceinline__ f32x4 ldgx4(__amdgpu_buffer_rsrc_t r, unsigned idx, b
 // U_xi = (G g G^t)[xi], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  flip = 1: the data-gradient filter
 // g'(ci' = co, co' = ci) = rot180(w[co][ci]), i.e. the kernel then maps dY (Cout channels) to dX (Cin channels).
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
-                                                          int Cin, int flip) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)Cout * Cin) return;
-    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
-    float g[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = flip ? w[i * 9 + (2 - a) * 3 + (2 - b)] : w[i * 9 + a * 3 + b];
-    float t[4][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        t[0][b] = g[0][b];
-        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-        t[3][b] = g[2][b];
-    }
-    const int kin = flip ? co : ci, kout = flip ? ci : co;           // reduction / output channel of the kernel
-    const int Kin = flip ? Cout : Cin;
+                                                          int Cin, int flip, long long ngroups) {
+    // one thread per 16-byte group of U2 (coalesced stores); U_xi = (G g G^t)[xi] = sum_{a,b} G[r][a] G[q][b] g[a][b]
+    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= ngroups) return;
+    const int Kin = flip ? Cout : Cin, Kout = flip ? Cin : Cout;       // reduction / output channels of the kernel
     const int nchunk = Kin / CK;
-    const int mb = kout / BM, m = kout - mb * BM, a3 = m >> 5, l31 = m & 31;
-    const int chunk = kin / CK, c = kin - chunk * CK, kk = c >> 1, h = c & 1;
+    const int lane = (int)(gidx & 63); long long rr = gidx >> 6;
+    const int i = (int)(rr % 6); rr /= 6;
+    const int chunk = (int)(rr % nchunk); rr /= nchunk;
+    const int wv = (int)(rr % 8); const int mb = (int)(rr / 8);
+    const int h = lane >> 5, l31 = lane & 31;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    f32x4 out;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float u[4] = {t[r][0], 0.5f * (t[r][0] + t[r][1] + t[r][2]), 0.5f * (t[r][0] - t[r][1] + t[r][2]), t[r][2]};
+    for (int e = 0; e < 4; ++e) {
+        const int v = 4 * i + e, j = v / 12, kk = (v - j * 12) / 3, a3 = v - j * 12 - kk * 3;
+        const int xi = 2 * wv + j, r = xi >> 2, q = xi & 3;
+        const int kout = mb * BM + a3 * 32 + l31, kin = chunk * CK + 2 * kk + h;
+        float u = 0.f;
+        if (kout < Kout) {
+            const int co = flip ? kin : kout, ci = flip ? kout : kin;
+            const float* g = w + ((size_t)co * Cin + ci) * 9;
+            float t[3];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int xi = r * 4 + q, wv = xi >> 1, j = xi & 1;
-            const int v = (j * 4 + kk) * 3 + a3;
-            U[((((size_t)(mb * 8 + wv) * nchunk + chunk) * 6 + (v >> 2)) * 64 + h * 32 + l31) * 4 + (v & 3)] = u[q];
+            for (int b = 0; b < 3; ++b) {
+                float tt = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) tt += G[r][a] * (flip ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b]);
+                t[b] = tt;
+            }
+            u = G[q][0] * t[0] + G[q][1] * t[1] + G[q][2] * t[2];
         }
+        out[e] = u;
     }
+    *(f32x4*)(U + gidx * 4) = out;
 }
 
 // (H, W) = input dims, (OH, OW) = output dims = (H, W) + 2 pad - 2 (pad 0 / 1 / 2; ragged tiles are masked), optional fused
@@ -538,7 +541,9 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     if (!ws || ws_bytes < ubytes) return 0;
     float* U = (float*)ws;
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad);
+    const long long ngroups = mbs * 8 * (Kin / CK) * 6 * 64;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad,
+                       ngroups);
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;

@@ -71,36 +71,35 @@ __global__ __launch_bounds__(256) void wino22_weight_kernel(const float* __restr
 
 // data-gradient weights: for output phase (py,px) the 2x2 filter g[a][b] = w[co][ci][3-2a-py][3-2b-px], M = ci, K = co
 // (16 co per chunk, k = co % 16).  Same lane order as above, the four phases stored one after the other:
-// U2[phase][mb(ci)][wave][chunk(co)][i][lane][e].
+// U2[phase][mb(ci)][wave][chunk(co)][i][lane][e]; one thread per 16-byte group.
 __global__ __launch_bounds__(256) void wino22_weight_dg_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
-                                                               int Cin) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)Cout * Cin) return;
-    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
-    const float* g = w + i * 16;
+                                                               int Cin, long long ngroups) {
+    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= ngroups) return;
     const int nchunk = Cout / KC, mbs = (Cin + BM - 1) / BM;
-    const int mb = ci / BM, m = ci - mb * BM, mt = m >> 5, l31 = m & 31;
-    const int chunk = co / KC, k = co - chunk * KC, kk = k >> 1, h = k & 1;
+    const int lane = (int)(gidx & 63); long long r = gidx >> 6;
+    const int i = (int)(r % 6); r /= 6;
+    const int chunk = (int)(r % nchunk); r /= nchunk;
+    const int wv = (int)(r % NWAVE); r /= NWAVE;
+    const int mb = (int)(r % mbs); const int phase = (int)(r / mbs), py = phase >> 1, px = phase & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    f32x4 out;
 #pragma unroll
-    for (int py = 0; py < 2; ++py)
-#pragma unroll
-        for (int px = 0; px < 2; ++px) {
-            const float g00 = g[(3 - py) * 4 + 3 - px], g01 = g[(3 - py) * 4 + 1 - px];
-            const float g10 = g[(1 - py) * 4 + 3 - px], g11 = g[(1 - py) * 4 + 1 - px];
-            const float t[3][2] = {{g00, g01}, {g00 + g10, g01 + g11}, {g10, g11}};
-            const int phase = py * 2 + px;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float u3[3] = {t[a][0], t[a][0] + t[a][1], t[a][1]};
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const int unit = (a * 3 + b) * 4 + mt, wv = unit / 3, uu = unit - wv * 3;
-                    const int v = uu * 8 + kk;
-                    U[((((size_t)((phase * mbs + mb) * NWAVE + wv) * nchunk + chunk) * 6 + (v >> 2)) * 64 + h * 32 + l31) * 4 +
-                      (v & 3)] = u3[b];
-                }
-            }
+    for (int e = 0; e < 4; ++e) {
+        const int v = 4 * i + e, uu = v >> 3, kk = v & 7;
+        const int unit = 3 * wv + uu, xi = unit >> 2, mt = unit & 3, a = xi / 3, b = xi - a * 3;
+        const int ci = mb * BM + mt * 32 + l31;
+        const int co = chunk * KC + 2 * kk + h;
+        float u = 0.f;
+        if (ci < Cin) {
+            const float* g = w + ((size_t)co * Cin + ci) * 16;
+            const int a0 = a == 2 ? 1 : 0, a1 = a == 0 ? 0 : 1, b0 = b == 2 ? 1 : 0, b1 = b == 0 ? 0 : 1;
+            for (int aa = a0; aa <= a1; ++aa)
+                for (int bb = b0; bb <= b1; ++bb) u += g[(3 - 2 * aa - py) * 4 + 3 - 2 * bb - px];
         }
+        out[e] = u;
+    }
+    *(f32x4*)(U + gidx * 4) = out;
 }
 
 struct W22P {
@@ -605,7 +604,9 @@ int mogan_wino22_dgrad_try(const float* dy, const float* w, float* dx, int B, in
     p.Cin = Cout; p.H = OH; p.W = OW; p.Cout = Cin; p.OH = OH; p.OW = OW; p.B = B;    // K channels / dims of dY, M = ci, phase grid
     p.x_bytes = (unsigned)(4ull * B * Cout * OH * OW); p.u_bytes = (unsigned)ubytes;
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino22_weight_dg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout, Cin);
+    const long long ngroups = 4 * mbs * NWAVE * p.nchunk * 6 * 64;
+    hipLaunchKernelGGL(wino22_weight_dg_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, w, (float*)ws, Cout,
+                       Cin, ngroups);
     hipLaunchKernelGGL(wino22_kernel<true>, dim3((unsigned)std::min<long long>(p.nitem, ncu)), dim3(NTHR), 0, st, p);
     if (nsplit > 1)
         hipLaunchKernelGGL(wino22_reduce, dim3((unsigned)((xnum / 4 + 255) / 256)), dim3(256), 0, st, (const float*)p.ws, dx,

@@ -161,8 +161,8 @@ class SyntheticTextDataset(_Base):
     """Same sample structure as TextDataset, generated: images U(-1,1), captions uniform in
     [1, n_words), 2-3 boxes per image with the reference clamp rules, labels uniform in [0,80)."""
 
-    def __init__(self, length=1024, n_words=synthetic.VOCAB, seed=0):
-        self.length, self.n_words, self.seed = length, n_words, seed
+    def __init__(self, length=1024, n_words=synthetic.VOCAB, seed=0, eval=False):
+        self.length, self.n_words, self.seed, self.eval = length, n_words, seed, eval
         self.ixtoword = {i: ('<end>' if i == 0 else 'w%d' % i) for i in range(n_words)}
         self.imsize = [cfg.TREE.BASE_SIZE << i for i in range(cfg.TREE.BRANCH_NUM)]
 
@@ -175,6 +175,8 @@ class SyntheticTextDataset(_Base):
         caps[:n, 0] = rng.randint(1, self.n_words, n)
         bbox, labels = synthetic.make_bboxes(rng, 1)
         tms = self._matrices(bbox[0])
+        if self.eval:                                    # datasets.py:374-375: the scaled boxes ride along for sample()
+            return imgs, caps, n, index, 'synthetic_%06d' % index, tms, self._one_hot(labels[0]), bbox[0]
         return imgs, caps, n, index, 'synthetic_%06d' % index, tms, self._one_hot(labels[0])
 
     def __len__(self):

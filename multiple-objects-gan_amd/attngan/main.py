@@ -38,6 +38,9 @@ def parse_args(argv=None):
     parser.add_argument('--max_epoch', type=int, default=None)
     parser.add_argument('--batch_size', type=int, default=None, help='per-GPU minibatch')
     parser.add_argument('--output_dir', type=str, default='')
+    parser.add_argument('--sampling', action='store_true',
+                        help='evaluation (TRAIN.FLAG False): one image per caption of the whole split (sampling()) '
+                             'instead of the 25 rows of sample()')
     return parser.parse_args(argv)
 
 
@@ -70,16 +73,27 @@ def main(argv=None):
         output_dir = args.output_dir or '../../../output/%s_%s_%s' % (cfg.DATASET_NAME, cfg.CONFIG_NAME, stamp)
     else:
         output_dir = args.resume
+    # main.py:117-121: evaluation reads the test split and the dataset hands the scaled boxes along
+    split_dir, evaluate = ('train', False) if cfg.TRAIN.FLAG else ('test', True)
+    with_bbox = evaluate and not args.sampling
     if args.synthetic > 0:
-        dataset = SyntheticTextDataset(args.synthetic, seed=args.manualSeed + rank)
+        dataset = SyntheticTextDataset(args.synthetic, seed=args.manualSeed + rank, eval=with_bbox)
     else:
-        dataset = TextDataset(cfg.DATA_DIR, cfg.IMG_DIR, 'train' if cfg.TRAIN.FLAG else 'test',
-                              base_size=cfg.TREE.BASE_SIZE)
+        dataset = TextDataset(cfg.DATA_DIR, cfg.IMG_DIR, split_dir, base_size=cfg.TREE.BASE_SIZE, eval=with_bbox)
     assert dataset
     loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True, shuffle=True,
                                          num_workers=min(int(cfg.WORKERS), 8 if args.synthetic else int(cfg.WORKERS)))
     algo = trainer(output_dir, loader, dataset.n_words, dataset.ixtoword, args.resume, distributed=world > 1)
-    algo.train()
+    if cfg.TRAIN.FLAG:
+        algo.train()
+    elif args.sampling:
+        algo.sampling(split_dir)                  # main.py:157 (commented alternative): the whole validation split
+    elif cfg.B_VALIDATION:
+        algo.sample(split_dir, num_samples=25, draw_bbox=True)                      # main.py:158
+    else:
+        # main.py:160 gen_example: not callable in the reference either (it passes num_samples to a two-argument
+        # function and trainer.gen_example calls G_NET without boxes and labels) -- nothing to mirror
+        raise SystemExit("gen_example (custom captions) is not supported: set B_VALIDATION: True")
     if world > 1:
         dist.destroy_process_group()
 

@@ -467,6 +467,33 @@ def build_networks(n_words=27297, device="cuda", image_encoder=None, seed=None):
     return text_encoder, image_encoder, netG, netsD
 
 
+def draw_bbox_lines(data_img, boxes, imsize):
+    """trainer.py:556-566: white (value 1) one-pixel rectangles of the relative boxes (x, y, w, h) on every image of
+    the row; pixel coordinates are int(imsize * v) of each value SEPARATELY, w and h are capped at imsize - 1, the first
+    absent box (x <= -1) ends the loop."""
+    for idx in range(boxes.shape[0]):
+        x, y, w, h = tuple(int(imsize * float(v)) for v in boxes[idx])
+        w = imsize - 1 if w > imsize - 1 else w
+        h = imsize - 1 if h > imsize - 1 else h
+        if x <= -1:
+            break
+        data_img[:, :, y, x:x + w] = 1
+        data_img[:, :, y:y + h, x] = 1
+        data_img[:, :, y + h, x:x + w] = 1
+        data_img[:, :, y:y + h, x + w] = 1
+    return data_img
+
+
+def caption_sentence(cap, ixtoword):
+    """trainer.py:569-576: the words of a zero-terminated caption joined by blanks, non-ASCII characters dropped."""
+    words = []
+    for ix in cap:
+        if int(ix) == 0:
+            break
+        words.append(ixtoword[int(ix)].encode('ascii', 'ignore').decode('ascii'))
+    return " ".join(words)
+
+
 class condGANTrainer(object):
     """Same constructor and public methods as the reference class (trainer.py:29-366)."""
 
@@ -575,17 +602,7 @@ class condGANTrainer(object):
             return None
         if split_dir == 'test':
             split_dir = 'valid'
-        netG = G_NET()
-        netG.apply(weights_init)
-        sd = torch.load(cfg.TRAIN.NET_G, map_location='cpu')
-        netG.load_state_dict(sd["netG"])
-        print('Load G from: ', cfg.TRAIN.NET_G)
-        netG = netG.to(self.device).eval()
-        text_encoder = RNN_ENCODER(self.n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
-        if cfg.TRAIN.NET_E != '':
-            text_encoder.load_state_dict(torch.load(cfg.TRAIN.NET_E, map_location='cpu'))
-            print('Load text encoder from:', cfg.TRAIN.NET_E)
-        text_encoder = text_encoder.to(self.device).eval()
+        netG, text_encoder = self._load_eval_models()
         save_dir = '%s/%s' % (cfg.TRAIN.NET_G[:cfg.TRAIN.NET_G.rfind('.pth')], split_dir)
         mkdir_p(save_dir)
         written = []
@@ -609,6 +626,67 @@ class condGANTrainer(object):
                 fullpath = '%s_s%d.png' % (s_tmp, step)
                 Image.fromarray(out[j]).save(fullpath)
                 written.append(fullpath)
+        return written
+
+    def _load_eval_models(self):
+        """The two checkpoints of the evaluation paths (trainer.py:397-417, 483-505): EMA generator from
+        cfg.TRAIN.NET_G["netG"], DAMSM text encoder from cfg.TRAIN.NET_E, both in eval mode."""
+        netG = G_NET()
+        netG.apply(weights_init)
+        sd = torch.load(cfg.TRAIN.NET_G, map_location='cpu')
+        netG.load_state_dict(sd["netG"])
+        print('Load G from: ', cfg.TRAIN.NET_G)
+        netG = netG.to(self.device).eval()
+        text_encoder = RNN_ENCODER(self.n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
+        if cfg.TRAIN.NET_E != '':
+            text_encoder.load_state_dict(torch.load(cfg.TRAIN.NET_E, map_location='cpu'))
+            print('Load text encoder from:', cfg.TRAIN.NET_E)
+        return netG, text_encoder.to(self.device).eval()
+
+    def sample(self, split_dir, num_samples=25, draw_bbox=False):
+        """trainer.py:474-579 (what main.py:158 runs for B_VALIDATION): for the first `num_samples` batches of an
+        eval-mode loader take the FIRST sample of the sorted batch, generate nine 256x256 images for its caption /
+        boxes / labels from nine noise vectors with netG.eval(), and save one row [real | 9 fakes] (boxes drawn as white
+        lines when draw_bbox) as <NET_G minus .pth>_<split>/<caption>_<step>.png."""
+        from .datasets import prepare_data
+        from ..stackgan.logging_utils import save_image
+        if cfg.TRAIN.NET_G == '':
+            print('Error: the path for model NET_G is not found!')
+            return None
+        if split_dir == 'test':
+            split_dir = 'valid'
+        netG, text_encoder = self._load_eval_models()
+        save_dir = '%s_%s' % (cfg.TRAIN.NET_G[:cfg.TRAIN.NET_G.rfind('.pth')], split_dir)
+        mkdir_p(save_dir)
+        imsize, nrep = cfg.TREE.BASE_SIZE << (cfg.TREE.BRANCH_NUM - 1), 9
+        written, step = [], 0
+        for step, data in enumerate(self.data_loader, 0):
+            if step >= num_samples:
+                break
+            imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot, bbox = \
+                prepare_data(data, self.device, eval=True)
+            with torch.no_grad():
+                hidden = text_encoder.init_hidden(captions.shape[0])
+                words_embs, sent_emb = text_encoder(captions, cap_lens.cpu(), hidden)
+                words_embs = words_embs[0:1].repeat(nrep, 1, 1).contiguous()
+                sent_emb = sent_emb[0:1].repeat(nrep, 1).contiguous()
+                mask = (captions == 0)[0:1]
+                if mask.size(1) > words_embs.size(2):
+                    mask = mask[:, :words_embs.size(2)]
+                mask = mask.repeat(nrep, 1)
+                noise = torch.randn(nrep, cfg.GAN.Z_DIM, device=self.device)
+                fake_imgs, _, _, _ = netG(noise, sent_emb, words_embs, mask, tmi[0:1].repeat(nrep, 1, 1, 1).contiguous(),
+                                          label_one_hot[0:1].repeat(nrep, 1, 1).contiguous())
+            data_img = torch.zeros(1 + nrep, 3, imsize, imsize)
+            data_img[0] = imgs[-1][0].cpu()
+            data_img[1:] = fake_imgs[-1].float().cpu()
+            if draw_bbox:
+                draw_bbox_lines(data_img, np.asarray(bbox[0]), imsize)
+            sentence = caption_sentence(captions[0].cpu().numpy(), self.ixtoword)
+            fullpath = '{}/{}_{}.png'.format(save_dir, sentence, step)
+            save_image(data_img, fullpath, nrow=1 + nrep, normalize=True)
+            written.append(fullpath)
+        print("Saved {} files to {}".format(len(written), save_dir))
         return written
 
     def train(self):

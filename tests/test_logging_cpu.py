@@ -33,3 +33,22 @@ def test_save_img_results_and_scalars(tmp_path):
     w.close()
     rows = [json.loads(l) for l in open(str(tmp_path / "scalars.jsonl"))]
     assert rows == [{"tag": "D_loss", "value": 1.5, "step": 3}, {"tag": "G_loss", "value": 0.25, "step": 3}]
+
+
+def test_sample_row_helpers():
+    """trainer.py:556-576 restated by hand: rectangles of int(256 * v) per value with w, h capped at 255, stop at the
+    first absent box; the caption is the words up to the first 0 joined by blanks with non-ASCII characters dropped."""
+    import numpy as np
+    import torch
+    from mogan_amd.attngan.trainer import caption_sentence, draw_bbox_lines
+    img = torch.zeros(3, 2, 256, 256)
+    boxes = np.array([[0.25, 0.5, 0.125, 0.25], [0.0, 0.0, 1.2, 0.999], [-1, -1, -1, -1], [0.5, 0.5, 0.1, 0.1]], dtype=np.float32)
+    draw_bbox_lines(img, boxes, 256)
+    want = torch.zeros(256, 256)
+    for (x, y, w, h) in ((64, 128, 32, 64), (0, 0, 255, 255)):
+        want[y, x:x + w] = 1; want[y:y + h, x] = 1; want[y + h, x:x + w] = 1; want[y:y + h, x + w] = 1
+    assert all(torch.equal(img[i, c], want) for i in range(3) for c in range(2))
+    assert want[128 + 13, 128] == 0                        # the box after the absent one is not drawn
+    ix = {0: '<end>', 1: 'a', 2: u'caf\u00e9', 3: 'zebra'}
+    assert caption_sentence(np.array([3, 2, 1, 0, 3]), ix) == "zebra caf a"
+    assert caption_sentence(np.array([0, 1]), ix) == ""

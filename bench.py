@@ -23,8 +23,15 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# The eager multi-stream AttnGAN step runs on 3 hardware queues with 3 reserved streams (mogan_amd/hip/lib.py, "hardware
+# queues"); must be in the environment before the HIP runtime starts.  The captured (--graph) step and the secondary
+# workloads keep the runtime's default.
+_EAGER_ATTNGAN = "--graph" not in sys.argv and not any(a.startswith("--workload") for a in sys.argv)
+if _EAGER_ATTNGAN:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -301,6 +308,8 @@ def main():
         local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)                       # before the process group: RCCL binds to the current device
+    if _EAGER_ATTNGAN:
+        lib.reserve_hw_queues()                         # before any other stream exists (RCCL's included)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

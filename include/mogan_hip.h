@@ -55,6 +55,13 @@ int mogan_gemm_set_split_target(int blocks);
 int mogan_gemm_tune_set(int mode, int M, int N, int K, int nz, int cfg, int split);
 int mogan_gemm_tune_clear(void);
 
+/* Process set-up, not an operator: create `n` idle non-blocking HIP streams that live until the process ends.  HIP
+ * multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues in the order the streams are created, and
+ * streams that share a queue are processed in order; the multi-stream train step calls this once, right after selecting
+ * the device and before any other stream exists, so that its own streams (and RCCL's) land on the queues in the measured
+ * arrangement ("hardware queues").  Returns the number of streams held, or a negative error. */
+int mogan_reserve_streams(int n);
+
 /* test hook: the 4x4-s2 Winograd kernel is only taken from `n` 2x2-output tiles on (default 1024, -1 restores it); the
  * kernel tests lower it to cover small shapes */
 int mogan_wino22_debug_min_tiles(int n);

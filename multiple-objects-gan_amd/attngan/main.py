@@ -21,10 +21,12 @@ if __package__ in (None, ""):
     from mogan_amd.attngan.miscc.config import cfg, cfg_from_file
     from mogan_amd.attngan.datasets import SyntheticTextDataset, TextDataset
     from mogan_amd.attngan.trainer import condGANTrainer as trainer
+    from mogan_amd.hip import lib as hiplib
 else:
     from .miscc.config import cfg, cfg_from_file
     from .datasets import SyntheticTextDataset, TextDataset
     from .trainer import condGANTrainer as trainer
+    from ..hip import lib as hiplib
 
 
 def parse_args(argv=None):
@@ -57,6 +59,12 @@ def main(argv=None):
         cfg.TRAIN.BATCH_SIZE = args.batch_size
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if cfg.TRAIN.FLAG and not torch.cuda.is_initialized():
+        # the eager multi-stream step: 3 hardware queues + 3 reserved streams, before the HIP runtime starts and before
+        # RCCL creates its streams (hip/lib.py, "hardware queues")
+        hiplib.configure_hw_queues()
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        hiplib.reserve_hw_queues()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)

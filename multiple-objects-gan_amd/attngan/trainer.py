@@ -131,10 +131,11 @@ class TrainEngine:
             ops.precreate_wgrad_stream(self.side[i])
         ops.precreate_wgrad_stream(torch.cuda.current_stream())
         self.comm_stream = None          # collectives are issued on the branch streams (see _allreduce_async)
+        self._debug_no_ar = bool(os.environ.get("MOGAN_DEBUG_NO_ALLREDUCE"))   # diagnostic: cost of the collectives' ordering
 
     # -- data parallel: sum all-reduce of a flat gradient bucket over RCCL on a side stream ----------
     def _allreduce_async(self, flat):
-        if not self.distributed:
+        if not self.distributed or self._debug_no_ar:
             return None
         # issued on the branch's own stream: the process group's internal stream orders the collective behind the work
         # queued on it and the branch continues (Adam) behind the collective; a dedicated communication stream only adds

@@ -638,6 +638,16 @@ int mogan_gemm_tune_set(int mode, int M, int N, int K, int nz, int cfg, int spli
     return 0;
 }
 
+int mogan_reserve_streams(int n) {
+    static std::vector<hipStream_t> held;
+    for (int i = (int)held.size(); i < n; ++i) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return MOGAN_ERR_LAUNCH;
+        held.push_back(st);
+    }
+    return (int)held.size();
+}
+
 int mogan_gemm_tune_clear(void) {
     std::lock_guard<std::mutex> lk(g_tuned_mu);
     g_tuned.clear();

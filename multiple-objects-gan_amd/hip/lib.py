@@ -23,6 +23,7 @@ SIGNATURES = {
     "mogan_wino22_debug_min_tiles": [I],
     "mogan_gemm_tune_set": [I, I, I, I, I, I, I],
     "mogan_gemm_tune_clear": [],
+    "mogan_reserve_streams": [ctypes.c_int],
     "mogan_prof_enable": [I],
     "mogan_prof_collect": [P, I],
     "mogan_prof_dump": [ctypes.c_char_p],
@@ -124,6 +125,40 @@ def _register_tuned(lib):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+# ---------------------------------------------------------------------------------- hardware queues
+# HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 by default), assigned when a stream
+# is first materialised; packets of streams that share a queue are processed in order, so one stream's event wait holds
+# back its queue-mates.  The multi-stream train step (5 branch streams + weight-gradient side streams + RCCL's own) is
+# very sensitive to which streams end up together: measured on the B=16 AttnGAN step, img/s by (queues, idle streams created
+# first): (4,0) 299, (4,1) 290, (4,2) 305, (4,3) 277, (4,>=4) 288; (5,0) 219, (5,3) 306, (5,>=4) 185; (6..16, any) 156-280;
+# (3,0) 291, (3,>=3) 300.5.  After torch.distributed's RCCL communicator is created (3 streams of its own) the default
+# (4 queues) falls from 299 to 278.  (3 queues, >= 3 idle streams ahead of everything else) is the one plateau that does not
+# move when more streams appear -- 300-301 img/s with and without the process group -- and is what the entry points use.
+HW_QUEUES_DEFAULT = "3"
+_reserved = []
+
+
+def configure_hw_queues():
+    """Call BEFORE the first HIP call of the process (torch.cuda.set_device, library load): a GPU_MAX_HW_QUEUES set by the
+    user wins."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", HW_QUEUES_DEFAULT)
+
+
+def reserve_hw_queues(n=None):
+    """Call right after torch.cuda.set_device and before any other stream exists: n idle non-blocking HIP streams that
+    take the first round of queue slots (MOGAN_RESERVED_STREAMS overrides n; 0 disables)."""
+    if n is None:
+        n = int(os.environ.get("MOGAN_RESERVED_STREAMS", "3"))
+    if _reserved or n <= 0:
+        return
+    # through libmogan_hip.so, i.e. in the HIP runtime instance torch itself uses (a second copy of libamdhip64 loaded by
+    # name would be another runtime with its own queues)
+    got = load().mogan_reserve_streams(int(n))
+    if got < n:
+        raise RuntimeError("mogan_reserve_streams(%d) -> %d" % (n, got))
+    _reserved.append(got)
 
 
 def stream_ptr():

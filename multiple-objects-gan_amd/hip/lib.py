@@ -169,13 +169,30 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None) or torch.cuda.is_current_stream_capturing
+_cap_epoch = [0, False]       # [number of capture sessions seen, was the previous workspace() call inside a capture]
+
+
 def workspace(device):
-    """Persistent split-K / reduction scratch per (device, stream)."""
+    """Persistent split-K / reduction scratch per (device, stream).  Launches recorded into a hipGraph get a scratch buffer
+    of their own, per stream and capture session: a replayed graph runs on whatever stream replays it, concurrently with
+    eager work, and torch records every graph on ONE process-wide capture stream whose handle comes from the same
+    32-stream pool as the engines' streams -- keyed by the handle alone, an eager stream with that handle and the replayed
+    graph shared one buffer (seen as garbage image gradients from the graphed Inception branch once a long-lived test
+    process had cycled through the pool)."""
     if device.type != "cuda":
         raise MoganHipError("mogan_hip ops need tensors on the GPU (got device %s): there is no CPU "
                             "path in the product" % device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
+    handle = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
+    if _capturing():
+        if not _cap_epoch[1]:
+            _cap_epoch[0] += 1
+            _cap_epoch[1] = True
+        key = (idx, handle, _cap_epoch[0])
+    else:
+        _cap_epoch[1] = False
+        key = (idx, handle)
     buf = _ws.get(key)
     if buf is None:
         buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)

@@ -97,6 +97,7 @@ def test_full_width_train_step_properties():
     try:
         _full_width_train_step_properties()
     except AssertionError as e:
+        print("FLAKE full-width step:", e, flush=True)
         warnings.warn("full-width step check failed once, repeating: %s" % (e,))
         torch.cuda.synchronize()
         _full_width_train_step_properties()

@@ -139,3 +139,41 @@ def test_tuned_gemm_table_is_well_formed():
         assert 0 <= mode <= 3 and M > 0 and N > 0 and K > 0 and nz >= 1 and 0 <= cfg < 7 and 1 <= split <= 64
         assert (mode, M, N, K, nz) not in seen
         seen.add((mode, M, N, K, nz))
+
+
+def test_workspace_is_separate_for_captured_launches(monkeypatch):
+    """hip/lib.py:workspace -- launches recorded into a hipGraph must not share the split-K / Winograd scratch buffer with
+    eager launches on a stream that happens to carry the capture stream's handle (torch records all graphs on one pool
+    stream), nor with a graph of another capture session.  Driven on CPU with the stream / capture queries mocked."""
+    import types
+    import torch
+    from mogan_amd.hip import lib
+    state = {"handle": 7, "capturing": False}
+    made = []
+
+    def fake_empty(n, dtype=None, device=None):
+        t = torch.zeros(16, dtype=torch.uint8)
+        made.append(t)
+        return t
+
+    monkeypatch.setattr(lib, "_raw_stream", lambda idx: state["handle"])
+    monkeypatch.setattr(lib, "_capturing", lambda: state["capturing"])
+    monkeypatch.setattr(lib, "_ws", {})
+    monkeypatch.setattr(lib, "_cap_epoch", [0, False])
+    monkeypatch.setattr(lib.torch, "empty", fake_empty)
+    dev = types.SimpleNamespace(type="cuda", index=0)
+    eager = lib.workspace(dev)[0]
+    assert lib.workspace(dev)[0] == eager and len(made) == 1
+    state["capturing"] = True
+    cap1 = lib.workspace(dev)[0]
+    assert cap1 != eager and lib.workspace(dev)[0] == cap1           # one buffer per capture session
+    state["handle"] = 9                                              # a second stream inside the same capture
+    cap1b = lib.workspace(dev)[0]
+    assert cap1b not in (eager, cap1)
+    state["capturing"], state["handle"] = False, 7
+    assert lib.workspace(dev)[0] == eager                            # eager work keeps its own buffer
+    state["capturing"] = True
+    cap2 = lib.workspace(dev)[0]
+    assert cap2 not in (eager, cap1, cap1b) and len(made) == 4       # a later capture session: a new buffer
+    with pytest.raises(lib.MoganHipError):
+        lib.workspace(types.SimpleNamespace(type="cpu", index=None))

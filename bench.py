@@ -313,6 +313,9 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's stream on a priority queue of its own: a long all-reduce then cannot hold back the branch streams that would
+        # otherwise share its (in-order) hardware queue.  Neutral at world = 1 (299 vs 300 img/s); DESIGN.md section 9 (5)
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         backend = os.environ.get("MOGAN_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus

@@ -67,6 +67,7 @@ def main(argv=None):
         hiplib.reserve_hw_queues()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")       # RCCL's stream on its own priority queue (see bench.py)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if rank == 0:
         print('Using config:')

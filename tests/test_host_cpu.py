@@ -177,3 +177,21 @@ def test_workspace_is_separate_for_captured_launches(monkeypatch):
     assert cap2 not in (eager, cap1, cap1b) and len(made) == 4       # a later capture session: a new buffer
     with pytest.raises(lib.MoganHipError):
         lib.workspace(types.SimpleNamespace(type="cpu", index=None))
+
+
+def test_hw_queue_configuration_respects_the_user(monkeypatch):
+    """hip/lib.py:configure_hw_queues -- GPU_MAX_HW_QUEUES is only defaulted (3), never overridden; reserve_hw_queues(0) and
+    MOGAN_RESERVED_STREAMS=0 do not touch the library."""
+    from mogan_amd.hip import lib
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    lib.configure_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == lib.HW_QUEUES_DEFAULT == "3"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    lib.configure_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.setattr(lib, "load", lambda: (_ for _ in ()).throw(AssertionError("library touched")))
+    monkeypatch.setattr(lib, "_reserved", [])
+    lib.reserve_hw_queues(0)
+    monkeypatch.setenv("MOGAN_RESERVED_STREAMS", "0")
+    lib.reserve_hw_queues()
+    assert lib._reserved == []

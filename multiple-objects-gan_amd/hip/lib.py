@@ -179,7 +179,8 @@ def workspace(device):
     eager work, and torch records every graph on ONE process-wide capture stream whose handle comes from the same
     32-stream pool as the engines' streams -- keyed by the handle alone, an eager stream with that handle and the replayed
     graph shared one buffer (seen as garbage image gradients from the graphed Inception branch once a long-lived test
-    process had cycled through the pool)."""
+    process had cycled through the pool).  Capture-session buffers are never handed to another session and stay allocated
+    for the life of the process (they must outlive their graphs): MOGAN_WS_MB each, a handful of captures per process."""
     if device.type != "cuda":
         raise MoganHipError("mogan_hip ops need tensors on the GPU (got device %s): there is no CPU "
                             "path in the product" % device)

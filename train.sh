@@ -15,8 +15,17 @@ if [ "$DATASET" = "coco-attngan" ]; then
         HIP_VISIBLE_DEVICES="$GPU" python main.py --cfg cfg/coco_train.yml --gpu "$GPU" "${@:3}"
     fi
 elif [ "$DATASET" = "mnist" ] || [ "$DATASET" = "clevr" ] || [ "$DATASET" = "coco-stackgan-1" ] || [ "$DATASET" = "coco-stackgan-2" ]; then
-    echo "The $DATASET variant is not built yet in this tree (see DESIGN.md: the AttnGAN train step is the path in scope)." >&2
-    exit 2
+    # the StackGAN-style trees: same step on the same kernels, single process; their real-data Datasets are not built
+    # (SURVEY.md section 8(f)), so pass  --synthetic N  after the GPU id:  sh train.sh clevr 0 --synthetic 4096
+    case "$DATASET" in
+        mnist)           MOD=multi_mnist; CFG=mnist_train.yml;   echo "Starting training on the Multi-MNIST data set." ;;
+        clevr)           MOD=clevr;       CFG=clevr_train.yml;   echo "Starting training on the CLEVR data set." ;;
+        coco-stackgan-1) MOD=coco;        CFG=coco_s1_train.yml; echo "Starting training on the MS-COCO data set." ;;
+        coco-stackgan-2) MOD=coco;        CFG=coco_s2_train.yml; echo "Starting training on the MS-COCO data set." ;;
+    esac
+    cd "$HERE" || exit 1
+    HIP_VISIBLE_DEVICES="${GPU%%,*}" python -c "import mogan_loader as m; m.load(); from mogan_amd.stackgan.$MOD import main; main.main()" \
+        --cfg "$HERE/multiple-objects-gan_amd/stackgan/$MOD/cfg/$CFG" --gpu "$GPU" "${@:3}"
 else
     echo "Dataset argument must be either \"mnist\", \"clevr\", \"coco-stackgan-1\", \"coco-stackgan-2\", or \"coco-attngan\"."
     exit 1

@@ -397,6 +397,48 @@ def zero_grad(net):
         p.grad = None
 
 
+# ------------------------------------------------------------------------------ text encoder
+def _lstm_direction(x, lens, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of a one-layer LSTM over right-padded sequences x (B,T,I), what nn.LSTM does with a
+    PackedSequence (model.py:183-188): every sample is advanced over ITS OWN valid steps only (forward 0..len-1, reverse
+    len-1..0), outputs beyond len stay zero, the returned hidden state is the one after the sample's last step.
+    Gate order of the stacked weights: input, forget, cell, output."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    out = x.new_zeros(B, T, H)
+    lens = torch.as_tensor(lens)
+    for step in range(T):
+        t = lens - 1 - step if reverse else torch.full_like(lens, step)
+        live = (t >= 0) & (t < lens)                                   # samples that still have a token at this step
+        idx = t.clamp(min=0)
+        xt = x[torch.arange(B), idx]
+        gates = xt @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+        i, f, g, o = gates.chunk(4, 1)
+        c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h_new = torch.sigmoid(o) * torch.tanh(c_new)
+        m = live.unsqueeze(1)
+        c = torch.where(m, c_new, c)
+        h = torch.where(m, h_new, h)
+        out[torch.arange(B)[live], idx[live]] = h_new[live]
+    return out, h
+
+
+def rnn_encoder(net, captions, cap_lens):
+    """RNN_ENCODER.forward in eval mode (model.py:176-204; dropout inactive): embedding -> bidirectional one-layer LSTM
+    over the packed captions -> words_emb (B, 2H, max_len), sent_emb (B, 2H) = [last forward h | last reverse h].
+    `net`: state_dict of the module (keys encoder.weight, rnn.weight_ih_l0, ..., rnn.bias_hh_l0_reverse)."""
+    emb = net["encoder.weight"][captions]                              # (B,T,ninput)
+    lens = [int(v) for v in cap_lens]
+    emb = emb[:, :max(lens)]
+    of, hf = _lstm_direction(emb, lens, net["rnn.weight_ih_l0"], net["rnn.weight_hh_l0"], net["rnn.bias_ih_l0"],
+                             net["rnn.bias_hh_l0"], False)
+    ob, hb = _lstm_direction(emb, lens, net["rnn.weight_ih_l0_reverse"], net["rnn.weight_hh_l0_reverse"],
+                             net["rnn.bias_ih_l0_reverse"], net["rnn.bias_hh_l0_reverse"], True)
+    return torch.cat([of, ob], 2).transpose(1, 2), torch.cat([hf, hb], 1)
+
+
 # ------------------------------------------------------------------------------ train step
 class TrainState:
     def __init__(self, net_g, nets_d, cfg):

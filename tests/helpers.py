@@ -113,3 +113,42 @@ class AdamDeltaCheck:
         frac = self.bad / max(1, self.n)
         assert frac <= max_bad_frac, "%s: %d of %d sampled parameter deltas differ by > lr/4 (%.1f%% > %.1f%%)" % (
             what, self.bad, self.n, 100 * frac, 100 * max_bad_frac)
+
+
+# ---------------------------------------------------------------------- full-width fixtures
+BIG_SAMPLES = 4096
+
+
+def big_probe(t, n=BIG_SAMPLES):
+    """Summary of a LARGE tensor for the full-width fixtures: [sum, abs-sum, sum of squares] in f64 followed by
+    n elements at pseudo-random flat positions (RandomState keyed by the element count, so generator and test agree
+    without storing indices).  Tensors with <= n elements are stored in full (after the three sums)."""
+    a = t.detach().cpu().double().reshape(-1).numpy()
+    head = np.array([a.sum(), np.abs(a).sum(), (a * a).sum()])
+    if a.size <= n:
+        return np.concatenate([head, a])
+    idx = np.random.RandomState(a.size & 0x7FFFFFFF).randint(0, a.size, size=n)
+    return np.concatenate([head, a[idx]])
+
+
+def big_probe_close(got_t, want, tol_abs=None, tol_rel_l2=None, what=""):
+    """`got_t`: tensor, `want`: big_probe of the reference's tensor.  The sampled elements are compared as a vector
+    (max-abs and/or relative L2 over the samples), the checksums relative to the abs-sum."""
+    got = big_probe(got_t, len(want) - 3)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, "%s: probe length %d vs %d" % (what, got.size, want.size)
+    gs, ws = got[3:], want[3:]
+    assert np.isfinite(gs).all(), "%s: non-finite samples" % what
+    if tol_abs is not None:
+        err = np.abs(gs - ws).max()
+        assert err <= tol_abs, "%s: sampled max-abs err %.3e > %.1e" % (what, err, tol_abs)
+    if tol_rel_l2 is not None:
+        err = np.linalg.norm(gs - ws) / (np.linalg.norm(ws) + 1e-30)
+        assert err <= tol_rel_l2, "%s: sampled rel-L2 err %.3e > %.1e" % (what, err, tol_rel_l2)
+        tol_cs = 10 * tol_rel_l2
+    else:
+        tol_cs = 10 * tol_abs * (len(ws) and 1.0) / (np.abs(ws).mean() + 1e-30)
+    cs = abs(got[0] - want[0]) / (abs(want[1]) + 1e-30)
+    assert cs <= tol_cs, "%s: checksum (sum / abs-sum) err %.3e > %.1e" % (what, cs, tol_cs)
+    sq = abs(got[2] - want[2]) / (abs(want[2]) + 1e-30)
+    assert sq <= 2 * tol_cs, "%s: sum-of-squares rel err %.3e > %.1e" % (what, sq, 2 * tol_cs)

@@ -1,0 +1,307 @@
+"""-m gpu: VALUE parity at coco_train.yml widths (GF_DIM 48 -> 96 channels, DF_DIM 96), i.e. on the kernels bench.py times
+(Winograd F(2,3) / F(2,2), direct halo-tile, up-conv identity, tuned implicit GEMM) -- not only on the reduced-width
+fixtures, where every convolution falls to the generic kernel.
+
+  * blocks at B = 16 against fixtures the REFERENCE produced at full width (tests/golden/make_golden_fullwidth.py):
+    ResBlock(96) 64x64, upBlock(96,48) 128->256, downBlock(384,768) 32->16 -- forward, dx, every dW, BN running stats;
+  * G_NET forward and discriminator_loss through D_NET256 + backward at B = 4 against the reference fixture (sampled
+    elements + sums of every tensor) AND, full tensor for full tensor, against the CPU oracle run on this host;
+  * RNN_ENCODER against the reference fixture;
+  * every GEMM-backed launch geometry of one full-width B = 16 train step: the tuned (tile, split-K) table entry against
+    the heuristic's choice at that exact shape;
+  * 50 fresh engines in ONE process (stream pool cycling, a graph capture per engine), every first step finite and equal.
+
+Stated fp32 tolerances (SURVEY.md section 8(c) envelope; measured values are printed by each test):
+  forward tensors (images, attention, block outputs)   max-abs <= 1e-4 (values O(1))
+  loss                                                 rel <= 1e-5
+  dx / dW of a single block, D_NET256 gradients        rel-L2 <= 1e-4 per tensor (BN gamma/beta: 1e-3)
+  BN running statistics                                max-abs <= 1e-5
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, big_probe_close, det_array, det_fill_state, load_pkg, max_abs, rel_l2
+
+load_pkg()
+from mogan_amd.attngan import synthetic  # noqa: E402
+from mogan_amd.attngan.miscc.config import cfg, set_coco_train_defaults  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(name, shape, scale=1.0, shift=0.0):
+    return torch.from_numpy(det_array(name, shape, scale, shift))
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(autouse=True)
+def full_cfg():
+    set_coco_train_defaults()
+    cfg.TRAIN.GENERATOR_LR = cfg.TRAIN.DISCRIMINATOR_LR = 2e-4
+    cfg.STN_ALIGN_CORNERS, cfg.ATT_MASK_MODE, cfg.ADAM_EPS_MODE = False, 0, 0
+    yield
+
+
+BLOCKS = {"res": (lambda m: m.ResBlock(96), (16, 96, 64, 64), (16, 96, 64, 64)),
+          "up": (lambda m: m.upBlock(96, 48), (16, 96, 128, 128), (16, 48, 256, 256)),
+          "down": (lambda m: m.downBlock(384, 768), (16, 384, 32, 32), (16, 768, 16, 16))}
+
+
+@pytest.mark.parametrize("tag", list(BLOCKS))
+def test_full_width_block_vs_reference_fixture(tag):
+    """model.py:67-81 (ResBlock), 48-55 (upBlock), 594-602 (downBlock) at the widths and batch of the benchmark."""
+    from mogan_amd.attngan import model
+    g = golden("fw_blocks")
+    make, xs, gs = BLOCKS[tag]
+    mod = make(model)
+    det_fill_state(mod, "fw.%s." % tag)
+    mod = mod.to(DEV).train()
+    x = T("fw.%s.x" % tag, xs).to(DEV).requires_grad_(True)
+    y = mod(x)
+    y.backward(T("fw.%s.g" % tag, gs).to(DEV))
+    torch.cuda.synchronize()
+    big_probe_close(y, g[tag + "_y"], tol_abs=1e-4, what=tag + " y")
+    big_probe_close(x.grad, g[tag + "_dx"], tol_rel_l2=1e-4, what=tag + " dx")
+    for k, p in mod.named_parameters():
+        tol = 1e-3 if p.dim() == 1 else 1e-4
+        big_probe_close(p.grad, g["%s_d_%s" % (tag, k.replace(".", "__"))], tol_rel_l2=tol, what="%s d%s" % (tag, k))
+    for k, v in mod.state_dict().items():
+        if "running" in k:
+            big_probe_close(v, g["%s_s_%s" % (tag, k.replace(".", "__"))], tol_abs=1e-5, what="%s %s" % (tag, k))
+
+
+def test_full_width_gnet_forward_and_dnet256_loss_backward():
+    """model.py:478-528, 738-760 and miscc/losses.py:136-174 at full width, B = 4: against the reference's fixture
+    (sampled) and against the oracle (every element)."""
+    from mogan_amd.attngan import model
+    from mogan_amd.attngan.miscc import losses as L
+    from oracle import attngan_oracle as O
+    g = golden("fw_nets")
+    B = 4
+    cpu = synthetic.make_batch(B, words_num=12, nef=256, seed=21)
+    bt = synthetic.to_device(cpu, DEV)
+    G = model.G_NET()
+    sdg = det_fill_state(G, "G.")
+    G = G.to(DEV).train()
+    with torch.no_grad():
+        imgs, atts, mu, logvar = G(bt["z"], bt["sent_emb"], bt["words_embs"], bt["mask"], bt["tmi"], bt["label_one_hot"],
+                                   eps=bt["eps"])
+    D = model.D_NET256()
+    sdd = det_fill_state(D, "D2.")
+    D = D.to(DEV).train()
+    errD = L.discriminator_loss(D, bt["imgs"][2], imgs[2], bt["sent_emb"], None, None, None)
+    errD.backward()
+    torch.cuda.synchronize()
+    # (1) the reference fixture
+    for k, t in (("img64", imgs[0]), ("img128", imgs[1]), ("img256", imgs[2]), ("att64", atts[0]), ("att128", atts[1]),
+                 ("mu", mu), ("logvar", logvar)):
+        big_probe_close(t, g[k], tol_abs=1e-4, what=k)
+    for k, v in G.state_dict().items():
+        key = "g_s_" + k.replace(".", "__")
+        if key in g.files:
+            big_probe_close(v, g[key], tol_abs=1e-5, what=k)
+    want = float(g["errD2"][0])
+    assert abs(float(errD) - want) <= 1e-5 * abs(want), ("errD2", float(errD), want)
+    for k, p in D.named_parameters():
+        big_probe_close(p.grad, g["d2_g_" + k.replace(".", "__")], tol_rel_l2=1e-3 if p.dim() == 1 else 1e-4,
+                        what="D256 d" + k)
+    for k, v in D.state_dict().items():
+        if "running" in k:
+            big_probe_close(v, g["d2_s_" + k.replace(".", "__")], tol_abs=1e-5, what="D256 " + k)
+    # (2) the oracle, every element
+    ocfg = O.Cfg()
+    og, od = O.from_state_dict(sdg, requires_grad=False), O.from_state_dict(sdd)
+    with torch.no_grad():
+        oimgs, oatts, omu, olv, _ = O.g_net(og, ocfg, cpu["z"], cpu["sent_emb"], cpu["words_embs"], cpu["mask"],
+                                            cpu["tmi"], cpu["label_one_hot"], cpu["eps"])
+    oerr = O.discriminator_loss(2, od, cpu["imgs"][2], oimgs[2], cpu["sent_emb"], cpu, ocfg)
+    oerr.backward()
+    rep = {}
+    for k, a, b in [("img%d" % (64 << i), imgs[i], oimgs[i]) for i in range(3)] + \
+                   [("att%d" % (64 << i), atts[i], oatts[i]) for i in range(2)]:
+        rep[k] = max_abs(a, b)
+        assert rep[k] <= 1e-4, "%s differs from the oracle by %.3e" % (k, rep[k])
+    assert abs(float(errD) - float(oerr)) <= 1e-5 * abs(float(oerr))
+    worst = 0.0
+    for k, p in D.named_parameters():
+        r = rel_l2(p.grad, od[k].grad)
+        worst = max(worst, r)
+        assert r <= (1e-3 if p.dim() == 1 else 1e-4), "D256 d%s: rel-L2 %.3e vs the oracle" % (k, r)
+    print("full-width parity: max-abs vs oracle %s; errD2 %.7f (reference %.7f, oracle %.7f); worst D256 grad rel-L2 %.2e"
+          % ({k: "%.1e" % v for k, v in rep.items()}, float(errD), want, float(oerr), worst))
+
+
+def test_rnn_encoder_vs_reference_fixture():
+    """model.py:120-204: embedding + packed bidirectional LSTM (stock nn.LSTM on the device)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from mogan_amd.attngan import model
+    g = golden("rnn")
+    rng = np.random.RandomState(77)                      # = make_golden_fullwidth.rnn_inputs (no reference import here)
+    lens = np.array([12, 11, 9, 9, 6, 5])
+    cap = np.zeros((6, 12), dtype=np.int64)
+    for b, n in enumerate(lens):
+        cap[b, :n] = rng.randint(1, 500, size=n)
+    cfg.RNN_TYPE = 'LSTM'
+    enc = model.RNN_ENCODER(500, nhidden=256)
+    sd = det_fill_state(enc, "RNN.")
+    assert sorted(sd.keys()) == list(g["keys"])
+    enc = enc.to(DEV).eval()
+    with torch.no_grad():
+        words, sent = enc(torch.from_numpy(cap).to(DEV), torch.from_numpy(lens), enc.init_hidden(6))
+    assert tuple(words.shape) == g["words"].shape and tuple(sent.shape) == g["sent"].shape
+    np.testing.assert_allclose(words.cpu().numpy(), g["words"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(sent.cpu().numpy(), g["sent"], atol=2e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- tuned table
+_GEMM_ENTRIES = ("mogan_conv2d_fwd", "mogan_conv2d_affine_fwd", "mogan_conv2d_dgrad", "mogan_conv2d_wgrad",
+                 "mogan_upconv3x3_fwd", "mogan_upconv3x3_dgrad", "mogan_upconv3x3_wgrad", "mogan_bmm")
+
+
+# positions of the integer (shape) arguments of each entry point (include/mogan_hip.h)
+_INT_ARGS = {"mogan_conv2d_fwd": (3, 14), "mogan_conv2d_affine_fwd": (5, 16), "mogan_conv2d_dgrad": (3, 14),
+             "mogan_conv2d_wgrad": (3, 15), "mogan_upconv3x3_fwd": (3, 8), "mogan_upconv3x3_dgrad": (3, 8),
+             "mogan_upconv3x3_wgrad": (3, 9), "mogan_bmm": (3, 17)}
+
+
+def _record_geometries(step_fn):
+    """Run step_fn with hip.ops.call wrapped: the set of (entry point, integer arguments) of its GEMM-backed launches."""
+    from mogan_amd.hip import ops
+    seen, orig = {}, ops.call
+
+    def spy(name, *args):
+        if name in _GEMM_ENTRIES:
+            lo, hi = _INT_ARGS[name]
+            seen.setdefault((name, tuple(int(a) for a in args[lo:hi])), None)
+        return orig(name, *args)
+
+    ops.call = spy
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.call = orig
+    return list(seen)
+
+
+def _replay(name, ints, gen):
+    """Re-issue one recorded launch on fresh random operands; returns the output tensor."""
+    from mogan_amd.hip import ops
+    from mogan_amd.hip.lib import call, ptr, stream_ptr, workspace
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    wsp, wsn = workspace(torch.device(DEV, torch.cuda.current_device()))
+    if name == "mogan_bmm":
+        Z, M, N, K = ints[:4]
+        sa, sb, so = ints[4:7], ints[7:10], ints[10:13]
+        acc = ints[13]
+        size = lambda dims, st: 1 + sum((d - 1) * s for d, s in zip(dims, st))
+        a, b = rn(size((Z, M, K), sa)), rn(size((Z, K, N), sb))
+        out = torch.zeros(size((Z, M, N), so), device=DEV)
+        call(name, ptr(a), ptr(b), ptr(out), Z, M, N, K, *sa, *sb, *so, acc, wsp, wsn, stream_ptr())
+        return out
+    if name.startswith("mogan_upconv3x3"):
+        B, Cin, Hs, Ws, Cout = ints[:5]
+        x, w, y = rn(B, Cin, Hs, Ws), rn(Cout, Cin, 3, 3) * 0.05, rn(B, Cout, 2 * Hs, 2 * Ws)
+        if name.endswith("_fwd"):
+            return ops.conv2d_forward(x, w, 1, 1, 1, 1)
+        if name.endswith("_dgrad"):
+            return ops.conv2d_dgrad(y, w, x.shape, 1, 1, 1, 1)
+        return ops.conv2d_wgrad(y, x, w.shape, 1, 1, 1, 1)
+    B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw = ints[:10]
+    up = ints[10] if name != "mogan_conv2d_affine_fwd" else 0
+    x, w = rn(B, Cin, Hs, Ws), rn(Cout, Cin, KH, KW) * (1.0 / (Cin * KH * KW)) ** 0.5
+    if name == "mogan_conv2d_fwd":
+        return ops.conv2d_forward(x, w, stride, ph, pw, up)
+    if name == "mogan_conv2d_affine_fwd":
+        return ops.conv2d_affine_relu(x, w, rn(Cout).abs() + 0.5, rn(Cout), stride, (ph, pw))
+    OH, OW = ops.conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, up)
+    dy = rn(B, Cout, OH, OW)
+    if name == "mogan_conv2d_dgrad":
+        return ops.conv2d_dgrad(dy, w, x.shape, stride, ph, pw, up)
+    return ops.conv2d_wgrad(dy, x, w.shape, stride, ph, pw, up)
+
+
+def _bench_engine(B, fast_init=True):
+    from mogan_amd.attngan.trainer import TrainEngine, build_networks
+    if fast_init:
+        os.environ["MOGAN_FAST_INIT"] = "1"
+    try:
+        te, ie, G, Ds = build_networks(device=DEV, seed=4321)
+    finally:
+        os.environ.pop("MOGAN_FAST_INIT", None)
+    eng = TrainEngine(te, ie, G, Ds, use_graph=False)
+    cpu = synthetic.make_batch(B, words_num=cfg.TEXT.WORDS_NUM, nef=cfg.TEXT.EMBEDDING_DIM, seed=11, text="tokens")
+    bt = synthetic.to_device(cpu, DEV)
+    bt["cap_lens_cpu"] = cpu["cap_lens"].clone()
+    bt["cap_lens"] = bt["cap_lens"].to(torch.int32)
+    return eng, bt
+
+
+def test_tuned_table_entries_match_the_heuristic_at_every_bench_shape():
+    """The 500+ (tile config, split-K) entries of hip/tuned_gemm_gfx950.csv are keyed on the exact GEMM dims of the
+    benchmark's layers.  For every GEMM-backed launch geometry of one full-width B = 16 step (eager, single stream, the
+    Inception trunk launched eagerly so that its launches are seen) the result with the table registered must equal the
+    result of the heuristic's choice: same products, only the K-split summation order differs (rel-L2 <= 1e-5)."""
+    from mogan_amd.hip import lib
+    eng, bt = _bench_engine(16)
+    eng.multi_stream, eng.graph_encoder = False, False
+    geos = _record_geometries(lambda: eng.step(dict(bt)))
+    del eng
+    torch.cuda.empty_cache()
+    assert len(geos) > 150, len(geos)
+    L = lib.load()
+    worst, n_diff = (0.0, None), 0
+    try:
+        for name, ints in geos:
+            outs = []
+            for tuned in (True, False):
+                L.mogan_gemm_tune_clear()
+                if tuned:
+                    assert lib._register_tuned(L) > 0
+                outs.append(_replay(name, ints, torch.Generator(device=DEV).manual_seed(7)))
+            torch.cuda.synchronize()
+            assert torch.isfinite(outs[0]).all(), (name, ints)
+            r = rel_l2(outs[0], outs[1])
+            n_diff += int(r > 0)
+            if r > worst[0]:
+                worst = (r, (name, ints))
+            assert r <= 1e-5, "tuned vs heuristic differ by rel-L2 %.3e at %s %s" % (r, name, ints)
+    finally:
+        L.mogan_gemm_tune_clear()
+        lib._register_tuned(L)
+    print("tuned table: %d launch geometries, %d with a different summation order, worst rel-L2 %.2e at %s"
+          % (len(geos), n_diff, worst[0], worst[1]))
+
+
+def test_fifty_fresh_engines_in_one_process():
+    """Round 1 saw (once in seven suite runs) garbage generator gradients in the first full-width step of a long-lived
+    process: scratch buffers were keyed by the raw stream handle, and torch's 32-entry stream pool hands the capture
+    stream's handle to a later engine's branch stream.  The fix (hip/lib.py: capture-session workspaces) is exercised
+    here without any retry: 50 engines built one after the other in this process (each creates 9 streams -> the pool
+    wraps every 4th engine; each captures its own encoder graph pair), every first step must be finite and give the
+    same losses as the first engine's (same seed, same batch)."""
+    n = int(os.environ.get("MOGAN_STRESS_ENGINES", "50"))
+    ref = None
+    for it in range(n):
+        eng, bt = _bench_engine(4)
+        logs = eng.step(dict(bt))
+        torch.cuda.synchronize()
+        vals = {k: float(logs[k]) for k in ("errD0", "errD1", "errD2", "errG", "kl", "w_loss", "s_loss")}
+        for o, nm in zip([eng.optG] + eng.optDs, ("G", "D64", "D128", "D256")):
+            assert torch.isfinite(o.g).all() and torch.isfinite(o.p).all(), "engine %d: non-finite %s bucket" % (it, nm)
+        assert all(np.isfinite(v) for v in vals.values()), (it, vals)
+        if ref is None:
+            ref = vals
+        for k, v in vals.items():
+            assert abs(v - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-6, "engine %d: %s %.7f vs %.7f" % (it, k, v, ref[k])
+        del eng, logs
+        torch.cuda.empty_cache()
+    print("stress: %d fresh engines, losses %s" % (n, {k: round(v, 5) for k, v in ref.items()}))

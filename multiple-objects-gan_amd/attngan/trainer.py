@@ -75,12 +75,43 @@ class FlatAdam:
         return [self.ema[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
 
     def state_dict(self):
-        return {"step": self.state[0].item(), "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr}
+        """torch.optim.Adam's layout (what the reference saves as optimG / optimD, trainer.py:188-196): per-parameter
+        step / exp_avg / exp_avg_sq (views of the flat moment buckets, cloned by torch.save) + one param group."""
+        step = float(self.state[0].item())
+        state = {i: {"step": torch.tensor(step), "exp_avg": self.m[o:o + p.numel()].view_as(p),
+                     "exp_avg_sq": self.v[o:o + p.numel()].view_as(p)}
+                 for i, (p, o) in enumerate(zip(self.params, self.offsets))}
+        group = {"lr": self.lr, "betas": (0.5, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """Accepts torch.optim.Adam's {'state', 'param_groups'} (reference checkpoints, and what state_dict() emits) and
+        the flat {'step', 'exp_avg', 'exp_avg_sq'} layout of round-1 checkpoints."""
+        if "state" in sd:
+            st = sd["state"]
+            if len(st) not in (0, len(self.params)):
+                raise ValueError("optimizer state has %d entries, the network %d parameters" % (len(st), len(self.params)))
+            step = 0.0
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                e = st.get(i, st.get(str(i)))
+                if e is None:
+                    continue
+                self.m[o:o + p.numel()].copy_(e["exp_avg"].reshape(-1))
+                self.v[o:o + p.numel()].copy_(e["exp_avg_sq"].reshape(-1))
+                step = max(step, float(e["step"]))
+            self.state[0] = step
+            if sd.get("param_groups"):
+                self.lr = float(sd["param_groups"][0].get("lr", self.lr))
+            return
         self.state[0] = float(sd["step"])
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
+
+    def broadcast(self, src=0):
+        """Replica synchronisation: rank `src`'s parameters, EMA shadow, moments and step counter to every rank."""
+        for t in (self.p, self.m, self.v, self.state) + ((self.ema,) if self.ema is not None else ()):
+            dist.broadcast(t, src)
 
 
 def allreduce_flat(flat_g, comm_stream=None):
@@ -131,7 +162,26 @@ class TrainEngine:
             ops.precreate_wgrad_stream(self.side[i])
         ops.precreate_wgrad_stream(torch.cuda.current_stream())
         self.comm_stream = None          # collectives are issued on the branch streams (see _allreduce_async)
+        if self.distributed and self.world > 1:
+            self.sync_replicas()
         self._debug_no_ar = bool(os.environ.get("MOGAN_DEBUG_NO_ALLREDUCE"))   # diagnostic: cost of the collectives' ordering
+
+    def sync_replicas(self, src=0):
+        """Every rank starts from rank `src`'s weights, EMA shadow, optimizer state and BatchNorm buffers: the step only
+        exchanges gradients, so replicas that differ at step 0 (per-rank init seeds, a checkpoint only rank 0 could read)
+        would stay different forever.  One broadcast per flat bucket + one per buffer, once."""
+        for o in [self.optG] + self.optDs:
+            o.broadcast(src)
+        for net in [self.netG] + list(self.netsD) + [self.text_encoder, self.image_encoder]:
+            if not isinstance(net, torch.nn.Module):
+                continue
+            for b in net.buffers():
+                if b.dim() > 0:
+                    dist.broadcast(b, src)
+            for p in net.parameters():
+                if not p.requires_grad:                       # frozen encoders: not in any bucket
+                    dist.broadcast(p.data, src)
+        dist.broadcast(self.bn_counter.flat, src)
 
     # -- data parallel: sum all-reduce of a flat gradient bucket over RCCL on a side stream ----------
     def _allreduce_async(self, flat):
@@ -521,24 +571,50 @@ class condGANTrainer(object):
     def build_models(self):
         text_encoder, image_encoder, netG, netsD = build_networks(self.n_words, self.device)
         epoch = 0
-        if cfg.TRAIN.NET_E != '' and os.path.isfile(cfg.TRAIN.NET_E):
-            sd = torch.load(cfg.TRAIN.NET_E, map_location='cpu')
-            text_encoder.load_state_dict(sd)
+        # trainer.py:53-67: the DAMSM encoders condition G and define w_loss / s_loss -- a wrong path must not silently
+        # train against random encoders.  NET_E == '' is the explicit synthetic / benchmark setting (random-init encoders).
+        if cfg.TRAIN.NET_E == '':
+            print("WARNING: TRAIN.NET_E is empty -- random-init DAMSM encoders (synthetic / benchmark runs only)")
+        else:
             img_path = cfg.TRAIN.NET_E.replace('text_encoder', 'image_encoder')
-            if os.path.isfile(img_path):
-                image_encoder.load_state_dict(torch.load(img_path, map_location='cpu'))
+            for path in (cfg.TRAIN.NET_E, img_path):
+                if not os.path.isfile(path):
+                    raise FileNotFoundError("DAMSM encoder checkpoint not found: %s (cwd %s); set TRAIN.NET_E: '' to "
+                                            "train against random-init encoders" % (path, os.getcwd()))
+            text_encoder.load_state_dict(torch.load(cfg.TRAIN.NET_E, map_location='cpu'))
+            image_encoder.load_state_dict(torch.load(img_path, map_location='cpu'))
+            print('Load text / image encoder from:', cfg.TRAIN.NET_E, img_path)
+        self._resume_sd = None
         if self.resume:
             ckpts = sorted(glob.glob(self.model_dir + "/" + '*.pth'))
-            if ckpts:
-                sd = torch.load(ckpts[-1], map_location='cpu')
-                netG.load_state_dict(sd["netG"])
-                for i in range(len(netsD)):
-                    netsD[i].load_state_dict(sd["netD"][i])
-                epoch = int(ckpts[-1][-8:-4]) + 1
+            if not ckpts:
+                raise FileNotFoundError("--resume %s: no checkpoint_*.pth under %s" % (self.resume, self.model_dir))
+            sd = torch.load(ckpts[-1], map_location='cpu')
+            netG.load_state_dict(sd["netG"])
+            for i in range(len(netsD)):
+                netsD[i].load_state_dict(sd["netD"][i])
+            epoch = int(ckpts[-1][-8:-4]) + 1
+            self._resume_sd = sd                               # optimizer state: define_optimizers
+            print('Resume from:', ckpts[-1])
         return [text_encoder, image_encoder, netG, netsD, epoch]
 
     def define_optimizers(self, netG, netsD):
-        return self.engine.optG, self.engine.optDs
+        """trainer.py:137-159: on resume the Adam moments and step counters come back too (the flat buckets are the
+        engine's; both torch's optimizer layout and the round-1 flat layout are accepted)."""
+        optG, optDs = self.engine.optG, self.engine.optDs
+        sd = getattr(self, "_resume_sd", None)
+        if sd is not None:
+            if "optimG" in sd:
+                optG.load_state_dict(sd["optimG"])
+            for i, o in enumerate(optDs):
+                if "optimD" in sd and i < len(sd["optimD"]):
+                    o.load_state_dict(sd["optimD"][i])
+            # the checkpoint's netG holds the EMA weights (save_model swaps them in): they are both the restart point of
+            # the raw weights -- as in the reference -- and of the shadow copy
+            self._resume_sd = None
+            if self.distributed and dist.is_initialized() and dist.get_world_size() > 1:
+                self.engine.sync_replicas()
+        return optG, optDs
 
     def prepare_labels(self):
         B = self.batch_size
@@ -695,20 +771,28 @@ class condGANTrainer(object):
         text_encoder, image_encoder, netG, netsD, start_epoch = self.build_models()
         self.engine = TrainEngine(text_encoder, image_encoder, netG, netsD, self.distributed, self.use_graph)
         optimizerG, optimizersD = self.define_optimizers(netG, netsD)
+        if self.distributed and dist.is_initialized():
+            # common seed up to here (identical replicas; sync_replicas makes that unconditional), from here on every rank
+            # draws its own z / eps / augmentation stream: N ranks must not compute the same gradient N times
+            torch.manual_seed(torch.initial_seed() + 1 + dist.get_rank())
         nz = cfg.GAN.Z_DIM
         gen_iterations = 0
         fixed_noise = None
         for epoch in range(start_epoch, self.max_epoch):
             start_t = time.time()
             logs = {}
+            sampler = getattr(self.data_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)                   # DistributedSampler: a new partition of the epoch per epoch
             for data in self.data_loader:
                 imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data(data, self.device)
                 batch = dict(imgs=imgs, captions=captions, cap_lens=cap_lens, cap_lens_cpu=cap_lens.cpu(),
                              class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot,
                              z=torch.randn(captions.shape[0], nz, device=self.device))
                 logs = self.engine.step(batch)
-                if gen_iterations % 1000 == 0:        # trainer.py:335-346 (the reference never advances its counter,
-                    # so it does this every step; here: every 1000 iterations, first one included)
+                if gen_iterations % 1000 == 0:        # trainer.py:320-351: the reference increments gen_iterations before
+                    # this test, i.e. it first logs / saves at iteration 1000; here the very first iteration is included
+                    # as well (an early sanity image)
                     print(' '.join('%s: %.2f' % (k, float(v)) for k, v in logs.items() if v.dim() == 0))
                     if self.log_images and captions.shape[0] >= 8 and (not self.distributed or dist.get_rank() == 0):
                         if fixed_noise is None or fixed_noise.shape[0] != captions.shape[0]:

@@ -14,7 +14,10 @@ fixtures, where every convolution falls to the generic kernel.
 Stated fp32 tolerances (SURVEY.md section 8(c) envelope; measured values are printed by each test):
   forward tensors (images, attention, block outputs)   max-abs <= 1e-4 (values O(1))
   loss                                                 rel <= 1e-5
-  dx / dW of a single block, D_NET256 gradients        rel-L2 <= 1e-4 per tensor (BN gamma/beta: 1e-3)
+  dx / dW of a single block                            rel-L2 <= 1e-4 per tensor (BN gamma/beta: 1e-3)
+  D_NET256 gradients (8 LeakyReLU layers deep)         rel-L2 <= 2e-5 per tensor against the fp64 oracle evaluated with the
+                                                       same LeakyReLU sign decisions; <= 5e-3 against the fp32 fixture
+                                                       (kink allowance, see the test)
   BN running statistics                                max-abs <= 1e-5
 """
 import os
@@ -82,6 +85,7 @@ def test_full_width_gnet_forward_and_dnet256_loss_backward():
     (sampled) and against the oracle (every element)."""
     from mogan_amd.attngan import model
     from mogan_amd.attngan.miscc import losses as L
+    from mogan_amd.hip import ops
     from oracle import attngan_oracle as O
     g = golden("fw_nets")
     B = 4
@@ -96,10 +100,18 @@ def test_full_width_gnet_forward_and_dnet256_loss_backward():
     D = model.D_NET256()
     sdd = det_fill_state(D, "D2.")
     D = D.to(DEV).train()
-    errD = L.discriminator_loss(D, bt["imgs"][2], imgs[2], bt["sent_emb"], None, None, None)
+    ops.ACT_TRACE = []                       # the LeakyReLU outputs of this pass, in launch order (hip/ops.py)
+    try:
+        errD = L.discriminator_loss(D, bt["imgs"][2], imgs[2], bt["sent_emb"], None, None, None)
+    finally:
+        trace, ops.ACT_TRACE = ops.ACT_TRACE, None
     errD.backward()
     torch.cuda.synchronize()
-    # (1) the reference fixture
+    # (1) the reference fixture (fp32 torch-CPU).  Forward tensors and the loss: tight.  Gradients: a LeakyReLU whose
+    # pre-activation lies within fp32 noise of 0 may decide differently here than there (measured on this very case: 1 of
+    # 3.1 M decisions behind BN3 differs from an fp64 run, |t| = 3e-7, and moves the three tensors below it by 1e-4..2e-3
+    # while everything above agrees to 2e-6) -- so against the fixed fp32 fixture the gradients get a kink allowance,
+    # and the tight gradient check is (2), where the oracle is handed the decisions made here.
     for k, t in (("img64", imgs[0]), ("img128", imgs[1]), ("img256", imgs[2]), ("att64", atts[0]), ("att128", atts[1]),
                  ("mu", mu), ("logvar", logvar)):
         big_probe_close(t, g[k], tol_abs=1e-4, what=k)
@@ -108,34 +120,43 @@ def test_full_width_gnet_forward_and_dnet256_loss_backward():
         if key in g.files:
             big_probe_close(v, g[key], tol_abs=1e-5, what=k)
     want = float(g["errD2"][0])
-    assert abs(float(errD) - want) <= 1e-5 * abs(want), ("errD2", float(errD), want)
+    assert abs(float(errD.detach()) - want) <= 1e-5 * abs(want), ("errD2", float(errD.detach()), want)
     for k, p in D.named_parameters():
-        big_probe_close(p.grad, g["d2_g_" + k.replace(".", "__")], tol_rel_l2=1e-3 if p.dim() == 1 else 1e-4,
-                        what="D256 d" + k)
+        big_probe_close(p.grad, g["d2_g_" + k.replace(".", "__")], tol_rel_l2=5e-3, what="D256 d" + k)
     for k, v in D.state_dict().items():
         if "running" in k:
             big_probe_close(v, g["d2_s_" + k.replace(".", "__")], tol_abs=1e-5, what="D256 " + k)
-    # (2) the oracle, every element
+    # (2) the oracle in fp64 with this pass's LeakyReLU decisions, every element of every tensor
+    dt = torch.float64
     ocfg = O.Cfg()
-    og, od = O.from_state_dict(sdg, requires_grad=False), O.from_state_dict(sdd)
+    og, od = O.from_state_dict(sdg, dtype=dt, requires_grad=False), O.from_state_dict(sdd, dtype=dt)
+    c64 = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in cpu.items()}
+    c64["imgs"] = [t.to(dt) for t in cpu["imgs"]]
     with torch.no_grad():
-        oimgs, oatts, omu, olv, _ = O.g_net(og, ocfg, cpu["z"], cpu["sent_emb"], cpu["words_embs"], cpu["mask"],
-                                            cpu["tmi"], cpu["label_one_hot"], cpu["eps"])
-    oerr = O.discriminator_loss(2, od, cpu["imgs"][2], oimgs[2], cpu["sent_emb"], cpu, ocfg)
-    oerr.backward()
+        oimgs, oatts, omu, olv, _ = O.g_net(og, ocfg, c64["z"], c64["sent_emb"], c64["words_embs"], c64["mask"],
+                                            c64["tmi"], c64["label_one_hot"], c64["eps"])
     rep = {}
     for k, a, b in [("img%d" % (64 << i), imgs[i], oimgs[i]) for i in range(3)] + \
                    [("att%d" % (64 << i), atts[i], oatts[i]) for i in range(2)]:
         rep[k] = max_abs(a, b)
-        assert rep[k] <= 1e-4, "%s differs from the oracle by %.3e" % (k, rep[k])
-    assert abs(float(errD) - float(oerr)) <= 1e-5 * abs(float(oerr))
-    worst = 0.0
+        assert rep[k] <= 1e-4, "%s differs from the fp64 oracle by %.3e" % (k, rep[k])
+    O.LRELU_MASKS = [(t > 0).cpu() for t in trace]
+    try:
+        # the same fake image as the HIP pass (so that the decisions belong to the same function)
+        oerr = O.discriminator_loss(2, od, c64["imgs"][2], imgs[2].detach().cpu().to(dt), c64["sent_emb"], c64, ocfg)
+        assert len(O.LRELU_MASKS) == 0, "%d LeakyReLU launches were not consumed by the oracle" % len(O.LRELU_MASKS)
+    finally:
+        O.LRELU_MASKS = None
+    oerr.backward()
+    assert abs(float(errD.detach()) - float(oerr.detach())) <= 1e-5 * abs(float(oerr.detach()))
+    worst = (0.0, "")
     for k, p in D.named_parameters():
         r = rel_l2(p.grad, od[k].grad)
-        worst = max(worst, r)
-        assert r <= (1e-3 if p.dim() == 1 else 1e-4), "D256 d%s: rel-L2 %.3e vs the oracle" % (k, r)
-    print("full-width parity: max-abs vs oracle %s; errD2 %.7f (reference %.7f, oracle %.7f); worst D256 grad rel-L2 %.2e"
-          % ({k: "%.1e" % v for k, v in rep.items()}, float(errD), want, float(oerr), worst))
+        worst = max(worst, (r, k))
+        assert r <= 2e-5, "D256 d%s: rel-L2 %.3e vs the fp64 oracle (same LeakyReLU decisions)" % (k, r)
+    print("full-width parity: max-abs vs fp64 oracle %s; errD2 %.7f (reference %.7f, oracle %.7f); worst D256 grad rel-L2 "
+          "%.2e (%s), %d LeakyReLU launches matched" % ({k: "%.1e" % v for k, v in rep.items()}, float(errD.detach()), want,
+                                                       float(oerr.detach()), worst[0], worst[1], len(trace)))
 
 
 def test_rnn_encoder_vs_reference_fixture():
@@ -305,3 +326,36 @@ def test_fifty_fresh_engines_in_one_process():
         del eng, logs
         torch.cuda.empty_cache()
     print("stress: %d fresh engines, losses %s" % (n, {k: round(v, 5) for k, v in ref.items()}))
+
+
+# (Cin, H, Cout, k, stride, pad): the convolutions that carry the step's FLOPs, at their real spatial sizes
+FULL_SIZE_CONVS = [(3, 256, 96, 4, 2, 1), (96, 128, 192, 4, 2, 1), (192, 64, 384, 4, 2, 1), (384, 32, 768, 4, 2, 1),
+                   (768, 16, 1536, 4, 2, 1), (96, 64, 192, 3, 1, 1), (96, 128, 96, 3, 1, 1), (48, 256, 3, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("B", [4, 16])
+@pytest.mark.parametrize("layer", FULL_SIZE_CONVS, ids=lambda l: "%d-%d@%d-k%ds%d" % (l[0], l[2], l[1], l[3], l[4]))
+def test_full_size_convolution_values_vs_fp64(layer, B):
+    """Forward, data gradient and weight gradient of one convolution at its benchmark shape (both the B = 4 shard of
+    BASELINE config 4 and B = 16) against torch-CPU fp64 -- every element, rel-L2 <= 5e-6 (measured 1e-7..1e-6): the value
+    check that the adjoint identities of test_fullsize_gpu.py cannot give (a consistently wrong operator satisfies them)."""
+    import torch.nn.functional as F
+    from mogan_amd.hip import ops
+    Cin, H, Cout, k, s, p = layer
+    if B == 16 and Cin * Cout * k * k * (H // s) ** 2 > 3e9:
+        pytest.skip("fp64 CPU reference of this layer at B=16 takes > 20 s; B=4 covers the same kernels")
+    g = torch.Generator().manual_seed(Cin * 7 + H + B)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, s, p)
+    dy = torch.randn(yd.shape, generator=g)
+    yd.backward(dy.double())
+    xg, wg, dyg = x.to(DEV), w.to(DEV), dy.to(DEV)
+    y = ops.conv2d_forward(xg, wg, s, p, p, 0)
+    dx = ops.conv2d_dgrad(dyg, wg, xg.shape, s, p, p, 0)
+    dw = ops.conv2d_wgrad(dyg, xg, wg.shape, s, p, p, 0)
+    torch.cuda.synchronize()
+    for what, a, b in (("forward", y, yd), ("data gradient", dx, xd.grad), ("weight gradient", dw, wd.grad)):
+        r = rel_l2(a, b)
+        assert r <= 5e-6, "%s of %s at B=%d: rel-L2 %.3e vs fp64" % (what, layer, B, r)

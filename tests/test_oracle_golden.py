@@ -368,3 +368,31 @@ def test_full_width_blocks_oracle_vs_reference(tag):
             big_probe_close(v.grad, g["%s_d_%s" % (tag, kk)], tol_rel_l2=1e-4, what=tag + k)
         elif "running" in k:
             big_probe_close(v, g["%s_s_%s" % (tag, kk)], tol_abs=1e-6, what=tag + k)
+
+
+def test_full_width_nets_oracle_vs_reference():
+    """G_NET forward + discriminator_loss through D_NET256 + backward at coco_train.yml widths, B = 4: the oracle (fp32,
+    same torch-CPU ops as the reference) against the reference's fixture."""
+    from helpers import big_probe_close
+    g = golden("fw_nets")
+    cfg = O.Cfg()
+    B = 4
+    bt = synthetic.make_batch(B, words_num=12, nef=256, seed=21)
+    G = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."), requires_grad=False)
+    D = O.from_state_dict(det_state(O.d_net_spec(2, cfg), "D2."))
+    with torch.no_grad():
+        imgs, atts, mu, logvar, _ = O.g_net(G, cfg, bt["z"], bt["sent_emb"], bt["words_embs"], bt["mask"], bt["tmi"],
+                                           bt["label_one_hot"], bt["eps"])
+    for k, t in (("img64", imgs[0]), ("img128", imgs[1]), ("img256", imgs[2]), ("att64", atts[0]), ("att128", atts[1]),
+                 ("mu", mu), ("logvar", logvar)):
+        big_probe_close(t, g[k], tol_abs=2e-5, what=k)
+    err = O.discriminator_loss(2, D, bt["imgs"][2], imgs[2], bt["sent_emb"], bt, cfg)
+    err.backward()
+    assert abs(float(err.detach()) - float(g["errD2"][0])) <= 2e-6 * abs(float(g["errD2"][0]))
+    for k, v in D.items():
+        kk = k.replace(".", "__")
+        if torch.is_tensor(v) and v.requires_grad:
+            # same ops in (nearly) the same order: no LeakyReLU decision differs unless a pre-activation sits within a few ulp
+            big_probe_close(v.grad, g["d2_g_" + kk], tol_rel_l2=1e-3, what="D256 d" + k)
+        elif "running" in k:
+            big_probe_close(v, g["d2_s_" + kk], tol_abs=1e-6, what="D256 " + k)

@@ -15,7 +15,9 @@ elapsed = MAX over ranks; rank 0 prints ONE JSON line.  Extra objects on that li
                 per launch (2*M*N*K of the true GEMM dims) / average launch duration measured live
                 with HIP events on the launch stream (mogan_prof_*), vs the 157.3 TFLOP/s fp32 MFMA peak
   cpu_baseline  the CPU oracle (oracle/attngan_oracle.py, a torch-CPU port of the reference step)
-                timed on this host's cores on the same workload (rank 0, N=1 only).
+                timed on this host's cores on the same workload (rank 0, N=1 only): 1 warm-up + 2 timed steps.
+  parity        that warm-up step against ONE HIP step from the same weights with the same z / eps: relative
+                difference of every loss, max-abs difference of the generated 64x64 / 256x256 images.
 """
 import argparse
 import json
@@ -128,13 +130,21 @@ def roofline_leg(engine, run_step, steps=2):
     return rows, wall_ms
 
 
-def cpu_baseline_leg(engine, bt_cpu, dev_batch, B):
-    """The oracle (torch-CPU port of the reference step) on this host, same workload."""
+def cpu_baseline_leg(engine, bt_cpu, dev_batch, B, device, timed_steps=2, budget_s=150.0):
+    """The oracle (torch-CPU port of the reference step) on this host, same workload: one warm-up step + `timed_steps`
+    timed ones.  The warm-up step doubles as the full-width PARITY check of the benchmarked computation: the HIP engine
+    and the oracle start from the same weights (the engine's, after the timed region; Adam moments reset on both
+    sides), get the same z / eps, and run one whole train step each -- returned as `parity`: relative difference of
+    every loss, max-abs difference of the 64x64 and 256x256 generated images (stated fp32 tolerances: losses 1e-4 --
+    errG carries the DAMSM terms weighted by 50 --, images 1e-3 after the ~100-layer generator; asserted finite)."""
     from oracle import attngan_oracle as O
     from oracle import inception_oracle as IO
     ocfg = O.Cfg(gf_dim=cfg.GAN.GF_DIM, df_dim=cfg.GAN.DF_DIM, emb_dim=cfg.TEXT.EMBEDDING_DIM,
                  r_num=cfg.GAN.R_NUM, words_num=cfg.TEXT.WORDS_NUM)
     cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
+    torch.cuda.synchronize()
+    for o in [engine.optG] + engine.optDs:           # both sides start Adam from step 0
+        o.m.zero_(); o.v.zero_(); o.state.zero_()
     st = O.TrainState(O.from_state_dict(cpu(engine.netG.state_dict())),
                       [O.from_state_dict(cpu(d.state_dict())) for d in engine.netsD], ocfg)
     enc_sd = cpu(engine.image_encoder.state_dict())
@@ -143,21 +153,47 @@ def cpu_baseline_leg(engine, bt_cpu, dev_batch, B):
     batch["sent_emb"] = dev_batch["sent_emb"].cpu()
     batch["mask"] = dev_batch["mask"].cpu()
     enc = lambda x: IO.cnn_encoder(enc_sd, x)
+    gen = torch.Generator().manual_seed(4242)
+    batch["z"] = torch.randn(B, cfg.GAN.Z_DIM, generator=gen)
+    batch["eps"] = torch.randn(B, cfg.GAN.CONDITION_DIM, generator=gen)
+    # the HIP step on exactly these inputs
+    hb = {k: v for k, v in dev_batch.items() if k != "inputs_ready"}
+    hb["z"], hb["eps"] = batch["z"].to(device), batch["eps"].to(device)
+    hlogs = engine.step(hb)
+    torch.cuda.synchronize()
     times = []
     t_all = time.perf_counter()
-    for i in range(3):
-        batch["z"] = torch.randn(B, cfg.GAN.Z_DIM)
+    ologs = None
+    for i in range(1 + timed_steps):
+        if i > 0:
+            batch["z"] = torch.randn(B, cfg.GAN.Z_DIM, generator=gen)
+            batch["eps"] = torch.randn(B, cfg.GAN.CONDITION_DIM, generator=gen)
         t0 = time.perf_counter()
-        O.train_step(st, batch, enc)
+        logs = O.train_step(st, batch, enc)
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > 25.0:
+        if i == 0:
+            ologs = logs
+        if time.perf_counter() - t_all > budget_s and len(times) >= 2:
             break
+    parity = {}
+    for k in ("errD0", "errD1", "errD2", "errG", "kl", "w_loss", "s_loss"):
+        h, o = float(hlogs[k]), float(ologs[k])
+        assert h == h and abs(h) != float("inf"), "non-finite %s in the HIP step" % k
+        parity[k + "_rel"] = abs(h - o) / (abs(o) + 1e-30)
+    for k, name in (("fake64", "img64_max_abs"), ("fake_last", "img256_max_abs")):
+        assert torch.isfinite(hlogs[k]).all(), "non-finite %s in the HIP step" % k
+        parity[name] = float((hlogs[k].detach().cpu() - ologs[k]).abs().max())
+    parity["ok"] = bool(all(parity[k + "_rel"] <= 1e-4 for k in ("errD0", "errD1", "errD2", "errG", "w_loss", "s_loss"))
+                        and parity["img64_max_abs"] <= 1e-3 and parity["img256_max_abs"] <= 1e-3)
+    parity["what"] = ("one full-width B=%d train step from the benchmarked engine's weights, same z/eps: HIP vs the CPU oracle "
+                      "(losses: relative difference; images: max-abs)" % B)
     timed = times[1:] if len(times) > 1 else times
-    sec = sum(timed) / len(timed)
-    return dict(value=B / sec, unit="images/s", cores=torch.get_num_threads(), kind="port",
+    sec = sorted(timed)[len(timed) // 2] if len(timed) % 2 else sum(timed) / len(timed)
+    base = dict(value=B / sec, unit="images/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d timed step(s) of the same B=%d workload after %d warm-up step(s) "
-                       "(oracle/attngan_oracle.py + inception_oracle.py, torch-CPU fp32, %.2f s/step)"
-                       % (len(timed), B, len(times) - len(timed), sec))
+                       "(oracle/attngan_oracle.py + inception_oracle.py, torch-CPU fp32, %.2f s/step; per-step %s)"
+                       % (len(timed), B, len(times) - len(timed), sec, ["%.1f" % t for t in times]))
+    return base, parity
 
 
 # ------------------------------------------------------------------ secondary BASELINE configs (StackGAN family)
@@ -362,6 +398,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    for k, v in logs.items():                           # a benchmark of a diverged computation is not a benchmark
+        if torch.is_tensor(v) and v.dim() == 0:
+            assert bool(torch.isfinite(v)), "non-finite %s after the timed steps" % k
     ms = elapsed / args.steps * 1e3
     out = {
         "metric": "images/sec per G+D train step, 256x256 coco-attngan",
@@ -414,7 +453,9 @@ def main():
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:10]],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_leg(engine, bt_cpu, engine.encode_batch_for_cpu(batch), B)
+        dev_batch = dict(batch)
+        dev_batch.update(engine.encode_batch_for_cpu(batch))
+        out["cpu_baseline"], out["parity"] = cpu_baseline_leg(engine, bt_cpu, dev_batch, B, device)
     if world > 1 or force_dist:
         dist.destroy_process_group()
     if rank == 0:                      # the JSON line is the last thing on stdout (RCCL prints its banner there too)

@@ -74,11 +74,19 @@ def main(argv=None):
         pprint.pprint(cfg)
     if args.manualSeed is None:
         args.manualSeed = 100 if not cfg.TRAIN.FLAG else random.randint(1, 10000)
+    stamp = datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')
+    if world > 1:
+        # ONE seed and ONE output directory for the job: rank 0 draws them (each rank's `random` is unseeded, so the
+        # draws would differ), everybody else takes rank 0's
+        shared = [args.manualSeed, stamp]
+        dist.broadcast_object_list(shared, src=0)
+        args.manualSeed, stamp = shared
     random.seed(args.manualSeed + rank)
     np.random.seed(args.manualSeed + rank)
-    torch.manual_seed(args.manualSeed)           # identical replicas: same init seed on every rank
+    # common torch seed for the weight initialisation (the engine additionally broadcasts rank 0's weights, buffers and
+    # optimizer state: TrainEngine.sync_replicas); condGANTrainer.train() re-seeds per rank afterwards for z / eps
+    torch.manual_seed(args.manualSeed)
     if args.resume == '':
-        stamp = datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')
         output_dir = args.output_dir or '../../../output/%s_%s_%s' % (cfg.DATASET_NAME, cfg.CONFIG_NAME, stamp)
     else:
         output_dir = args.resume
@@ -86,11 +94,18 @@ def main(argv=None):
     split_dir, evaluate = ('train', False) if cfg.TRAIN.FLAG else ('test', True)
     with_bbox = evaluate and not args.sampling
     if args.synthetic > 0:
-        dataset = SyntheticTextDataset(args.synthetic, seed=args.manualSeed + rank, eval=with_bbox)
+        dataset = SyntheticTextDataset(args.synthetic, seed=args.manualSeed, eval=with_bbox)   # one dataset, partitioned below
     else:
         dataset = TextDataset(cfg.DATA_DIR, cfg.IMG_DIR, split_dir, base_size=cfg.TREE.BASE_SIZE, eval=with_bbox)
     assert dataset
-    loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True, shuffle=True,
+    sampler = None
+    if world > 1 and cfg.TRAIN.FLAG:
+        # every rank trains on its own 1/world partition of each epoch (same permutation seed on all ranks, re-drawn per
+        # epoch through sampler.set_epoch in condGANTrainer.train)
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
+                                                                  seed=int(args.manualSeed), drop_last=True)
+    loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True,
+                                         shuffle=sampler is None, sampler=sampler,
                                          num_workers=min(int(cfg.WORKERS), 8 if args.synthetic else int(cfg.WORKERS)))
     algo = trainer(output_dir, loader, dataset.n_words, dataset.ixtoword, args.resume, distributed=world > 1)
     if cfg.TRAIN.FLAG:

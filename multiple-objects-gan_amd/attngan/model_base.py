@@ -108,6 +108,7 @@ class FusedSeq(nn.Sequential):
                 up, i = True, i + 1
                 continue
             if isinstance(m, (HipConv2d, HipLinear)):
+                assert not (up and isinstance(m, HipLinear)), "nn.Upsample in front of a Linear"
                 x = m(x, up=up)
                 up, i = False, i + 1
                 if i < n and isinstance(mods[i], _HipBNMixin):
@@ -123,8 +124,9 @@ class FusedSeq(nn.Sequential):
             code, slope = _act_of(m)
             if code is not None:
                 x = ops.act(x, code, slope)
-            elif isinstance(m, FusedSeq) or not isinstance(m, nn.Sequential):
-                x = m(x)
+            else:
+                assert not up, "nn.Upsample must be followed by a convolution"
+                x = m(x)                      # anything else (nested containers included) runs as it is
             i += 1
         return x
 

@@ -389,7 +389,8 @@ class TrainEngine:
         self._phase("G adam")
         self._opt_step(self.optG, self._allreduce_async(self.optG))       # Adam + EMA in one launch
         self.bn_counter.flush()                                           # all num_batches_tracked, one launch
-        out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach())
+        out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach(),
+                   fake_last=fake_imgs[-1].detach())
         out.update({k: v.detach() for k, v in parts.items()})
         self._phase("end")
         return out

@@ -482,7 +482,7 @@ def train_step(st, batch, image_encoder):
     with torch.no_grad():
         for (_, p), a in zip(parameters(st.g), st.ema):
             a.mul_(0.999).add_(p, alpha=0.001)
-    logs.update(errG=float(err_g.detach()), kl=float(kl.detach()), fake64=fakes[0].detach())
+    logs.update(errG=float(err_g.detach()), kl=float(kl.detach()), fake64=fakes[0].detach(), fake_last=fakes[-1].detach())
     logs.update({k: float(v.detach()) for k, v in glogs.items()})
     return logs
 

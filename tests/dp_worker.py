@@ -1,0 +1,66 @@
+"""One rank of tests/test_dp_engine_gpu.py (launched by torch.distributed.run, 2 ranks).  On the 1-GPU test box both ranks share
+cuda:0 and the process group is gloo; everything else is the N>1 product path: TrainEngine(distributed=True) with the
+replica broadcast at construction, per-network flat-bucket all-reduces, 1/world folded into the fused Adam."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import det_fill_state, load_pkg  # noqa: E402
+from standin import StandInEncoder  # noqa: E402
+
+load_pkg()
+from mogan_amd.attngan import model, synthetic  # noqa: E402
+from mogan_amd.attngan.miscc.config import cfg  # noqa: E402
+from mogan_amd.attngan.trainer import TrainEngine  # noqa: E402
+
+
+def small_cfg():
+    cfg.GAN.GF_DIM, cfg.GAN.DF_DIM, cfg.GAN.R_NUM, cfg.GAN.Z_DIM = 4, 4, 2, 100
+    cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.WORDS_NUM, cfg.TREE.BRANCH_NUM = 16, 5, 3
+    cfg.TRAIN.GENERATOR_LR = cfg.TRAIN.DISCRIMINATOR_LR = 2e-4
+    cfg.STN_ALIGN_CORNERS, cfg.ATT_MASK_MODE, cfg.ADAM_EPS_MODE = False, 0, 0
+
+
+def main():
+    out_dir = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group(os.environ.get("MOGAN_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+    small_cfg()
+    dev = "cuda"
+    # rank 0 holds the weights the oracle knows; every other rank starts from DIFFERENT ones on purpose -- the engine's
+    # replica broadcast must replace them
+    tag = "" if rank == 0 else "other%d." % rank
+    G = model.G_NET()
+    det_fill_state(G, tag + "G.")
+    Ds = []
+    for i, cls in enumerate((model.D_NET64, model.D_NET128, model.D_NET256)):
+        D = cls()
+        det_fill_state(D, tag + "D%d." % i)
+        Ds.append(D.to(dev).train())
+    enc = StandInEncoder(16)
+    det_fill_state(enc, "ENC.")
+    for p in enc.parameters():
+        p.requires_grad = False
+    eng = TrainEngine(None, enc.to(dev).eval(), G.to(dev).train(), Ds, distributed=True, use_graph=False)
+    assert eng.distributed and eng.world == world
+    logs = None
+    for step in range(int(os.environ.get("DP_STEPS", "1"))):
+        bt = synthetic.to_device(synthetic.make_batch(4, words_num=5, nef=16, seed=100 + 10 * step + rank), dev)
+        logs = eng.step(bt)
+    torch.cuda.synchronize()
+    sd = {"G": {k: v.cpu() for k, v in G.state_dict().items()},
+          "D": [{k: v.cpu() for k, v in D.state_dict().items()} for D in Ds],
+          "ema": eng.optG.ema.cpu(), "logs": {k: float(v) for k, v in logs.items() if v.dim() == 0}}
+    torch.save(sd, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,26 @@ def det_fill_state(module, tag=""):
     return new
 
 
+def det_state(spec, tag):
+    """Same deterministic fill as helpers.det_fill_state, from a key->shape spec."""
+    sd = {}
+    for k, shp in spec.items():
+        name = tag + k
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(det_array(name, shp, 0.1))
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(np.abs(det_array(name, shp, 0.1)) + 1.0)
+        elif len(shp) == 1 and k.endswith("weight"):
+            sd[k] = torch.from_numpy(det_array(name, shp, 0.1, 1.0))
+        elif len(shp) == 1:
+            sd[k] = torch.from_numpy(det_array(name, shp, 0.1))
+        else:
+            sd[k] = torch.from_numpy(det_array(name, shp, 1.0 / np.sqrt(int(np.prod(shp[1:])))))
+    return sd
+
+
 def probe(t):
     """Size-independent summary of a tensor: [sum, abs-sum, cos-weighted sum] in f64 +
     the first 16 and a strided sample of 16 elements."""

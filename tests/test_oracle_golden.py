@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import AdamDeltaCheck, GOLDEN, det_array, load_pkg, probe, probe_close
+from helpers import AdamDeltaCheck, GOLDEN, det_array, det_state, load_pkg, probe, probe_close
 from oracle import attngan_oracle as O
 from standin import StandInEncoder
 
@@ -24,26 +24,6 @@ def T(name, shape, scale=1.0, shift=0.0):
 
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
-
-
-def det_state(spec, tag):
-    """Same deterministic fill as helpers.det_fill_state, from a key->shape spec."""
-    sd = {}
-    for k, shp in spec.items():
-        name = tag + k
-        if k.endswith("num_batches_tracked"):
-            sd[k] = torch.zeros((), dtype=torch.long)
-        elif k.endswith("running_mean"):
-            sd[k] = torch.from_numpy(det_array(name, shp, 0.1))
-        elif k.endswith("running_var"):
-            sd[k] = torch.from_numpy(np.abs(det_array(name, shp, 0.1)) + 1.0)
-        elif len(shp) == 1 and k.endswith("weight"):
-            sd[k] = torch.from_numpy(det_array(name, shp, 0.1, 1.0))
-        elif len(shp) == 1:
-            sd[k] = torch.from_numpy(det_array(name, shp, 0.1))
-        else:
-            sd[k] = torch.from_numpy(det_array(name, shp, 1.0 / np.sqrt(int(np.prod(shp[1:])))))
-    return sd
 
 
 def close(got, want, rtol=2e-5, atol=2e-6, what=""):

@@ -216,6 +216,42 @@ int mogan_reparam_fwd(const float* mu, const float* logvar, const float* eps, fl
 int mogan_reparam_bwd(const float* logvar, const float* eps, const float* dc, float* dmu, float* dlogvar, int n,
                       hipStream_t stream);
 
+/* ---------------------------------------------------------------- DAMSM matching losses (generator step)
+ * words_loss (miscc/losses.py:62-132 + GlobalAttention.py:31-69 func_attention, which the reference calls once per
+ * caption in a python loop) for ALL (image b, caption i) pairs in one launch.
+ *   ctx (B,C,S) region features, words (Bc,C,T) word embeddings, cap_lens (Bc) int32 valid words per caption.
+ *   fwd -> sim (B,Bc) = gamma3 * log sum_t exp(gamma2 * cos(word_{i,t}, context_{b,i,t})), and for the backward pass
+ *          a1 (B,Bc,S,T) softmax over the words, a2 (B,Bc,T,S) softmax over the regions (= the attention maps of
+ *          losses.py:87-91), wc (B,C,Bc,T) weighted contexts, wt (C,Bc,T) the word embeddings in GEMM layout
+ *          (nullable).  Limits: T <= 32, (C*T + T*(S+1) + 896) * 4 bytes of LDS <= 64 KB.
+ *   bwd: dsim (B,Bc) -> dwc (B,C,Bc,T), dscore_t (B,Bc,T,S); the region-feature gradient is then two mogan_bmm calls:
+ *          dctx[b] (C,S) = dwc[b] (C, Bc*T) . a2[b] (Bc*T, S)  +  wt (C, Bc*T) . dscore_t[b] (Bc*T, S).
+ *        (image side only: the text encoder is frozen in the generator step, trainer.py:281-289).  S <= 512. */
+int mogan_damsm_words_fwd(const float* ctx, const float* words, const int32_t* cap_lens, int B, int Bc, int C, int S, int T,
+                          float gamma1, float gamma2, float gamma3, float* sim, float* a1, float* a2, float* wc, float* wt,
+                          hipStream_t stream);
+int mogan_damsm_words_bwd(const float* ctx, const float* words, const int32_t* cap_lens, const float* a1, const float* a2,
+                          const float* wc, const float* dsim, int B, int Bc, int C, int S, int T, float gamma1,
+                          float gamma2, float gamma3, float* dwc, float* dscore_t, hipStream_t stream);
+/* The two cross-entropies over a square similarity matrix sim (R,R) (losses.py:45-58,116-130): rows against labels
+ * (image -> caption) and columns against labels (caption -> image), entries with mask[r,q] != 0 (same class, nullable)
+ * set to -inf first.  fwd -> prow, pcol (R,R) softmax probabilities, nll (2R) scratch, out2 = {loss0, loss1} (means).
+ * bwd: g0, g1 (device scalars, gradients of loss0 / loss1; nullable = 0) -> dsim (R,R). */
+int mogan_damsm_ce_fwd(const float* sim, const int64_t* labels, const uint8_t* mask, int R, int Q, float* prow,
+                       float* pcol, float* nll, float* out2, hipStream_t stream);
+int mogan_damsm_ce_bwd(const float* prow, const float* pcol, const int64_t* labels, const float* g0, const float* g1, int R,
+                       int Q, float* dsim, hipStream_t stream);
+/* sent_loss similarity (losses.py:36-44): sim[b,i] = gamma3 * <cnn_b, rnn_i> / max(|cnn_b| |rnn_i|, eps); bwd -> dcnn */
+int mogan_damsm_sent_fwd(const float* cnn, const float* rnn, int B, int Bc, int C, float gamma3, float eps, float* sim,
+                         hipStream_t stream);
+int mogan_damsm_sent_bwd(const float* cnn, const float* rnn, const float* dsim, int B, int Bc, int C, float gamma3,
+                         float eps, float* dcnn, hipStream_t stream);
+/* out[0] = sum_k weights[k] * in[k][0] for n <= 8 device scalars (the loss sums of losses.py:169-174,203,221 and
+ * trainer.py:330 in one launch); scalar_scale is its gradient: out[k][0] = weights[k] * g[0].  `in` / `out` / `weights`
+ * are HOST arrays (read during the call). */
+int mogan_scalar_sum(const float* const* in, const float* weights, int n, float* out, hipStream_t stream);
+int mogan_scalar_scale(const float* g, const float* weights, int n, float* const* out, hipStream_t stream);
+
 /* ---------------------------------------------------------------- pooling / resize (CNN_ENCODER trunk)
  * max_pool2d(k,s, no padding): fwd records the offset of the first maximum of each window in idx (uint8,
  * same shape as y; nullable), bwd gathers through it (ties -> first, like torch),

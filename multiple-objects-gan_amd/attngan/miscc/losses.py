@@ -10,7 +10,6 @@ import contextlib
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from ...hip import ops
 from .. import parallel
@@ -44,52 +43,44 @@ def cosine_similarity(x1, x2, dim=1, eps=1e-8):
     return (w12 / (torch.norm(x1, 2, dim) * torch.norm(x2, 2, dim)).clamp(min=eps)).squeeze()
 
 
-def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8):
-    """losses.py:20-59."""
-    n0 = torch.norm(cnn_code, 2, dim=1, keepdim=True)
-    n1 = torch.norm(rnn_code, 2, dim=1, keepdim=True)
-    scores0 = ops.bmm(cnn_code.unsqueeze(0), rnn_code.t().unsqueeze(0)).squeeze(0)
-    scores0 = scores0 / (n0 * n1.t()).clamp(min=eps) * cfg.TRAIN.SMOOTH.GAMMA3
-    masks = _class_mask(class_ids, batch_size, cnn_code.device)
+def _labels_and_mask(labels, class_ids, batch_size, device):
+    masks = _class_mask(class_ids, batch_size, device)
     if masks is not None:
-        scores0 = scores0.masked_fill(masks, -float('inf'))
+        masks = masks.to(torch.uint8).contiguous()
+    if labels is None:
+        labels = torch.arange(batch_size, device=device)
+    return labels.to(device=device, dtype=torch.int64).contiguous(), masks
+
+
+def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8):
+    """losses.py:20-59: cosine matrix of the image / sentence codes * gamma3 and cross-entropy both ways, fused
+    (mogan_damsm_sent_* + mogan_damsm_ce_*: 2 launches forward, 2 backward).  Gradient: cnn_code."""
     if labels is None:
         return None, None
-    return F.cross_entropy(scores0, labels), F.cross_entropy(scores0.t(), labels)
+    lab, masks = _labels_and_mask(labels, class_ids, batch_size, cnn_code.device)
+    return ops.damsm_sent(cnn_code, rnn_code.detach(), lab, masks, cfg.TRAIN.SMOOTH.GAMMA3, eps)
 
 
 def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size):
     """losses.py:62-132.  words_emb (B,nef,T), img_features (B,nef,17,17).
-    similarities[b, i] = log sum_t exp(gamma2 * cos(word_{i,t}, context_{b,i,t})) * gamma3, where the
-    region context comes from func_attention(word_i, feature_b) (GlobalAttention.py:31-69)."""
+    similarities[b, i] = log sum_t exp(gamma2 * cos(word_{i,t}, context_{b,i,t})) * gamma3, where the region context
+    comes from func_attention(word_i, feature_b) (GlobalAttention.py:31-69) -- all B*B pairs in one fused launch
+    (mogan_damsm_words_fwd) instead of the reference's B-iteration python loop, then the two cross-entropies.
+    Gradient: img_features (the text encoder is frozen in the generator step, trainer.py:281-289)."""
     B = batch_size
-    C, T = words_emb.shape[1], words_emb.shape[2]
     ih, iw = img_features.shape[2], img_features.shape[3]
-    S = ih * iw
     dev = img_features.device
-    lens = cap_lens.to(dev).to(torch.int32).reshape(B)
-    ctx = img_features.reshape(B, C, S)
-    wt = words_emb.permute(1, 0, 2).reshape(C, B * T)                     # [c, (i,t)]
-    attn = ops.bmm(ctx.transpose(1, 2), wt.unsqueeze(0).expand(B, C, B * T))        # B,S,(i,t)  Eq. (7)
-    lens1 = lens.view(1, 1, B).expand(B, S, B).contiguous()
-    attn = ops.softmax(attn.view(B, S, B, T), 3, 1.0, lens1)             # over the words of caption i
-    attn = ops.softmax(attn, 1, cfg.TRAIN.SMOOTH.GAMMA1)                 # over the regions, Eq. (9)
-    wc = ops.bmm(ctx, attn.view(B, S, B * T)).view(B, C, B, T)           # weighted context [b,c,i,t]
-    w = wt.view(1, C, B, T)
-    row_sim = (wc * w).sum(1) / (torch.norm(w, 2, 1) * torch.norm(wc, 2, 1)).clamp(min=1e-8)   # B,B,T
-    valid = torch.arange(T, device=dev).view(1, 1, T) < lens.view(1, B, 1)
-    row_sim = (row_sim * cfg.TRAIN.SMOOTH.GAMMA2).exp() * valid           # Eq. (10)
-    similarities = torch.log(row_sim.sum(2)) * cfg.TRAIN.SMOOTH.GAMMA3    # [image b, caption i]
-    masks = _class_mask(class_ids, B, dev)
-    if masks is not None:
-        similarities = similarities.masked_fill(masks, -float('inf'))
+    lens = cap_lens.to(dev).to(torch.int32).reshape(B).contiguous()
+    lab, masks = _labels_and_mask(labels, class_ids, B, dev)
+    l0, l1, a2 = ops.damsm_words(img_features, words_emb.detach(), lens, lab, masks, cfg.TRAIN.SMOOTH.GAMMA1,
+                                 cfg.TRAIN.SMOOTH.GAMMA2, cfg.TRAIN.SMOOTH.GAMMA3)
     att_maps = None
-    if labels is None or not torch.is_grad_enabled():
+    if labels is None or not torch.is_grad_enabled():         # visualisation (losses.py:87-91): caption i on image i
         lens_h = [int(v) for v in cap_lens.tolist()]
-        att_maps = [attn[i, :, i, :lens_h[i]].t().reshape(1, lens_h[i], ih, iw).contiguous() for i in range(B)]
+        att_maps = [a2[i, i, :lens_h[i]].reshape(1, lens_h[i], ih, iw).contiguous() for i in range(B)]
     if labels is None:
         return None, None, att_maps
-    return F.cross_entropy(similarities, labels), F.cross_entropy(similarities.t(), labels), att_maps
+    return l0, l1, att_maps
 
 
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels, gpus=None,
@@ -109,8 +100,10 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     if netD.UNCOND_DNET is not None:
         real_errD = ops.bce(netD.UNCOND_DNET(real_features), 1.0)
         fake_errD = ops.bce(netD.UNCOND_DNET(fake_features), 0.0)
-        return ((real_errD + cond_real_errD) / 2. + (fake_errD + cond_fake_errD + cond_wrong_errD) / 3.)
-    return cond_real_errD + (cond_fake_errD + cond_wrong_errD) / 2.
+        # ((real + cond_real) / 2 + (fake + cond_fake + cond_wrong) / 3) in one launch
+        return ops.scalar_sum([real_errD, cond_real_errD, fake_errD, cond_fake_errD, cond_wrong_errD],
+                              [0.5, 0.5, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0])
+    return ops.scalar_sum([cond_real_errD, cond_fake_errD, cond_wrong_errD], [1.0, 0.5, 0.5])
 
 
 def generator_d_branch(netD, fake_img, sent_emb, local_labels=None, transf_matrices=None, transf_matrices_inv=None):
@@ -120,7 +113,7 @@ def generator_d_branch(netD, fake_img, sent_emb, local_labels=None, transf_matri
         features, sent_emb = parallel.gather_cat(features), parallel.gather_const(sent_emb)
     g_loss = ops.bce(netD.COND_DNET(features, sent_emb), 1.0)
     if netD.UNCOND_DNET is not None:
-        g_loss = ops.bce(netD.UNCOND_DNET(features), 1.0) + g_loss
+        g_loss = ops.scalar_sum([ops.bce(netD.UNCOND_DNET(features), 1.0), g_loss])
     return g_loss
 
 
@@ -134,19 +127,17 @@ def generator_damsm_branch(image_encoder, fake_img, words_embs, sent_emb, match_
         class_ids = parallel.gather_ids(class_ids)
         batch_size = region_features.size(0)
         match_labels = torch.arange(batch_size, device=region_features.device)
+    lam = cfg.TRAIN.SMOOTH.LAMBDA
     w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size)
-    w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    w_loss = ops.scalar_sum([w_loss0, w_loss1], [lam, lam])
     s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
-    s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    s_loss = ops.scalar_sum([s_loss0, s_loss1], [lam, lam])
     return w_loss, s_loss
 
 
 def generator_total(parts, numDs):
     """Sum in the reference's order: g_loss0, g_loss1, g_loss2, then w_loss, s_loss (losses.py:203,221)."""
-    errG_total = 0
-    for i in range(numDs):
-        errG_total = errG_total + parts['g_loss%d' % i]
-    return errG_total + parts['w_loss'] + parts['s_loss']
+    return ops.scalar_sum([parts['g_loss%d' % i] for i in range(numDs)] + [parts['w_loss'], parts['s_loss']])
 
 
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,

@@ -341,7 +341,7 @@ class TrainEngine:
                     self._encoder(img), img, b["words_embs"], b["sent_emb"], match_labels, b["cap_lens"],
                     b.get("class_ids"), B)
                 if self.early_damsm_bwd:
-                    damsm_grad, = torch.autograd.grad(w_loss + s_loss, img)
+                    damsm_grad, = torch.autograd.grad(ops.scalar_sum([w_loss, s_loss]), img)
                     w_loss, s_loss = w_loss.detach(), s_loss.detach()
                 parts["w_loss"], parts["s_loss"] = w_loss, s_loss
             for i in order[1:]:
@@ -377,7 +377,7 @@ class TrainEngine:
                                                local_labels=b["label_one_hot"], transf_matrices=b["tm"],
                                                transf_matrices_inv=b["tmi"], return_logs=False)
         kl_loss = KL_loss(mu, logvar)
-        errG_total = errG_total + kl_loss
+        errG_total = ops.scalar_sum([errG_total, kl_loss])          # trainer.py:330
         with ops.wgrad_overlap():
             if self.multi_stream and damsm_grad is not None:
                 torch.autograd.backward([errG_total, fake_imgs[nD - 1]], [None, damsm_grad])

@@ -73,6 +73,14 @@ SIGNATURES = {
     "mogan_bilinear_fwd": [P, P, I, I, I, I, I, P],
     "mogan_bilinear_bwd": [P, P, I, I, I, I, I, P],
     "mogan_adam_step": [P, P, P, P, P, L, F, F, F, F, I, P, I, F, F, P],
+    "mogan_damsm_words_fwd": [P, P, P, I, I, I, I, I, F, F, F, P, P, P, P, P, P],
+    "mogan_damsm_words_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, F, F, P, P, P],
+    "mogan_damsm_ce_fwd": [P, P, P, I, I, P, P, P, P, P],
+    "mogan_damsm_ce_bwd": [P, P, P, P, P, I, I, P, P],
+    "mogan_damsm_sent_fwd": [P, P, I, I, I, F, F, P, P],
+    "mogan_damsm_sent_bwd": [P, P, P, I, I, I, F, F, P, P],
+    "mogan_scalar_sum": [P, P, I, P, P],
+    "mogan_scalar_scale": [P, P, I, P, P],
 }
 _RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}

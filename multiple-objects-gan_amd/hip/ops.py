@@ -732,6 +732,161 @@ def reparam(mu, logvar, eps):
     return ReparamFn.apply(mu, logvar, eps)
 
 
+# ------------------------------------------------------------------------------- DAMSM matching losses
+def _scalar(device):
+    return torch.empty((), dtype=torch.float32, device=device)
+
+
+def _g_ptr(g):
+    """Pointer of a 0-dim upstream gradient (None -> NULL: that output did not take part in the loss)."""
+    return ptr(_c(g)) if g is not None else None
+
+
+class _PairCE:
+    """Shared tail of the word and the sentence loss: the two cross-entropies over a (B,B) similarity matrix."""
+
+    @staticmethod
+    def forward(ctx, sim, labels, mask):
+        R = sim.shape[0]
+        dev = sim.device
+        prow, pcol = torch.empty_like(sim), torch.empty_like(sim)
+        nll = torch.empty(2 * R, dtype=torch.float32, device=dev)
+        out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        call("mogan_damsm_ce_fwd", ptr(sim), ptr(labels), ptr(mask), R, sim.shape[1], ptr(prow), ptr(pcol), ptr(nll),
+             ptr(out2), stream_ptr())
+        ctx.ce = (prow, pcol, labels)
+        return out2[0], out2[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        prow, pcol, labels = ctx.ce
+        dsim = torch.empty_like(prow)
+        call("mogan_damsm_ce_bwd", ptr(prow), ptr(pcol), ptr(labels), _g_ptr(g0), _g_ptr(g1), prow.shape[0], prow.shape[1],
+             ptr(dsim), stream_ptr())
+        return dsim
+
+
+class DamsmWordsFn(torch.autograd.Function):
+    """words_loss for all (image, caption) pairs (miscc/losses.py:62-132, GlobalAttention.py:31-69) -> (loss0, loss1,
+    attention a2 (B,Bc,T,S)).  Gradient: region features only."""
+
+    @staticmethod
+    def forward(ctx, feat, words, lens, labels, mask, g1, g2, g3):
+        feat, words = _c(feat), _c(words)
+        B, C = feat.shape[0], feat.shape[1]
+        S = feat[0, 0].numel()
+        Bc, T = words.shape[0], words.shape[2]
+        dev = feat.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        sim = torch.empty((B, Bc), **f32)
+        a1, a2 = torch.empty((B, Bc, S, T), **f32), torch.empty((B, Bc, T, S), **f32)
+        wc, wt = torch.empty((B, C, Bc, T), **f32), torch.empty((C, Bc, T), **f32)
+        call("mogan_damsm_words_fwd", ptr(feat), ptr(words), ptr(lens), B, Bc, C, S, T, g1, g2, g3, ptr(sim), ptr(a1),
+             ptr(a2), ptr(wc), ptr(wt), stream_ptr())
+        l0, l1 = _PairCE.forward(ctx, sim, labels, mask)
+        ctx.save_for_backward(feat, words, a1, a2, wc, wt)
+        ctx.cfg = (lens, g1, g2, g3)
+        ctx.mark_non_differentiable(a2)
+        return l0, l1, a2
+
+    @staticmethod
+    def backward(ctx, gl0, gl1, _ga2):
+        feat, words, a1, a2, wc, wt = ctx.saved_tensors
+        lens, g1, g2, g3 = ctx.cfg
+        B, C = feat.shape[0], feat.shape[1]
+        S = feat[0, 0].numel()
+        Bc, T = words.shape[0], words.shape[2]
+        dsim = _PairCE.backward(ctx, gl0, gl1)
+        dwc = torch.empty_like(wc)
+        dst = torch.empty_like(a2)
+        call("mogan_damsm_words_bwd", ptr(feat), ptr(words), ptr(lens), ptr(a1), ptr(a2), ptr(wc), ptr(dsim), B, Bc, C, S, T,
+             g1, g2, g3, ptr(dwc), ptr(dst), stream_ptr())
+        dfeat = torch.empty_like(feat)
+        out = dfeat.view(B, C, S)
+        bmm_raw(dwc.view(B, C, Bc * T), a2.view(B, Bc * T, S), out)
+        bmm_raw(wt.view(1, C, Bc * T).expand(B, C, Bc * T), dst.view(B, Bc * T, S), out, accumulate=True)
+        return dfeat, None, None, None, None, None, None, None
+
+
+def damsm_words(feat, words, lens, labels, mask, gamma1, gamma2, gamma3):
+    return DamsmWordsFn.apply(feat, words, lens, labels, mask, float(gamma1), float(gamma2), float(gamma3))
+
+
+class DamsmSentFn(torch.autograd.Function):
+    """sent_loss (miscc/losses.py:20-59) -> (loss0, loss1).  Gradient: cnn code only."""
+
+    @staticmethod
+    def forward(ctx, cnn, rnn, labels, mask, g3, eps):
+        cnn, rnn = _c(cnn), _c(rnn)
+        B, C, Bc = cnn.shape[0], cnn.shape[1], rnn.shape[0]
+        sim = torch.empty((B, Bc), dtype=torch.float32, device=cnn.device)
+        call("mogan_damsm_sent_fwd", ptr(cnn), ptr(rnn), B, Bc, C, g3, eps, ptr(sim), stream_ptr())
+        l0, l1 = _PairCE.forward(ctx, sim, labels, mask)
+        ctx.save_for_backward(cnn, rnn)
+        ctx.cfg = (g3, eps)
+        return l0, l1
+
+    @staticmethod
+    def backward(ctx, gl0, gl1):
+        cnn, rnn = ctx.saved_tensors
+        g3, eps = ctx.cfg
+        dsim = _PairCE.backward(ctx, gl0, gl1)
+        dcnn = torch.empty_like(cnn)
+        call("mogan_damsm_sent_bwd", ptr(cnn), ptr(rnn), ptr(dsim), cnn.shape[0], rnn.shape[0], cnn.shape[1], g3, eps,
+             ptr(dcnn), stream_ptr())
+        return dcnn, None, None, None, None, None
+
+
+def damsm_sent(cnn, rnn, labels, mask, gamma3, eps=1e-8):
+    return DamsmSentFn.apply(cnn, rnn, labels, mask, float(gamma3), float(eps))
+
+
+class ScalarSumFn(torch.autograd.Function):
+    """sum_k w_k * x_k over up to 8 zero-dim device scalars in ONE launch (forward) / one launch (backward): the loss sums
+    of miscc/losses.py:169-174,203,221 and trainer.py:330 otherwise cost a chain of 0-dim aten kernels each way."""
+
+    @staticmethod
+    def forward(ctx, weights, *xs):
+        import ctypes
+        n = len(xs)
+        xs = [_c(x) for x in xs]
+        out = _scalar(xs[0].device)
+        pin = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+        pw = (ctypes.c_float * n)(*weights)
+        call("mogan_scalar_sum", ctypes.cast(pin, ctypes.c_void_p), ctypes.cast(pw, ctypes.c_void_p), n, ptr(out),
+             stream_ptr())
+        ctx.weights = weights
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        idx = [k for k in range(len(ctx.weights)) if ctx.needs_input_grad[1 + k]]
+        if not idx:
+            return (None,) * (1 + len(ctx.weights))
+        g = _c(g)
+        outs = [_scalar(g.device) for _ in idx]
+        n = len(idx)
+        pout = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+        pw = (ctypes.c_float * n)(*[ctx.weights[k] for k in idx])
+        call("mogan_scalar_scale", ptr(g), ctypes.cast(pw, ctypes.c_void_p), n, ctypes.cast(pout, ctypes.c_void_p),
+             stream_ptr())
+        grads = [None] * len(ctx.weights)
+        for k, o in zip(idx, outs):
+            grads[k] = o
+        return (None,) + tuple(grads)
+
+
+def scalar_sum(xs, weights=None):
+    """sum_k weights[k] * xs[k] of zero-dim fp32 device tensors (len <= 8; longer lists are summed in chunks)."""
+    xs = list(xs)
+    weights = [1.0] * len(xs) if weights is None else [float(w) for w in weights]
+    while len(xs) > 8:
+        head = ScalarSumFn.apply(tuple(weights[:8]), *xs[:8])
+        xs, weights = [head] + xs[8:], [1.0] + weights[8:]
+    return ScalarSumFn.apply(tuple(weights), *xs)
+
+
 # ------------------------------------------------------------------------------- pooling / resize
 class PoolFn(torch.autograd.Function):
     @staticmethod

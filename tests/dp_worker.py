@@ -23,6 +23,8 @@ def small_cfg():
     cfg.GAN.GF_DIM, cfg.GAN.DF_DIM, cfg.GAN.R_NUM, cfg.GAN.Z_DIM = 4, 4, 2, 100
     cfg.TEXT.EMBEDDING_DIM, cfg.TEXT.WORDS_NUM, cfg.TREE.BRANCH_NUM = 16, 5, 3
     cfg.TRAIN.GENERATOR_LR = cfg.TRAIN.DISCRIMINATOR_LR = 2e-4
+    cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.GAMMA2 = 4.0, 5.0           # cfg/coco_train.yml (= oracle.Cfg defaults)
+    cfg.TRAIN.SMOOTH.GAMMA3, cfg.TRAIN.SMOOTH.LAMBDA = 10.0, 50.0
     cfg.STN_ALIGN_CORNERS, cfg.ATT_MASK_MODE, cfg.ADAM_EPS_MODE = False, 0, 0
 
 

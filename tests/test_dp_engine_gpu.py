@@ -77,6 +77,7 @@ def test_two_rank_engine_step_equals_oracle_mean_gradient_step(tmp_path):
     # (2) = the oracle's step on the mean gradient
     init, st = _oracle_mean_gradient_step()
     lr = 2e-4
+    report, failures = [], []
     for name, got_sd, want_net, init_net, max_bad in [("G", r0["G"], st.g, init["G"], 0.15)] + \
             [("D%d" % i, r0["D"][i], st.ds[i], init["D"][i], 0.05) for i in range(3)]:
         n = bad = moved = 0
@@ -88,8 +89,13 @@ def test_two_rank_engine_step_equals_oracle_mean_gradient_step(tmp_path):
             n += d_want.numel()
             bad += int(((d_got - d_want).abs() > 0.25 * lr).sum())
             moved += int((d_want.abs() > 0.5 * lr).sum())
-            assert float(d_got.abs().max()) <= lr * 1.001, "%s %s moved by more than lr" % (name, k)
-        assert moved > 0.5 * n, "%s: the oracle moved only %d of %d elements" % (name, moved, n)
-        assert bad <= max_bad * n, "%s: %d of %d parameter deltas differ from the mean-gradient step by > lr/4" % (name, bad, n)
-        print("%s: %d parameters, %.2f%% of the deltas off by > lr/4 (allowed %.0f%%)" % (name, n, 100.0 * bad / n,
-                                                                                          100 * max_bad))
+            if float(d_got.abs().max()) > lr * 1.001:
+                failures.append("%s %s moved by more than lr" % (name, k))
+        report.append("%s: %d parameters, %.2f%% of the deltas off by > lr/4 (allowed %.0f%%), %.0f%% moved by > lr/2"
+                      % (name, n, 100.0 * bad / n, 100 * max_bad, 100.0 * moved / n))
+        if moved <= 0.5 * n:
+            failures.append("%s: the oracle moved only %d of %d elements" % (name, moved, n))
+        if bad > max_bad * n:
+            failures.append("%s: %d of %d parameter deltas differ from the mean-gradient step by > lr/4" % (name, bad, n))
+    print("\n".join(report))
+    assert not failures, "; ".join(failures) + " | " + " | ".join(report)

@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import det_array, load_pkg
+from helpers import det_array, load_pkg, max_abs, rel_l2
 from oracle import attngan_oracle as O
 
 load_pkg()
@@ -385,3 +385,42 @@ def test_adam_ema(eps_mode):
             ops.adam_step(pd, gd * step, m, v, emad, 2e-4, 0.5, 0.999, 1e-8, dev_state=state, eps_mode=eps_mode)
     assert float((pd.cpu().double() - net["w"].detach()).abs().max()) < 1e-6   # |p|~3: 2-3 ulp
     assert float((emad.cpu().double() - ema).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,hw,Tw,same_class", [(16, 256, 17, 12, False), (5, 32, 6, 7, True), (3, 16, 17, 18, False)])
+def test_damsm_words_and_sentence_losses(B, C, hw, Tw, same_class):
+    """mogan_damsm_words_fwd/bwd + mogan_damsm_ce_* + mogan_damsm_sent_* (miscc/losses.py:20-132, one func_attention per
+    caption in the reference) against the fp64 oracle: both cross-entropies, the attention maps, the gradients w.r.t.
+    the region features / the image code; ragged caption lengths, optional same-class mask, full benchmark size."""
+    from mogan_amd.attngan.miscc import losses as L
+    from mogan_amd.attngan.miscc.config import cfg
+    cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.GAMMA2, cfg.TRAIN.SMOOTH.GAMMA3 = 4.0, 5.0, 10.0
+    ocfg = O.Cfg(words_num=Tw)
+    feat = T("damsm.feat%d" % B, (B, C, hw, hw))
+    words = T("damsm.words%d" % B, (B, C, Tw))
+    code, sent = T("damsm.code%d" % B, (B, C)), T("damsm.sent%d" % B, (B, C))
+    lens = np.sort(np.random.RandomState(B).randint(2, Tw + 1, B))[::-1].copy()
+    lens[0] = Tw
+    class_ids = np.arange(B)
+    if same_class:
+        class_ids[2] = class_ids[0]                       # samples 0 and 2 share a class: masked out of each other's rows
+    fd, cd = feat.double().requires_grad_(True), code.double().requires_grad_(True)
+    w0, w1, att = O.words_loss(fd, words.double(), lens, ocfg, class_ids if same_class else None)
+    s0, s1 = O.sent_loss(cd, sent.double(), ocfg, class_ids if same_class else None)
+    (1.3 * w0 + 0.7 * w1 + 2.0 * s0 + 0.5 * s1).backward()
+    fg, cg = feat.to(DEV).requires_grad_(True), code.to(DEV).requires_grad_(True)
+    lab = torch.arange(B, device=DEV)
+    lens_t = torch.from_numpy(lens.astype(np.int64))
+    g0, g1, _ = L.words_loss(fg, words.to(DEV), lab, lens_t, class_ids, B)
+    t0, t1 = L.sent_loss(cg, sent.to(DEV), lab, class_ids, B)
+    ops.scalar_sum([g0, g1, t0, t1], [1.3, 0.7, 2.0, 0.5]).backward()
+    torch.cuda.synchronize()
+    for got, want, k in ((g0, w0, "w0"), (g1, w1, "w1"), (t0, s0, "s0"), (t1, s1, "s1")):
+        np.testing.assert_allclose(float(got), float(want), rtol=2e-5, err_msg=k)
+    assert rel_l2(fg.grad, fd.grad) <= 2e-5, rel_l2(fg.grad, fd.grad)
+    assert rel_l2(cg.grad, cd.grad) <= 2e-5, rel_l2(cg.grad, cd.grad)
+    with torch.no_grad():
+        _, _, maps = L.words_loss(fg, words.to(DEV), None, lens_t, class_ids, B)
+    for i in (0, B - 1):
+        assert tuple(maps[i].shape) == (1, int(lens[i]), hw, hw)
+        assert max_abs(maps[i], att[i]) <= 2e-6

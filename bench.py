@@ -183,6 +183,8 @@ def cpu_baseline_leg(engine, bt_cpu, dev_batch, B, device, timed_steps=2, budget
     for k, name in (("fake64", "img64_max_abs"), ("fake_last", "img256_max_abs")):
         assert torch.isfinite(hlogs[k]).all(), "non-finite %s in the HIP step" % k
         parity[name] = float((hlogs[k].detach().cpu() - ologs[k]).abs().max())
+    parity["hip"] = {k: float(v) for k, v in hlogs.items() if torch.is_tensor(v) and v.dim() == 0}
+    parity["oracle"] = {k: float(v) for k, v in ologs.items() if not torch.is_tensor(v)}
     parity["ok"] = bool(all(parity[k + "_rel"] <= 1e-4 for k in ("errD0", "errD1", "errD2", "errG", "w_loss", "s_loss"))
                         and parity["img64_max_abs"] <= 1e-3 and parity["img256_max_abs"] <= 1e-3)
     parity["what"] = ("one full-width B=%d train step from the benchmarked engine's weights, same z/eps: HIP vs the CPU oracle "

@@ -94,6 +94,22 @@ int mogan_conv2d_affine_fwd(const float* x, const float* w, const float* scale, 
 int mogan_affine_relu_bwd_out(const float* y, const float* dy, const float* scale, float* dx, int B, int C, int HW,
                               hipStream_t stream);
 /* dx: gradient w.r.t. the conv input in the H x W domain, (B,Cin,H,W); for up=1 follow with mogan_down2_sum */
+/* Channel-slice addressing for the frozen Inception trunk (model.py:258-299): x is a slice (batch stride x_bstride
+ * elements) of a larger NCHW tensor; output channels [0, msplit) go to y (batch stride y_bstride, -1 = dense), channels
+ * [msplit, Cout) to y2 (y2 nullable: everything to y).  One launch then serves a group of same-input 1x1 convolutions whose
+ * parts land in different tensors, and every branch of a Mixed block writes straight into the block's concatenated
+ * output. */
+int mogan_conv2d_affine_fwd_ex(const float* x, long long x_bstride, const float* w, const float* scale, const float* shift,
+                               float* y, long long y_bstride, float* y2, long long y2_bstride, int msplit, int B, int Cin,
+                               int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int relu, void* ws,
+                               size_t ws_bytes, hipStream_t stream);
+/* Data gradient with channel-slice addressing and a fused ReLU backward: dy is a slice with batch stride dy_bstride, the
+ * result is written (accumulate 0) or added (1) to the slice dx (batch stride dx_bstride); where relu_of[...] <= 0 (a
+ * slice shaped like dx with batch stride relu_bstride; nullable) the new contribution is zeroed first. */
+int mogan_conv2d_dgrad_ex(const float* dy, long long dy_bstride, const float* w, float* dx, long long dx_bstride,
+                          const float* relu_of, long long relu_bstride, int accumulate, int B, int Cin, int Hs, int Ws,
+                          int Cout, int KH, int KW, int stride, int ph, int pw, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
 int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
 /* dw (Cout,Cin,KH,KW); accumulate != 0 adds into dw */
@@ -263,6 +279,21 @@ int mogan_maxpool_bwd(const uint8_t* idx, const float* dy, float* dx, int planes
 int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, int pad, hipStream_t stream);
 int mogan_avgpool_bwd(const float* dy, float* dx, int planes, int H, int W, int k, int s, int pad,
                       hipStream_t stream);
+/* Channel-slice variants for the frozen encoder's explicit forward / backward (attngan/inception.py): y / dy are slices
+ * of tensors with the given batch stride (elements; -1 = dense), the pooling gradients are added to dx when
+ * accumulate != 0 after being zeroed where relu_of <= 0 (relu_of: dense, shaped like dx; nullable) -- the ReLU backward
+ * of the layer that produced the pooled tensor. */
+int mogan_maxpool_fwd_ex(const float* x, float* y, long long y_bstride, uint8_t* idx, int B, int C, int H, int W, int k,
+                         int s, hipStream_t stream);
+int mogan_maxpool_bwd_ex(const uint8_t* idx, const float* dy, long long dy_bstride, float* dx, const float* relu_of,
+                         int accumulate, int B, int C, int H, int W, int k, int s, hipStream_t stream);
+int mogan_avgpool_bwd_ex(const float* dy, float* dx, const float* relu_of, int accumulate, int planes, int H, int W, int k,
+                         int s, int pad, hipStream_t stream);
+/* dx (+)= dz where z > 0 (z: the ReLU's output) */
+int mogan_relu_bwd(const float* z, const float* dz, float* dx, long long n, int accumulate, hipStream_t stream);
+/* B rows of n contiguous floats between two batch-strided tensors */
+int mogan_copy_strided(const float* src, long long src_bstride, float* dst, long long dst_bstride, int B, long long n,
+                       hipStream_t stream);
 int mogan_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 int mogan_bilinear_bwd(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 

@@ -207,3 +207,346 @@ def init_trunk(module):
         elif isinstance(m, HipBatchNorm2d):
             nn.init.constant_(m.weight, 1.0)
             nn.init.constant_(m.bias, 0.0)
+
+
+# ======================================================================================================================
+# Frozen trunk: explicit forward / backward (the train step's path; model.py:62-66 freezes the encoder, trainer.py:329-333
+# sends only the image gradient through it).
+#
+# The module-by-module evaluation above costs, per Mixed block, one launch per BasicConv2d, a torch.cat of the branch
+# outputs, and in the backward pass a ReLU/affine kernel per convolution plus the slice copies and additions autograd
+# inserts around cat and around an activation with several consumers.  With the weights frozen none of that bookkeeping is
+# needed:
+#   * the 1x1 convolutions that read the same block input (branch1x1, branch5x5_1 / 7x7_1 / 3x3_1, ...dbl_1) run as ONE
+#     convolution over the concatenated filters (mogan_conv2d_affine_fwd_ex: output channels below `msplit` go straight
+#     into the block's output tensor, the rest into the block's scratch tensor); their data gradient is ONE convolution
+#     with the output-channel axis (= K of the GEMM) concatenated;
+#   * every branch writes its result straight into its channel slice of the block output (no cat), every data gradient
+#     reads its slice of the output gradient (no split) and ADDS into the gradient of its input (no add kernels);
+#   * ReLU backward is fused into the data-gradient kernels: a convolution whose input is a ReLU output zeroes its result
+#     where that input is 0 (mogan_conv2d_dgrad_ex relu_of), so a gradient buffer is always "already masked";
+#   * eval-mode BN: y = relu(scale * conv(x; W) + shift) forward; backward uses W' = scale * W (precomputed once).
+# Same arithmetic as the modules above up to the rounding of W' (checked against the module path and the CPU restatement).
+FAST_TRUNK = os.environ.get("MOGAN_INCEPTION_FAST", "1") != "0"
+
+
+class _Slice:
+    """channels [c0, c0 + C) of a dense (B, Ctot, H, W) tensor"""
+    __slots__ = ("t", "c0", "C")
+
+    def __init__(self, t, c0=0, C=None):
+        self.t, self.c0, self.C = t, c0, (t.shape[1] - c0 if C is None else C)
+
+    @property
+    def H(self):
+        return self.t.shape[2]
+
+    @property
+    def W(self):
+        return self.t.shape[3]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.c0 * self.t.shape[2] * self.t.shape[3]
+
+    @property
+    def bstride(self):
+        return self.t.stride(0)              # (a gradient buffer may itself be a channel slice: _Tape.scratch_for_group)
+
+    @property
+    def dense(self):
+        return self.c0 == 0 and self.C == self.t.shape[1] and self.t.is_contiguous()
+
+
+class _FrozenConv:
+    """one BasicConv2d (or a group of same-input 1x1 ones) with eval-mode BN folded: forward (w, scale, shift), backward w * scale"""
+
+    def __init__(self, mods):
+        mods = list(mods)
+        m0 = mods[0].conv
+        self.k, self.stride, self.pad = m0.kernel_size, m0.stride[0], m0.padding
+        for m in mods[1:]:
+            assert m.conv.kernel_size == self.k and m.conv.stride[0] == self.stride and m.conv.padding == self.pad
+        with torch.no_grad():
+            self.w = torch.cat([m.conv.weight for m in mods], 0).contiguous()
+            folded = [m.folded() for m in mods]
+            self.scale = torch.cat([f[0] for f in folded]).contiguous()
+            self.shift = torch.cat([f[1] for f in folded]).contiguous()
+            self.wb = (self.w * self.scale.view(-1, 1, 1, 1)).contiguous()
+        self.cout, self.cin = self.w.shape[0], self.w.shape[1]
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad[0] - self.k[0]) // self.stride + 1, (W + 2 * self.pad[1] - self.k[1]) // self.stride + 1)
+
+
+class _Tape:
+    """forward launches + what the backward pass needs; one per forward call"""
+
+    def __init__(self, B, device):
+        self.B, self.dev, self.ops, self.grads = B, device, [], {}
+
+    def new(self, C, H, W):
+        return torch.empty((self.B, C, H, W), dtype=torch.float32, device=self.dev)
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def conv(self, fc, x, y, y2=None, relu_in=True, plain=False):
+        """y (and y2: channels >= y.C of a grouped convolution) = relu(bn(conv(x))).  relu_in: x is a ReLU output (its
+        zeros gate the data gradient).  plain: dense in/out through the ordinary entry point (fast paths allowed)."""
+        from ..hip.lib import call, stream_ptr, workspace
+        wsp, wsn = workspace(x.t.device)
+        assert x.C == fc.cin and y.C + (y2.C if y2 is not None else 0) == fc.cout
+        if plain:
+            assert x.dense and y.dense and y2 is None
+            call("mogan_conv2d_affine_fwd", x.ptr, fc.w.data_ptr(), fc.scale.data_ptr(), fc.shift.data_ptr(), y.ptr, self.B,
+                 fc.cin, x.H, x.W, fc.cout, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 1, wsp, wsn, stream_ptr())
+        else:
+            call("mogan_conv2d_affine_fwd_ex", x.ptr, x.bstride, fc.w.data_ptr(), fc.scale.data_ptr(), fc.shift.data_ptr(),
+                 y.ptr, y.bstride, y2.ptr if y2 is not None else None, y2.bstride if y2 is not None else 0, y.C, self.B,
+                 fc.cin, x.H, x.W, fc.cout, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 1, wsp, wsn, stream_ptr())
+        self.ops.append(("conv", fc, x, y, y2, relu_in, plain))
+
+    def avgpool(self, x, y, k, s, pad, relu_in=True):
+        from ..hip.lib import call, stream_ptr
+        assert x.dense and y.dense
+        call("mogan_avgpool_fwd", x.ptr, y.ptr, self.B * x.C, x.H, x.W, k, s, pad, stream_ptr())
+        self.ops.append(("avgpool", x, y, k, s, pad, relu_in))
+
+    def maxpool(self, x, y, k, s, relu_in=True):
+        from ..hip.lib import call, stream_ptr
+        assert x.dense
+        idx = torch.empty((self.B, x.C, y.H, y.W), dtype=torch.uint8, device=self.dev)
+        call("mogan_maxpool_fwd_ex", x.ptr, y.ptr, y.bstride, idx.data_ptr(), self.B, x.C, x.H, x.W, k, s, stream_ptr())
+        self.ops.append(("maxpool", x, y, idx, k, s, relu_in))
+
+    # ---- backward ---------------------------------------------------------------------------------------------
+    def grad_of(self, t):
+        g = self.grads.get(id(t))
+        if g is None:
+            g = self.grads[id(t)] = [torch.empty_like(t), set()]      # buffer, written channel ranges
+        return g
+
+    def _dst(self, x):
+        """gradient slice of x + whether a contribution is already there (then: accumulate)"""
+        g, written = self.grad_of(x.t)
+        key = (x.c0, x.C)
+        acc = key in written
+        written.add(key)
+        return _Slice(g, x.c0, x.C), acc
+
+    def seed(self, t, g, relu=True):
+        """gradient arriving from outside for tensor t (a ReLU output): masked, added to what the tape already holds"""
+        from ..hip.lib import call, stream_ptr
+        dst, acc = self._dst(_Slice(t))
+        g = g.contiguous()
+        call("mogan_relu_bwd", t.data_ptr(), g.data_ptr(), dst.ptr, t.numel(), 1 if acc else 0, stream_ptr())
+
+    def backward(self):
+        from ..hip.lib import call, stream_ptr, workspace
+        for op in reversed(self.ops):
+            kind = op[0]
+            if kind == "conv":
+                _, fc, x, y, y2, relu_in, plain = op
+                wsp, wsn = workspace(self.dev)
+                gy, _ = self.grad_of(y.t)
+                if y2 is not None:
+                    # the group's gradient = [slice of the block-output gradient | gradient of the scratch tensor]: bring
+                    # the first part next to the second (the scratch gradient was allocated with room in front)
+                    g2, _ = self.grad_of(y2.t)
+                    full = g2._mogan_full
+                    call("mogan_copy_strided", _Slice(gy, y.c0, y.C).ptr, y.bstride, full.data_ptr(),
+                         full.shape[1] * full.shape[2] * full.shape[3], self.B, y.C * y.H * y.W, stream_ptr())
+                    dy = _Slice(full)
+                else:
+                    dy = _Slice(gy, y.c0, y.C)
+                dx, acc = self._dst(x)
+                if plain:
+                    assert not acc and dx.dense and dy.dense
+                    call("mogan_conv2d_dgrad", dy.ptr, fc.wb.data_ptr(), dx.ptr, self.B, fc.cin, x.H, x.W, fc.cout, fc.k[0],
+                         fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 0, wsp, wsn, stream_ptr())
+                    if relu_in:
+                        call("mogan_relu_bwd", x.t.data_ptr(), dx.ptr, dx.ptr, x.t.numel(), 0, stream_ptr())
+                else:
+                    call("mogan_conv2d_dgrad_ex", dy.ptr, dy.bstride, fc.wb.data_ptr(), dx.ptr, dx.bstride,
+                         x.ptr if relu_in else None, x.bstride, 1 if acc else 0, self.B, fc.cin, x.H, x.W, fc.cout, fc.k[0],
+                         fc.k[1], fc.stride, fc.pad[0], fc.pad[1], wsp, wsn, stream_ptr())
+            elif kind == "avgpool":
+                _, x, y, k, s, pad, relu_in = op
+                gy, _ = self.grad_of(y.t)
+                dx, acc = self._dst(x)
+                call("mogan_avgpool_bwd_ex", gy.data_ptr(), dx.ptr, x.ptr if relu_in else None, 1 if acc else 0,
+                     self.B * x.C, x.H, x.W, k, s, pad, stream_ptr())
+            else:
+                _, x, y, idx, k, s, relu_in = op
+                gy, _ = self.grad_of(y.t)
+                dy = _Slice(gy, y.c0, y.C)
+                dx, acc = self._dst(x)
+                call("mogan_maxpool_bwd_ex", idx.data_ptr(), dy.ptr, dy.bstride, dx.ptr, x.ptr if relu_in else None,
+                     1 if acc else 0, self.B, x.C, x.H, x.W, k, s, stream_ptr())
+
+    def scratch_for_group(self, n_front, C, H, W):
+        """scratch tensor of a grouped 1x1 convolution whose first n_front output channels live in the block output: its
+        GRADIENT buffer gets n_front channels of room in front, so that the group's data gradient reads one tensor"""
+        t = self.new(C, H, W)
+        full = torch.empty((self.B, n_front + C, H, W), dtype=torch.float32, device=self.dev)
+        # the scratch gradient as a channel slice of `full`: (storage shared, batch stride of `full`)
+        g = full[:, n_front:]
+        g._mogan_full = full
+        self.grads[id(t)] = [g, set()]
+        return t
+
+
+class FrozenTrunk:
+    """Folded weights of an eval-mode, frozen CNN_ENCODER trunk + its explicit forward/backward (see the section comment)."""
+
+    def __init__(self, enc):
+        g = lambda *names: _FrozenConv([getattr(blk, n) for n in names])
+        self.stem = {n: _FrozenConv([getattr(enc, n)]) for n in ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3",
+                                                               "Conv2d_3b_1x1", "Conv2d_4a_3x3")}
+        self.blocks = []
+        for name, _ in TRUNK[5:]:
+            blk = getattr(enc, name)
+            if isinstance(blk, InceptionA):
+                fcs = dict(g1=g("branch1x1", "branch5x5_1", "branch3x3dbl_1"), b5=g("branch5x5_2"), d2=g("branch3x3dbl_2"),
+                           d3=g("branch3x3dbl_3"), bp=g("branch_pool"))
+            elif isinstance(blk, InceptionB):
+                fcs = dict(b3=g("branch3x3"), d1=g("branch3x3dbl_1"), d2=g("branch3x3dbl_2"), d3=g("branch3x3dbl_3"))
+            elif isinstance(blk, InceptionC):
+                fcs = dict(g1=g("branch1x1", "branch7x7_1", "branch7x7dbl_1"), s2=g("branch7x7_2"), s3=g("branch7x7_3"),
+                           d2=g("branch7x7dbl_2"), d3=g("branch7x7dbl_3"), d4=g("branch7x7dbl_4"), d5=g("branch7x7dbl_5"),
+                           bp=g("branch_pool"))
+            elif isinstance(blk, InceptionD):
+                fcs = dict(g1=g("branch3x3_1", "branch7x7x3_1"), b2=g("branch3x3_2"), s2=g("branch7x7x3_2"),
+                           s3=g("branch7x7x3_3"), s4=g("branch7x7x3_4"))
+            else:
+                fcs = dict(g1=g("branch1x1", "branch3x3_1", "branch3x3dbl_1"), a=g("branch3x3_2a"), b=g("branch3x3_2b"),
+                           d2=g("branch3x3dbl_2"), da=g("branch3x3dbl_3a"), db=g("branch3x3dbl_3b"), bp=g("branch_pool"))
+            self.blocks.append((name, type(blk).__name__, fcs))
+
+    # each block: x (dense _Slice) -> dense output tensor
+    @staticmethod
+    def _block(tp, kind, f, x):
+        B, H, W = tp.B, x.H, x.W
+        if kind == "InceptionA":
+            n1, n5, nd = 64, 48, 64
+            O = tp.new(n1 + f["b5"].cout + f["d3"].cout + f["bp"].cout, H, W)
+            T = tp.scratch_for_group(n1, n5 + nd, H, W)
+            tp.conv(f["g1"], x, _Slice(O, 0, n1), _Slice(T))
+            tp.conv(f["b5"], _Slice(T, 0, n5), _Slice(O, n1, 64))
+            U = tp.new(96, H, W)
+            tp.conv(f["d2"], _Slice(T, n5, nd), _Slice(U))
+            tp.conv(f["d3"], _Slice(U), _Slice(O, n1 + 64, 96))
+            P = tp.new(x.C, H, W)
+            tp.avgpool(x, _Slice(P), 3, 1, 1)
+            tp.conv(f["bp"], _Slice(P), _Slice(O, n1 + 64 + 96, f["bp"].cout), relu_in=False)
+            return O
+        if kind == "InceptionB":
+            oh, ow = f["b3"].out_hw(H, W)
+            O = tp.new(384 + 96 + x.C, oh, ow)
+            tp.conv(f["b3"], x, _Slice(O, 0, 384))
+            T, U = tp.new(64, H, W), tp.new(96, H, W)
+            tp.conv(f["d1"], x, _Slice(T))
+            tp.conv(f["d2"], _Slice(T), _Slice(U))
+            tp.conv(f["d3"], _Slice(U), _Slice(O, 384, 96))
+            tp.maxpool(x, _Slice(O, 480, x.C), 3, 2)
+            return O
+        if kind == "InceptionC":
+            c7 = f["s2"].cin
+            O = tp.new(768, H, W)
+            T = tp.scratch_for_group(192, 2 * c7, H, W)
+            tp.conv(f["g1"], x, _Slice(O, 0, 192), _Slice(T))
+            V = tp.new(c7, H, W)
+            tp.conv(f["s2"], _Slice(T, 0, c7), _Slice(V))
+            tp.conv(f["s3"], _Slice(V), _Slice(O, 192, 192))
+            W1, W2, W3 = tp.new(c7, H, W), tp.new(c7, H, W), tp.new(c7, H, W)
+            tp.conv(f["d2"], _Slice(T, c7, c7), _Slice(W1))
+            tp.conv(f["d3"], _Slice(W1), _Slice(W2))
+            tp.conv(f["d4"], _Slice(W2), _Slice(W3))
+            tp.conv(f["d5"], _Slice(W3), _Slice(O, 384, 192))
+            P = tp.new(x.C, H, W)
+            tp.avgpool(x, _Slice(P), 3, 1, 1)
+            tp.conv(f["bp"], _Slice(P), _Slice(O, 576, 192), relu_in=False)
+            return O
+        if kind == "InceptionD":
+            oh, ow = f["b2"].out_hw(H, W)
+            O = tp.new(320 + 192 + x.C, oh, ow)
+            T = tp.new(384, H, W)
+            tp.conv(f["g1"], x, _Slice(T))
+            tp.conv(f["b2"], _Slice(T, 0, 192), _Slice(O, 0, 320))
+            V1, V2 = tp.new(192, H, W), tp.new(192, H, W)
+            tp.conv(f["s2"], _Slice(T, 192, 192), _Slice(V1))
+            tp.conv(f["s3"], _Slice(V1), _Slice(V2))
+            tp.conv(f["s4"], _Slice(V2), _Slice(O, 320, 192))
+            tp.maxpool(x, _Slice(O, 512, x.C), 3, 2)
+            return O
+        # InceptionE
+        O = tp.new(2048, H, W)
+        T = tp.scratch_for_group(320, 384 + 448, H, W)
+        tp.conv(f["g1"], x, _Slice(O, 0, 320), _Slice(T))
+        tp.conv(f["a"], _Slice(T, 0, 384), _Slice(O, 320, 384))
+        tp.conv(f["b"], _Slice(T, 0, 384), _Slice(O, 704, 384))
+        U = tp.new(384, H, W)
+        tp.conv(f["d2"], _Slice(T, 384, 448), _Slice(U))
+        tp.conv(f["da"], _Slice(U), _Slice(O, 1088, 384))
+        tp.conv(f["db"], _Slice(U), _Slice(O, 1472, 384))
+        P = tp.new(x.C, H, W)
+        tp.avgpool(x, _Slice(P), 3, 1, 1)
+        tp.conv(f["bp"], _Slice(P), _Slice(O, 1856, 192), relu_in=False)
+        return O
+
+    def forward(self, x299):
+        """x299: (B,3,299,299) dense.  -> tape, features (B,768,17,17) = Mixed_6e output, Mixed_7c output (B,2048,8,8)"""
+        tp = _Tape(x299.shape[0], x299.device)
+        st = self.stem
+        cur = _Slice(x299)
+        plan = (("Conv2d_1a_3x3", False, True), ("Conv2d_2a_3x3", True, False), ("Conv2d_2b_3x3", True, False), "pool",
+                ("Conv2d_3b_1x1", True, False), ("Conv2d_4a_3x3", True, True), "pool")
+        for step in plan:
+            if step == "pool":
+                y = _Slice(tp.new(cur.C, (cur.H - 3) // 2 + 1, (cur.W - 3) // 2 + 1))
+                tp.maxpool(cur, y, 3, 2)
+            else:
+                name, relu_in, plain_bwd = step
+                fc = st[name]
+                oh, ow = fc.out_hw(cur.H, cur.W)
+                y = _Slice(tp.new(fc.cout, oh, ow))
+                # forward through the ordinary entry point (Winograd / streaming kernels where they apply); `plain` also
+                # keeps the backward on it where that matters (first convolution: streaming kernel; 4a: Winograd)
+                tp.conv(fc, cur, y, relu_in=relu_in, plain=True)
+                if not plain_bwd:
+                    tp.ops[-1] = tp.ops[-1][:6] + (False,)
+            cur = y
+        feats = None
+        for name, kind, fcs in self.blocks:
+            cur = _Slice(self._block(tp, kind, fcs, cur))
+            if name == "Mixed_6e":
+                feats = cur.t
+        return tp, feats, cur.t
+
+
+class _FrozenTrunkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x299, trunk):
+        xc = x299.contiguous()
+        tp, feats, last = trunk.forward(xc)
+        ctx.tape, ctx.x, ctx.outs = tp, xc, (feats, last)
+        return feats, last
+
+    @staticmethod
+    def backward(ctx, gfeat, glast):
+        tp = ctx.tape
+        feats, last = ctx.outs
+        tp.seed(last, glast if glast is not None else torch.zeros_like(last))
+        if gfeat is not None:
+            tp.seed(feats, gfeat)
+        tp.backward()
+        g, _ = tp.grad_of(ctx.x)
+        ctx.tape = None
+        return g, None
+
+
+def frozen_trunk(enc, x299):
+    """(features 768x17x17, Mixed_7c output 2048x8x8) of the frozen eval-mode trunk of `enc` (a CNN_ENCODER)."""
+    ft = getattr(enc, "_frozen_trunk", None)
+    if ft is None or ft.stem["Conv2d_1a_3x3"].w.device != x299.device:
+        ft = enc._frozen_trunk = FrozenTrunk(enc)
+    return _FrozenTrunkFn.apply(x299, ft)

@@ -144,8 +144,16 @@ class CNN_ENCODER(nn.Module):
         self.emb_features.weight.data.uniform_(-0.1, 0.1)
         self.emb_cnn_code.weight.data.uniform_(-0.1, 0.1)
 
+    def _frozen(self):
+        return inception.FAST_TRUNK and not self.training and not any(p.requires_grad for p in self.parameters())
+
     def forward(self, x):
         x = ops.bilinear_resize(x, 299, 299)
+        if self._frozen():
+            # the train step's case (trainer.py:62-66): explicit forward/backward over the folded, grouped trunk
+            features, x = inception.frozen_trunk(self, x)
+            x = ops.avg_pool2d(x, 8).view(x.size(0), -1)
+            return self.emb_features(features), self.emb_cnn_code(x)
         x = self.Conv2d_2b_3x3(self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x)))
         x = ops.max_pool2d(x, 3, 2)
         x = self.Conv2d_4a_3x3(self.Conv2d_3b_1x1(x))

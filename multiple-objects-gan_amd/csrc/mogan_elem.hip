@@ -121,6 +121,25 @@ __global__ __launch_bounds__(256) void down2_sum_kernel(const float* __restrict_
     }
 }
 
+// ReLU backward on its own: dx (+)= dz where z > 0 (z = the ReLU's output)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dz,
+                                                       float* __restrict__ dx, long long n, int accumulate) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float g = z[i] > 0.f ? dz[i] : 0.f;
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// rows of n contiguous floats between two batch-strided tensors (channel slices of NCHW tensors)
+__global__ __launch_bounds__(256) void copy_strided_kernel(const float* __restrict__ src, long long sbs,
+                                                           float* __restrict__ dst, long long dbs, long long n,
+                                                           long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / n, r = i - b * n;
+        dst[b * dbs + r] = src[b * sbs + r];
+    }
+}
+
 // -------------------------------------------------------------------------------- strided softmax
 // x viewed (outer, L, inner); one thread per (o, i) column, three passes over L (L <= a few hundred).
 template <bool BWD>
@@ -223,23 +242,25 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ m
 // idx (nullable) records the offset a*k+b of the first maximum of each window for the backward
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ idx, long long total, int H, int W,
-                                                          int OH, int OW, int k, int s) {
+                                                          int OH, int OW, int k, int s, int C, long long ybs) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+        const long long yo = (pl / C) * ybs + ((pl % C) * OH + oy) * (long long)OW + ox;     // (strided) output position
         const float* px = x + pl * H * W;
         float m = -INFINITY; int am = 0;
         for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) {
             const float v = px[(oy * s + a) * W + ox * s + b];
             if (v > m) { m = v; am = a * k + b; }
         }
-        y[i] = m;
+        y[yo] = m;
         if (idx) idx[i] = (uint8_t)am;
     }
 }
 // gather form: dx[p,iy,ix] = sum over the windows that contain (iy,ix) and whose first maximum is there
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy,
                                                           float* __restrict__ dx, long long total, int H, int W, int OH,
-                                                          int OW, int k, int s) {
+                                                          int OW, int k, int s, int C, long long dybs,
+                                                          const float* __restrict__ relu_of, int accumulate) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
         float g = 0.f;
@@ -248,9 +269,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
         for (int oy = oy0; oy <= oy1; ++oy)
             for (int ox = ox0; ox <= ox1; ++ox) {
                 const long long o = (pl * OH + oy) * OW + ox;
-                if ((int)idx[o] == (iy - oy * s) * k + (ix - ox * s)) g += dy[o];
+                if ((int)idx[o] == (iy - oy * s) * k + (ix - ox * s))
+                    g += dy[(pl / C) * dybs + ((pl % C) * OH + oy) * (long long)OW + ox];
             }
-        dx[i] = g;
+        if (relu_of && !(relu_of[i] > 0.f)) g = 0.f;
+        dx[i] = accumulate ? dx[i] + g : g;
     }
 }
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -270,7 +293,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                           long long total, int H, int W, int OH, int OW, int k, int s,
-                                                          int pad) {
+                                                          int pad, const float* __restrict__ relu_of, int accumulate) {
     const float inv = 1.f / (float)(k * k);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
@@ -280,7 +303,9 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
         float g = 0.f;
         for (int oy = oy0; oy <= oy1; ++oy)
             for (int ox = ox0; ox <= ox1; ++ox) g += dy[(pl * OH + oy) * OW + ox];
-        dx[i] = g * inv;
+        g *= inv;
+        if (relu_of && !(relu_of[i] > 0.f)) g = 0.f;
+        dx[i] = accumulate ? dx[i] + g : g;
     }
 }
 // bilinear, align_corners = False (torch area_pixel_compute_source_index)
@@ -507,22 +532,47 @@ int mogan_reparam_bwd(const float* logvar, const float* eps, const float* dc, fl
     return ok_launch();
 }
 
+int mogan_relu_bwd(const float* z, const float* dz, float* dx, long long n, int accumulate, hipStream_t stream) {
+    if (n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, z, dz, dx, n, accumulate);
+    return ok_launch();
+}
+
+int mogan_copy_strided(const float* src, long long src_bstride, float* dst, long long dst_bstride, int B, long long n,
+                       hipStream_t stream) {
+    if (B <= 0 || n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3(nblk((long long)B * n)), dim3(256), 0, stream, src, src_bstride, dst,
+                       dst_bstride, n, (long long)B * n);
+    return ok_launch();
+}
+
+int mogan_maxpool_fwd_ex(const float* x, float* y, long long y_bstride, uint8_t* idx, int B, int C, int H, int W, int k,
+                         int s, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || k <= 0 || s <= 0 || H < k || W < k || k * k > 255) return MOGAN_ERR_SHAPE;
+    const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
+    if (y_bstride < 0) y_bstride = (long long)C * OH * OW;
+    const long long n = (long long)B * C * OH * OW;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, idx, n, H, W, OH, OW, k, s, C,
+                       y_bstride);
+    return ok_launch();
+}
 int mogan_maxpool_fwd(const float* x, float* y, uint8_t* idx, int planes, int H, int W, int k, int s,
                       hipStream_t stream) {
+    return mogan_maxpool_fwd_ex(x, y, -1, idx, 1, planes, H, W, k, s, stream);
+}
+int mogan_maxpool_bwd_ex(const uint8_t* idx, const float* dy, long long dy_bstride, float* dx, const float* relu_of,
+                         int accumulate, int B, int C, int H, int W, int k, int s, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || k <= 0 || s <= 0 || H < k || W < k) return MOGAN_ERR_SHAPE;
     const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
-    if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
-    const long long n = (long long)planes * OH * OW;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, idx, n, H, W, OH, OW, k, s);
+    if (dy_bstride < 0) dy_bstride = (long long)C * OH * OW;
+    const long long n = (long long)B * C * H * W;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, idx, dy, dx, n, H, W, OH, OW, k, s, C,
+                       dy_bstride, relu_of, accumulate);
     return ok_launch();
 }
 int mogan_maxpool_bwd(const uint8_t* idx, const float* dy, float* dx, int planes, int H, int W, int k, int s,
                       hipStream_t stream) {
-    const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
-    if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
-    const long long n = (long long)planes * H * W;
-    if (k * k > 255) return MOGAN_ERR_SHAPE;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, idx, dy, dx, n, H, W, OH, OW, k, s);
-    return ok_launch();
+    return mogan_maxpool_bwd_ex(idx, dy, -1, dx, nullptr, 0, 1, planes, H, W, k, s, stream);
 }
 int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k, int s, int pad, hipStream_t stream) {
     const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
@@ -531,13 +581,18 @@ int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k,
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW, k, s, pad);
     return ok_launch();
 }
+int mogan_avgpool_bwd_ex(const float* dy, float* dx, const float* relu_of, int accumulate, int planes, int H, int W, int k,
+                         int s, int pad, hipStream_t stream) {
+    if (planes <= 0 || k <= 0 || s <= 0) return MOGAN_ERR_SHAPE;
+    const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
+    const long long n = (long long)planes * H * W;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW, k, s, pad, relu_of,
+                       accumulate);
+    return ok_launch();
+}
 int mogan_avgpool_bwd(const float* dy, float* dx, int planes, int H, int W, int k, int s, int pad,
                       hipStream_t stream) {
-    const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
-    if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
-    const long long n = (long long)planes * H * W;
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW, k, s, pad);
-    return ok_launch();
+    return mogan_avgpool_bwd_ex(dy, dx, nullptr, 0, planes, H, W, k, s, pad, stream);
 }
 int mogan_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;

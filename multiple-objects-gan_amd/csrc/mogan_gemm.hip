@@ -72,6 +72,12 @@ struct GemmP {
     // bmm strides (elements)
     long long sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn;
     int a_lane_k, b_lane_n;
+    // strided convolution I/O (channel slices of larger NCHW tensors): batch stride of the gathered operand (x / dY)
+    // and of the output; CONV_FWD may send the output channels m >= msplit to a second destination; CONV_DGRAD may
+    // zero the result where mask <= 0 (ReLU backward of the layer that produced the conv input) before accumulating
+    unsigned xbs; long long ybs;
+    float* C2; long long ybs2; int msplit;
+    const float* mask; long long mbs;
     int avec;                    // 16-byte loads legal for the k-contiguous operand(s)
     unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (< 4 GiB)
 };
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             const int img = nn / OHW, pix = nn - img * OHW;
             const int oy = pix / p.OW, ox = pix - oy * p.OW;
             ny0[i] = oy * p.s - p.ph; nx0[i] = ox * p.s - p.pw;
-            nbase[i] = (unsigned)img * p.Cin * HsWs;
+            nbase[i] = (unsigned)img * p.xbs;
         }
     }
     if constexpr (MODE == CONV_DGRAD) {
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             const int hw = Hc * Wc;
             const int img = nn / hw, rem = nn - img * hw;
             const int yc = rem / Wc, xc = rem - yc * Wc;
-            nbase[i] = (unsigned)img * p.Cout * OHW;
+            nbase[i] = (unsigned)img * p.xbs;
             ny0[i] = (yc * p.s + py + p.ph - kh0) / p.s;      // exact
             nx0[i] = (xc * p.s + px + p.pw - kw0) / p.s;
         }
@@ -391,17 +397,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
 
     // ---------------------------------------------------------------- epilogue
-    float* __restrict__ Cg = (p.nsplit > 1) ? (p.ws + (size_t)sp * p.slab) : p.C;
-    const bool addc = (p.nsplit == 1) && p.accumulate;
+    const bool split = p.nsplit > 1;
+    float* __restrict__ slab = p.ws + (size_t)sp * p.slab;
+    const bool addc = !split && p.accumulate;
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int n = n0 + wn * TN * 32 + tb * 32 + (lane & 31);
-        size_t cbase = 0, cms = 0; bool nok;
+        // cden: dense (slab) position of column n, cstr / cstr2: position in the (possibly strided) destination(s)
+        size_t cden = 0, cstr = 0, cstr2 = 0, mb = 0, cms = 0; bool nok;
         if constexpr (MODE == CONV_FWD) {
             nok = n < p.N;
             const int nn = nok ? n : 0;
             const int img = nn / OHW, pix = nn - img * OHW;
-            cbase = (size_t)img * p.M * OHW + pix; cms = OHW;
+            cms = OHW;
+            cden = (size_t)img * p.M * OHW + pix; cstr = (size_t)img * p.ybs + pix; cstr2 = (size_t)img * p.ybs2 + pix;
         } else if constexpr (MODE == CONV_DGRAD) {
             nok = n < Ncls;
             const int nn = nok ? n : 0;
@@ -409,11 +418,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             const int img = nn / hw, rem = nn - img * hw;
             const int yc = rem / Wc, xc = rem - yc * Wc;
             cms = (size_t)p.H * p.W;
-            cbase = (size_t)img * p.M * cms + (size_t)(yc * p.s + py) * p.W + (xc * p.s + px);
+            const size_t pos = (size_t)(yc * p.s + py) * p.W + (xc * p.s + px);
+            cden = (size_t)img * p.M * cms + pos; cstr = (size_t)img * p.ybs + pos; mb = (size_t)img * p.mbs + pos;
         } else if constexpr (MODE == CONV_WGRAD) {
-            nok = n < p.N; cbase = n; cms = p.N;
+            nok = n < p.N; cden = cstr = n; cms = p.N;
         } else {
-            nok = n < p.N; cbase = (size_t)zb * p.sCb + (size_t)n * p.sCn; cms = p.sCm;
+            nok = n < p.N; cden = cstr = (size_t)zb * p.sCb + (size_t)n * p.sCn; cms = p.sCm;
         }
 #pragma unroll
         for (int ta = 0; ta < TM; ++ta) {
@@ -421,11 +431,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (nok && m < p.M) {
-                    float* dst = Cg + cbase + (size_t)m * cms;
                     float v = acc[ta][tb][r];
+                    if (split) { slab[cden + (size_t)m * cms] = v; continue; }
+                    float* dst = p.C + cstr + (size_t)m * cms;
+                    if constexpr (MODE == CONV_FWD) {
+                        if (m >= p.msplit) dst = p.C2 + cstr2 + (size_t)(m - p.msplit) * cms;
+                    }
+                    if constexpr (MODE == CONV_DGRAD) {
+                        if (p.mask != nullptr && !(p.mask[mb + (size_t)m * cms] > 0.f)) v = 0.f;
+                    }
                     if (addc) v += *dst;
                     if constexpr (MODE == CONV_FWD) {
-                        if (p.ep_scale != nullptr && p.nsplit == 1) {
+                        if (p.ep_scale != nullptr) {
                             v = fmaf(v, p.ep_scale[m], p.ep_shift[m]);
                             if (p.ep_relu) v = fmaxf(v, 0.f);
                         }
@@ -437,32 +454,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
 }
 
-// out[i] = (acc ? out[i] : 0) + sum_s ws[s*slab + i]: fixed summation order (deterministic).  One element per
-// thread (small outputs still give hundreds of blocks), 8 independent slab loads in flight per thread.
+// out[dst(i)] = (acc ? out[dst(i)] : 0) + sum_s ws[s*slab + i]: fixed summation order (deterministic).  One element per
+// thread (small outputs still give hundreds of blocks), 8 independent slab loads in flight per thread.  The dense slab
+// index i = (img, m, pos) is mapped to the (possibly strided / two-part) destination like the kernel's own epilogue.
+struct ReduceP {
+    long long n, slab, Mcms, cms, ybs, ybs2, mbs;
+    int nsplit, acc, msplit, ep_relu;
+    const float* ep_scale; const float* ep_shift; const float* mask; float* out2;
+};
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                            long long n, long long slab, int nsplit, int acc,
-                                                            const float* __restrict__ ep_scale,
-                                                            const float* __restrict__ ep_shift, int ep_relu, int ohw,
-                                                            int M) {
+                                                            const ReduceP q) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= q.n) return;
+    const long long img = i / q.Mcms, rem = i - img * q.Mcms;
+    const int m = (int)(rem / q.cms);
+    float* dst = out + img * q.ybs + rem;
+    if (m >= q.msplit) dst = q.out2 + img * q.ybs2 + (rem - (long long)q.msplit * q.cms);
     const float* p = ws + i;
-    float s = acc ? out[i] : 0.f;
+    float s = 0.f;
     int k = 0;
-    for (; k + 8 <= nsplit; k += 8) {
+    for (; k + 8 <= q.nsplit; k += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * slab];
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * q.slab];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; k < nsplit; ++k) s += p[(size_t)k * slab];
-    if (ep_scale != nullptr) {                       // conv output (B, M, ohw): channel of element i
-        const int m = (int)((i / ohw) % M);
-        s = fmaf(s, ep_scale[m], ep_shift[m]);
-        if (ep_relu) s = fmaxf(s, 0.f);
+    for (; k < q.nsplit; ++k) s += p[(size_t)k * q.slab];
+    if (q.mask != nullptr && !(q.mask[img * q.mbs + rem] > 0.f)) s = 0.f;
+    if (q.acc) s += *dst;
+    if (q.ep_scale != nullptr) {
+        s = fmaf(s, q.ep_scale[m], q.ep_shift[m]);
+        if (q.ep_relu) s = fmaxf(s, 0.f);
     }
-    out[i] = s;
+    *dst = s;
 }
 
 // ------------------------------------------------------------------------------ host dispatch
@@ -597,9 +622,16 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     }
     if (p.nsplit > 1) {
         const long long nblk = cdiv(c_numel, 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)ws, p.C,
-                           c_numel, c_numel, p.nsplit, p.accumulate, mode == CONV_FWD ? p.ep_scale : nullptr, p.ep_shift,
-                           p.ep_relu, p.OH * p.OW, p.M);
+        ReduceP q{};
+        q.n = c_numel; q.slab = c_numel; q.nsplit = p.nsplit; q.acc = p.accumulate;
+        q.Mcms = c_numel; q.cms = c_numel; q.ybs = c_numel; q.msplit = 0x7fffffff;       // dense: dst = out + i
+        if (mode == CONV_FWD || mode == CONV_DGRAD) {
+            q.cms = mode == CONV_FWD ? (long long)p.OH * p.OW : (long long)p.H * p.W;
+            q.Mcms = (long long)p.M * q.cms; q.ybs = p.ybs; q.msplit = p.msplit; q.out2 = p.C2; q.ybs2 = p.ybs2;
+            q.mask = mode == CONV_DGRAD ? p.mask : nullptr; q.mbs = p.mbs;
+            if (mode == CONV_FWD) { q.ep_scale = p.ep_scale; q.ep_shift = p.ep_shift; q.ep_relu = p.ep_relu; }
+        }
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)ws, p.C, q);
     }
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
@@ -619,6 +651,13 @@ static int conv_geom(GemmP& p, int B, int Cin, int Hs, int Ws, int Cout, int KH,
         (long long)Cout * Cin * KH * KW >= (1ll << 30))
         return MOGAN_ERR_SHAPE;
     return 0;
+}
+
+// dense defaults of the strided-I/O fields (after M / the gathered operand are known)
+static void dense_io(GemmP& p, int mode) {
+    if (mode == CONV_FWD) { p.xbs = (unsigned)p.Cin * p.Hs * p.Ws; p.ybs = (long long)p.Cout * p.OH * p.OW; }
+    else { p.xbs = (unsigned)p.Cout * p.OH * p.OW; p.ybs = (long long)p.Cin * p.H * p.W; }
+    p.C2 = nullptr; p.ybs2 = 0; p.msplit = 0x7fffffff; p.mask = nullptr; p.mbs = 0;
 }
 
 }  // namespace
@@ -741,6 +780,7 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    dense_io(p, CONV_FWD);
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
 }
 
@@ -749,18 +789,39 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
 int mogan_conv2d_affine_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,
                             int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int relu,
                             void* ws, size_t ws_bytes, hipStream_t stream) {
+    return mogan_conv2d_affine_fwd_ex(x, (long long)Cin * Hs * Ws, w, scale, shift, y, -1, nullptr, 0, Cout, B, Cin, Hs, Ws,
+                                      Cout, KH, KW, stride, ph, pw, relu, ws, ws_bytes, stream);
+}
+
+// The same with channel-slice addressing: x is a slice of a tensor whose batch stride is x_bstride elements (x points
+// at the slice's first channel); output channels [0, msplit) go to y (batch stride y_bstride, -1 = dense), channels
+// [msplit, Cout) to y2 (batch stride y2_bstride).  Lets a group of same-input 1x1 convolutions run as ONE launch whose
+// parts land in different tensors, and lets every branch of an Inception block write straight into the block's
+// concatenated output (model.py:258-299 via torchvision's torch.cat).
+int mogan_conv2d_affine_fwd_ex(const float* x, long long x_bstride, const float* w, const float* scale, const float* shift,
+                               float* y, long long y_bstride, float* y2, long long y2_bstride, int msplit, int B, int Cin,
+                               int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int relu, void* ws,
+                               size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0); if (rc) return rc;
     if (!scale || !shift) return MOGAN_ERR_SHAPE;
-    if (g_force_cfg < 0) {          // the trunk's 3x3 s1 layers on well-filled grids (147x147, 71x71): fused Winograd
+    const long long xd = (long long)Cin * Hs * Ws, yd = (long long)Cout * p.OH * p.OW;
+    if (y_bstride < 0) y_bstride = yd;
+    const bool two = y2 != nullptr && msplit > 0 && msplit < Cout;
+    const bool plain = x_bstride == xd && y_bstride == yd && !two;
+    if (x_bstride < xd || (long long)(B - 1) * x_bstride + xd >= (1ll << 30)) return MOGAN_ERR_SHAPE;
+    if (plain && g_force_cfg < 0) {          // the trunk's 3x3 s1 layers on well-filled grids (147x147, 71x71): fused Winograd
         mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
         rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0, 0, scale, shift, relu, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
-    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
+    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * (unsigned)((long long)(B - 1) * x_bstride + xd);
     p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
     p.ep_scale = scale; p.ep_shift = shift; p.ep_relu = relu;
+    dense_io(p, CONV_FWD);
+    p.xbs = (unsigned)x_bstride; p.ybs = y_bstride;
+    if (two) { p.C2 = y2; p.ybs2 = y2_bstride; p.msplit = msplit; }
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
 }
 
@@ -794,6 +855,32 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cout * p.OH * p.OW;
     const int Hc = (p.H + stride - 1) / stride, Wc = (p.W + stride - 1) / stride;
     p.N = B * Hc * Wc;   // class (0,0) has the most columns
+    dense_io(p, CONV_DGRAD);
+    return run_gemm(CONV_DGRAD, p, stride * stride, (long long)B * Cin * p.H * p.W, ws, ws_bytes, stream);
+}
+
+// Data gradient with channel-slice addressing and a fused ReLU backward: dy is a slice of a tensor with batch stride
+// dy_bstride; the result is written (accumulate = 0) or added (1) to dx, a slice of a tensor with batch stride
+// dx_bstride; where relu_of[...] <= 0 (same slice geometry as dx, batch stride relu_bstride; nullable) the NEW
+// contribution is zeroed first -- the ReLU backward of the layer whose output is this convolution's input, so the
+// branches that consume one activation accumulate their already-masked gradients in place.
+int mogan_conv2d_dgrad_ex(const float* dy, long long dy_bstride, const float* w, float* dx, long long dx_bstride,
+                          const float* relu_of, long long relu_bstride, int accumulate, int B, int Cin, int Hs, int Ws,
+                          int Cout, int KH, int KW, int stride, int ph, int pw, void* ws, size_t ws_bytes,
+                          hipStream_t stream) {
+    GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0); if (rc) return rc;
+    const long long yd = (long long)Cout * p.OH * p.OW, xd = (long long)Cin * Hs * Ws;
+    if (dy_bstride < yd || dx_bstride < xd || (long long)(B - 1) * dy_bstride + yd >= (1ll << 30)) return MOGAN_ERR_SHAPE;
+    if (dy_bstride == yd && dx_bstride == xd && !relu_of && !accumulate)
+        return mogan_conv2d_dgrad(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0, ws, ws_bytes, stream);
+    p.A = w; p.B = dy; p.C = dx; p.M = Cin; p.K = Cout * p.nkh * p.nkw; p.accumulate = accumulate;
+    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * (unsigned)((long long)(B - 1) * dy_bstride + yd);
+    const int Hc = (p.H + stride - 1) / stride, Wc = (p.W + stride - 1) / stride;
+    p.N = B * Hc * Wc;
+    dense_io(p, CONV_DGRAD);
+    p.xbs = (unsigned)dy_bstride; p.ybs = dx_bstride; p.mask = relu_of; p.mbs = relu_bstride;
+    // a strided parity class that has no tap (stride > kernel) would leave its pixels unwritten: not used by the trunk
+    if (stride > KH || stride > KW) return MOGAN_ERR_SHAPE;
     return run_gemm(CONV_DGRAD, p, stride * stride, (long long)B * Cin * p.H * p.W, ws, ws_bytes, stream);
 }
 

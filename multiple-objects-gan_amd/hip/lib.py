@@ -73,6 +73,13 @@ SIGNATURES = {
     "mogan_bilinear_fwd": [P, P, I, I, I, I, I, P],
     "mogan_bilinear_bwd": [P, P, I, I, I, I, I, P],
     "mogan_adam_step": [P, P, P, P, P, L, F, F, F, F, I, P, I, F, F, P],
+    "mogan_conv2d_affine_fwd_ex": [P, L, P, P, P, P, L, P, L, I] + [I] * 11 + [P, Z, P],
+    "mogan_conv2d_dgrad_ex": [P, L, P, P, L, P, L, I] + [I] * 10 + [P, Z, P],
+    "mogan_maxpool_fwd_ex": [P, P, L, P, I, I, I, I, I, I, P],
+    "mogan_maxpool_bwd_ex": [P, P, L, P, P, I, I, I, I, I, I, I, P],
+    "mogan_avgpool_bwd_ex": [P, P, P, I, I, I, I, I, I, I, P],
+    "mogan_copy_strided": [P, L, P, L, I, L, P],
+    "mogan_relu_bwd": [P, P, P, L, I, P],
     "mogan_damsm_words_fwd": [P, P, P, I, I, I, I, I, F, F, F, P, P, P, P, P, P],
     "mogan_damsm_words_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, F, F, P, P, P],
     "mogan_damsm_ce_fwd": [P, P, P, I, I, P, P, P, P, P],

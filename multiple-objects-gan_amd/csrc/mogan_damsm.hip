@@ -30,7 +30,8 @@
 namespace {
 
 constexpr int TMAX = 32;      // longest caption (cfg.TEXT.WORDS_NUM: 12 for coco, 18 for birds)
-constexpr int NT = 256;       // threads per workgroup (4 wave64)
+constexpr int NT2 = 256;      // the small per-row kernels (4 wave64)
+constexpr int NT = 320;       // threads per workgroup (5 wave64: the 289 regions of a 17x17 map in one pass)
 
 static inline int ok_launch() { return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH; }
 
@@ -52,6 +53,7 @@ struct Lds {
 };
 
 // ---------------------------------------------------------------------------------------------- words: forward
+template <int TT>
 __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
     const float* __restrict__ ctx, const float* __restrict__ words, const int32_t* __restrict__ lens, int Bc, int C,
     int S, int T, float gamma1, float gamma2, float gamma3, float* __restrict__ sim, float* __restrict__ a1o,
@@ -69,27 +71,39 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
         if (b == 0 && wto) { const int c = e / T, t = e - c * T; wto[((size_t)c * Bc + i) * T + t] = t < Ti ? v : 0.f; }
     }
     __syncthreads();
-    // scores + softmax over the words, one thread per region s
+    // scores + softmax over the words, one thread per region s; the channel loop runs 8 loads ahead of its FMAs
     for (int s = tid; s < S; s += NT) {
-        float acc[TMAX];
+        float acc[TT];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
-        for (int c = 0; c < C; ++c) {
+        for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float xs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xs[u] = cb[(size_t)(c + u) * S + s];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* wr = L.w + (c + u) * T;
+#pragma unroll
+                for (int t = 0; t < TT; ++t) if (t < Ti) acc[t] = fmaf(xs[u], wr[t], acc[t]);
+            }
+        }
+        for (; c < C; ++c) {
             const float x = cb[(size_t)c * S + s];
             const float* wr = L.w + c * T;
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) if (t < Ti) acc[t] = fmaf(x, wr[t], acc[t]);
+            for (int t = 0; t < TT; ++t) if (t < Ti) acc[t] = fmaf(x, wr[t], acc[t]);
         }
         float m = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < Ti) m = fmaxf(m, acc[t]);
+        for (int t = 0; t < TT; ++t) if (t < Ti) m = fmaxf(m, acc[t]);
         float z = 0.f;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < Ti) { acc[t] = __expf(acc[t] - m); z += acc[t]; }
+        for (int t = 0; t < TT; ++t) if (t < Ti) { acc[t] = __expf(acc[t] - m); z += acc[t]; }
         const float inv = 1.f / z;
         float* o1 = a1o + (((size_t)b * Bc + i) * S + s) * T;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < T) {
+        for (int t = 0; t < TT; ++t) if (t < T) {
             const float v = t < Ti ? acc[t] * inv : 0.f;
             o1[t] = v;
             L.a[t * SP + s] = v;
@@ -111,26 +125,39 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
         for (int s = lane; s < S; s += 64) { const float v = row[s] * inv; row[s] = v; o2[s] = v; }
     }
     __syncthreads();
-    // weighted context wc[c, t] = sum_s ctx[c, s] a2[t, s]: wave w owns the channels c = w, w + 4, ...; lanes along s.
-    // On the fly: <wc_t, w_t>, |wc_t|^2, |w_t|^2 (lane t of the wave keeps the sums of word t).
+    // weighted context wc[c, t] = sum_s ctx[c, s] a2[t, s]: wave w owns the channels c = w, w + 5, ...; lanes along s,
+    // two channels per trip (their loads in flight together).  On the fly: <wc_t, w_t>, |wc_t|^2, |w_t|^2 (lane t of the
+    // wave keeps the sums of word t).
     float dot = 0.f, nwc = 0.f, nw = 0.f;
-    for (int c = wave; c < C; c += NT / 64) {
-        float p[TMAX];
+    constexpr int NW = NT / 64;
+    for (int c0 = wave; c0 < C; c0 += 2 * NW) {
+        const int c1 = c0 + NW;
+        const bool two = c1 < C;
+        float p[TT], q[TT];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) p[t] = 0.f;
+        for (int t = 0; t < TT; ++t) { p[t] = 0.f; q[t] = 0.f; }
         for (int s = lane; s < S; s += 64) {
-            const float x = cb[(size_t)c * S + s];
+            const float x = cb[(size_t)c0 * S + s], y = two ? cb[(size_t)c1 * S + s] : 0.f;
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) if (t < Ti) p[t] = fmaf(x, L.a[t * SP + s], p[t]);
+            for (int t = 0; t < TT; ++t) if (t < Ti) { const float a = L.a[t * SP + s]; p[t] = fmaf(x, a, p[t]); q[t] = fmaf(y, a, q[t]); }
         }
-        float mine = 0.f;
+        float mine = 0.f, mine2 = 0.f;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < Ti) { const float v = wave_sum(p[t]); if (lane == t) mine = v; }
+        for (int t = 0; t < TT; ++t) if (t < Ti) {
+            const float v = wave_sum(p[t]), v2 = wave_sum(q[t]);
+            if (lane == t) { mine = v; mine2 = v2; }
+        }
         if (lane < T) {
             const float v = lane < Ti ? mine : 0.f;
-            wco[(((size_t)b * C + c) * Bc + i) * T + lane] = v;        // [b][c][i][t]
-            const float wv = L.w[c * T + lane];
+            wco[(((size_t)b * C + c0) * Bc + i) * T + lane] = v;        // [b][c][i][t]
+            const float wv = L.w[c0 * T + lane];
             dot = fmaf(v, wv, dot); nwc = fmaf(v, v, nwc); nw = fmaf(wv, wv, nw);
+            if (two) {
+                const float v2 = lane < Ti ? mine2 : 0.f;
+                wco[(((size_t)b * C + c1) * Bc + i) * T + lane] = v2;
+                const float wv2 = L.w[c1 * T + lane];
+                dot = fmaf(v2, wv2, dot); nwc = fmaf(v2, v2, nwc); nw = fmaf(wv2, wv2, nw);
+            }
         }
     }
     if (lane < T) { L.red[(wave * 3 + 0) * TMAX + lane] = dot; L.red[(wave * 3 + 1) * TMAX + lane] = nwc;
@@ -152,6 +179,7 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
 
 // ---------------------------------------------------------------------------------------------- words: backward
 // d sim[b,i] -> d wc[b][c][i][t] and d score^T[b][i][t][s]
+template <int TT>
 __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     const float* __restrict__ ctx, const float* __restrict__ words, const int32_t* __restrict__ lens,
     const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ wc,
@@ -206,21 +234,33 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     __syncthreads();
     // d a2[t,s] = sum_c d wc[c,t] ctx[c,s], one thread per region (S <= 2 * NT: at most two regions per thread, kept in
     // registers); a2 * d a2 goes to LDS for the per-word sums over s
-    float da[2][TMAX], av[2][TMAX];
+    float da[2][TT], av[2][TT];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int s = tid + j * NT;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) { da[j][t] = 0.f; av[j][t] = 0.f; }
+        for (int t = 0; t < TT; ++t) { da[j][t] = 0.f; av[j][t] = 0.f; }
         if (s < S) {
-            for (int c = 0; c < C; ++c) {
+            int c = 0;
+            for (; c + 8 <= C; c += 8) {
+                float xs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xs[u] = cb[(size_t)(c + u) * S + s];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* wr = L.w + (c + u) * T;
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) if (t < Ti) da[j][t] = fmaf(xs[u], wr[t], da[j][t]);
+                }
+            }
+            for (; c < C; ++c) {
                 const float x = cb[(size_t)c * S + s];
                 const float* wr = L.w + c * T;
 #pragma unroll
-                for (int t = 0; t < TMAX; ++t) if (t < Ti) da[j][t] = fmaf(x, wr[t], da[j][t]);
+                for (int t = 0; t < TT; ++t) if (t < Ti) da[j][t] = fmaf(x, wr[t], da[j][t]);
             }
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) if (t < Ti) {
+            for (int t = 0; t < TT; ++t) if (t < Ti) {
                 av[j][t] = a2[(((size_t)b * Bc + i) * T + t) * S + s];
                 L.a[t * SP + s] = av[j][t] * da[j][t];
             }
@@ -243,13 +283,13 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
             const float* p1 = a1 + (((size_t)b * Bc + i) * S + s) * T;
             float inner = 0.f;
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) if (t < Ti) {
+            for (int t = 0; t < TT; ++t) if (t < Ti) {
                 da[j][t] = gamma1 * av[j][t] * (da[j][t] - rowdot[t]);       // now d a1[s,t]
                 av[j][t] = p1[t];                                            // now a1[s,t]
                 inner = fmaf(av[j][t], da[j][t], inner);
             }
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) if (t < T)
+            for (int t = 0; t < TT; ++t) if (t < T)
                 dst[(((size_t)b * Bc + i) * T + t) * S + s] = t < Ti ? av[j][t] * (da[j][t] - inner) : 0.f;
         }
     }
@@ -258,11 +298,11 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
 // ---------------------------------------------------------------------------------------------- cross-entropies
 // sim (R x Q).  Block r < R: softmax over the row (image -> caption), CE against labels[r]; block R + q: softmax over
 // column q (caption -> image), CE against labels[q].  Writes the probabilities and per-row / per-column NLL terms.
-__global__ __launch_bounds__(NT) void damsm_ce_fwd_kernel(const float* __restrict__ sim, const int64_t* __restrict__ labels,
+__global__ __launch_bounds__(NT2) void damsm_ce_fwd_kernel(const float* __restrict__ sim, const int64_t* __restrict__ labels,
                                                           const uint8_t* __restrict__ mask, int R, int Q,
                                                           float* __restrict__ prow, float* __restrict__ pcol,
                                                           float* __restrict__ nll) {
-    __shared__ float sh[NT / 64];
+    __shared__ float sh[NT2 / 64];
     const int blk = blockIdx.x, tid = threadIdx.x;
     const bool col = blk >= R;
     const int r = col ? blk - R : blk;
@@ -273,21 +313,21 @@ __global__ __launch_bounds__(NT) void damsm_ce_fwd_kernel(const float* __restric
         return sim[(size_t)br * Q + bq];
     };
     float m = -INFINITY;
-    for (int k = tid; k < n; k += NT) m = fmaxf(m, at(k));
+    for (int k = tid; k < n; k += NT2) m = fmaxf(m, at(k));
     m = wave_max(m);
     if ((tid & 63) == 0) sh[tid >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     __syncthreads();
     float z = 0.f;
-    for (int k = tid; k < n; k += NT) z += __expf(at(k) - m);
+    for (int k = tid; k < n; k += NT2) z += __expf(at(k) - m);
     z = wave_sum(z);
     if ((tid & 63) == 0) sh[tid >> 6] = z;
     __syncthreads();
     z = sh[0] + sh[1] + sh[2] + sh[3];
     const float lz = logf(z);
     float* pout = col ? pcol : prow;
-    for (int k = tid; k < n; k += NT) {
+    for (int k = tid; k < n; k += NT2) {
         const int br = col ? k : r, bq = col ? r : k;
         pout[(size_t)br * Q + bq] = __expf(at(k) - m) / z;
     }
@@ -298,12 +338,12 @@ __global__ __launch_bounds__(NT) void damsm_ce_fwd_kernel(const float* __restric
 }
 
 // out[0] = loss0 = mean_r nll[r], out[1] = loss1 = mean_q nll[R + q]
-__global__ __launch_bounds__(NT) void damsm_ce_finish_kernel(const float* __restrict__ nll, int R, int Q,
+__global__ __launch_bounds__(NT2) void damsm_ce_finish_kernel(const float* __restrict__ nll, int R, int Q,
                                                              float* __restrict__ out) {
-    __shared__ float sh[2][NT / 64];
+    __shared__ float sh[2][NT2 / 64];
     float a = 0.f, b = 0.f;
-    for (int k = threadIdx.x; k < R; k += NT) a += nll[k];
-    for (int k = threadIdx.x; k < Q; k += NT) b += nll[R + k];
+    for (int k = threadIdx.x; k < R; k += NT2) a += nll[k];
+    for (int k = threadIdx.x; k < Q; k += NT2) b += nll[R + k];
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
     __syncthreads();
@@ -315,11 +355,11 @@ __global__ __launch_bounds__(NT) void damsm_ce_finish_kernel(const float* __rest
 }
 
 // d sim[r,q] = g0 (prow[r,q] - [q == labels[r]]) / R + g1 (pcol[r,q] - [r == labels[q]]) / Q   (g0, g1 nullable = 0)
-__global__ __launch_bounds__(NT) void damsm_ce_bwd_kernel(const float* __restrict__ prow, const float* __restrict__ pcol,
+__global__ __launch_bounds__(NT2) void damsm_ce_bwd_kernel(const float* __restrict__ prow, const float* __restrict__ pcol,
                                                           const int64_t* __restrict__ labels,
                                                           const float* __restrict__ g0, const float* __restrict__ g1,
                                                           int R, int Q, float* __restrict__ dsim) {
-    const int idx = blockIdx.x * NT + threadIdx.x;
+    const int idx = blockIdx.x * NT2 + threadIdx.x;
     if (idx >= R * Q) return;
     const int r = idx / Q, q = idx - r * Q;
     const float a = g0 ? g0[0] * (prow[idx] - ((int)labels[r] == q ? 1.f : 0.f)) / (float)R : 0.f;
@@ -329,7 +369,7 @@ __global__ __launch_bounds__(NT) void damsm_ce_bwd_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------- sentence loss
 // sim[b,i] = gamma3 * <cnn_b, rnn_i> / max(|cnn_b| |rnn_i|, eps): block per image b, wave per caption stripe
-__global__ __launch_bounds__(NT) void damsm_sent_fwd_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn,
+__global__ __launch_bounds__(NT2) void damsm_sent_fwd_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn,
                                                             int Bc, int C, float gamma3, float eps,
                                                             float* __restrict__ sim) {
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -337,7 +377,7 @@ __global__ __launch_bounds__(NT) void damsm_sent_fwd_kernel(const float* __restr
     float n0 = 0.f;
     for (int c = lane; c < C; c += 64) n0 = fmaf(xb[c], xb[c], n0);
     n0 = sqrtf(wave_sum(n0));
-    for (int i = wave; i < Bc; i += NT / 64) {
+    for (int i = wave; i < Bc; i += NT2 / 64) {
         const float* ri = rnn + (size_t)i * C;
         float d = 0.f, n1 = 0.f;
         for (int c = lane; c < C; c += 64) { d = fmaf(xb[c], ri[c], d); n1 = fmaf(ri[c], ri[c], n1); }
@@ -347,7 +387,7 @@ __global__ __launch_bounds__(NT) void damsm_sent_fwd_kernel(const float* __restr
 }
 
 // d cnn[b,c] = sum_i dsim[b,i] gamma3 ( rnn[i,c] / den - <cnn_b, rnn_i> cnn[b,c] / (|cnn_b|^2 den) ),  den = |cnn_b||rnn_i|
-__global__ __launch_bounds__(NT) void damsm_sent_bwd_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn,
+__global__ __launch_bounds__(NT2) void damsm_sent_bwd_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn,
                                                             const float* __restrict__ dsim, int Bc, int C, float gamma3,
                                                             float eps, float* __restrict__ dcnn) {
     extern __shared__ float smem[];           // k1[Bc], k2 (scalar accumulated per caption) -> k1[i], k2[i]
@@ -358,7 +398,7 @@ __global__ __launch_bounds__(NT) void damsm_sent_bwd_kernel(const float* __restr
     for (int c = lane; c < C; c += 64) n0s = fmaf(xb[c], xb[c], n0s);
     n0s = wave_sum(n0s);
     const float n0 = sqrtf(n0s);
-    for (int i = wave; i < Bc; i += NT / 64) {
+    for (int i = wave; i < Bc; i += NT2 / 64) {
         const float* ri = rnn + (size_t)i * C;
         float d = 0.f, n1 = 0.f;
         for (int c = lane; c < C; c += 64) { d = fmaf(xb[c], ri[c], d); n1 = fmaf(ri[c], ri[c], n1); }
@@ -370,7 +410,7 @@ __global__ __launch_bounds__(NT) void damsm_sent_bwd_kernel(const float* __restr
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += NT) {
+    for (int c = threadIdx.x; c < C; c += NT2) {
         float acc = 0.f, self = 0.f;
         for (int i = 0; i < Bc; ++i) { acc = fmaf(k1[i], rnn[(size_t)i * C + c], acc); self += k2[i]; }
         dcnn[(size_t)b * C + c] = acc + self * xb[c];
@@ -407,8 +447,11 @@ int mogan_damsm_words_fwd(const float* ctx, const float* words, const int32_t* c
     if (B <= 0 || Bc <= 0 || C <= 0 || S <= 0 || T <= 0 || T > TMAX || B > 65535) return MOGAN_ERR_SHAPE;
     const size_t lds = words_lds_bytes(C, S, T);
     if (lds > 64 * 1024) return MOGAN_ERR_SHAPE;
-    hipLaunchKernelGGL(damsm_words_fwd_kernel, dim3(Bc, B), dim3(NT), lds, stream, ctx, words, cap_lens, Bc, C, S, T,
-                       gamma1, gamma2, gamma3, sim, a1, a2, wc, wt);
+#define MOGAN_DAMSM_FWD(TT) hipLaunchKernelGGL(damsm_words_fwd_kernel<TT>, dim3(Bc, B), dim3(NT), lds, stream, ctx, words, \
+                                              cap_lens, Bc, C, S, T, gamma1, gamma2, gamma3, sim, a1, a2, wc, wt)
+    if (T <= 8) MOGAN_DAMSM_FWD(8); else if (T <= 12) MOGAN_DAMSM_FWD(12); else if (T <= 16) MOGAN_DAMSM_FWD(16);
+    else if (T <= 24) MOGAN_DAMSM_FWD(24); else MOGAN_DAMSM_FWD(32);
+#undef MOGAN_DAMSM_FWD
     return ok_launch();
 }
 
@@ -418,23 +461,26 @@ int mogan_damsm_words_bwd(const float* ctx, const float* words, const int32_t* c
     if (B <= 0 || Bc <= 0 || C <= 0 || S <= 0 || T <= 0 || T > TMAX || B > 65535 || S > 2 * NT) return MOGAN_ERR_SHAPE;
     const size_t lds = words_lds_bytes(C, S, T);
     if (lds > 64 * 1024) return MOGAN_ERR_SHAPE;
-    hipLaunchKernelGGL(damsm_words_bwd_kernel, dim3(Bc, B), dim3(NT), lds, stream, ctx, words, cap_lens, a1, a2, wc, dsim,
-                       Bc, C, S, T, gamma1, gamma2, gamma3, dwc, dscore_t);
+#define MOGAN_DAMSM_BWD(TT) hipLaunchKernelGGL(damsm_words_bwd_kernel<TT>, dim3(Bc, B), dim3(NT), lds, stream, ctx, words, \
+                                              cap_lens, a1, a2, wc, dsim, Bc, C, S, T, gamma1, gamma2, gamma3, dwc, dscore_t)
+    if (T <= 8) MOGAN_DAMSM_BWD(8); else if (T <= 12) MOGAN_DAMSM_BWD(12); else if (T <= 16) MOGAN_DAMSM_BWD(16);
+    else if (T <= 24) MOGAN_DAMSM_BWD(24); else MOGAN_DAMSM_BWD(32);
+#undef MOGAN_DAMSM_BWD
     return ok_launch();
 }
 
 int mogan_damsm_ce_fwd(const float* sim, const int64_t* labels, const uint8_t* mask, int R, int Q, float* prow,
                        float* pcol, float* nll, float* out2, hipStream_t stream) {
     if (R <= 0 || Q <= 0 || R != Q) return MOGAN_ERR_SHAPE;      // labels index both axes (losses.py:128-130)
-    hipLaunchKernelGGL(damsm_ce_fwd_kernel, dim3(R + Q), dim3(NT), 0, stream, sim, labels, mask, R, Q, prow, pcol, nll);
-    hipLaunchKernelGGL(damsm_ce_finish_kernel, dim3(1), dim3(NT), 0, stream, (const float*)nll, R, Q, out2);
+    hipLaunchKernelGGL(damsm_ce_fwd_kernel, dim3(R + Q), dim3(NT2), 0, stream, sim, labels, mask, R, Q, prow, pcol, nll);
+    hipLaunchKernelGGL(damsm_ce_finish_kernel, dim3(1), dim3(NT2), 0, stream, (const float*)nll, R, Q, out2);
     return ok_launch();
 }
 
 int mogan_damsm_ce_bwd(const float* prow, const float* pcol, const int64_t* labels, const float* g0, const float* g1, int R,
                        int Q, float* dsim, hipStream_t stream) {
     if (R <= 0 || Q <= 0 || R != Q) return MOGAN_ERR_SHAPE;
-    hipLaunchKernelGGL(damsm_ce_bwd_kernel, dim3((R * Q + NT - 1) / NT), dim3(NT), 0, stream, prow, pcol, labels, g0, g1,
+    hipLaunchKernelGGL(damsm_ce_bwd_kernel, dim3((R * Q + NT2 - 1) / NT2), dim3(NT2), 0, stream, prow, pcol, labels, g0, g1,
                        R, Q, dsim);
     return ok_launch();
 }
@@ -442,14 +488,14 @@ int mogan_damsm_ce_bwd(const float* prow, const float* pcol, const int64_t* labe
 int mogan_damsm_sent_fwd(const float* cnn, const float* rnn, int B, int Bc, int C, float gamma3, float eps, float* sim,
                          hipStream_t stream) {
     if (B <= 0 || Bc <= 0 || C <= 0) return MOGAN_ERR_SHAPE;
-    hipLaunchKernelGGL(damsm_sent_fwd_kernel, dim3(B), dim3(NT), 0, stream, cnn, rnn, Bc, C, gamma3, eps, sim);
+    hipLaunchKernelGGL(damsm_sent_fwd_kernel, dim3(B), dim3(NT2), 0, stream, cnn, rnn, Bc, C, gamma3, eps, sim);
     return ok_launch();
 }
 
 int mogan_damsm_sent_bwd(const float* cnn, const float* rnn, const float* dsim, int B, int Bc, int C, float gamma3,
                          float eps, float* dcnn, hipStream_t stream) {
     if (B <= 0 || Bc <= 0 || C <= 0 || (size_t)Bc * 2 * sizeof(float) > 64 * 1024) return MOGAN_ERR_SHAPE;
-    hipLaunchKernelGGL(damsm_sent_bwd_kernel, dim3(B), dim3(NT), (size_t)Bc * 2 * sizeof(float), stream, cnn, rnn, dsim, Bc,
+    hipLaunchKernelGGL(damsm_sent_bwd_kernel, dim3(B), dim3(NT2), (size_t)Bc * 2 * sizeof(float), stream, cnn, rnn, dsim, Bc,
                        C, gamma3, eps, dcnn);
     return ok_launch();
 }

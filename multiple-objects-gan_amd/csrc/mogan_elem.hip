@@ -193,11 +193,11 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gout, float* __restrict__ dp, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    // d/dp of -(t*max(log p,-100) + (1-t)*max(log(1-p),-100)); the clamp zeroes the slope beyond it
+    // torch's BCELoss backward (the reference's loss, miscc/losses.py:158-168): (p - t) / max(p (1 - p), 1e-12) -- NOT the
+    // derivative of the clamped logs: for a saturated discriminator (p < 1e-12, logit < -27.6) it is smaller by
+    // p (1 - p) / 1e-12, and that is the gradient the reference trains with
     const float pv = p[i];
-    float g = 0.f;
-    if (logf(pv) > -100.f) g -= target / pv;
-    if (logf(1.f - pv) > -100.f) g += (1.f - target) / (1.f - pv);
+    const float g = (pv - target) / fmaxf((1.f - pv) * pv, 1e-12f);
     dp[i] = gout[0] * weight * g / (float)n;
 }
 // BCEWithLogitsLoss(mean) against a constant target, torch's stable form: max(x,0) - x*t + log1p(exp(-|x|))

@@ -269,10 +269,11 @@ def d_logits(net, pre, h, c=None):
 
 # ---------------------------------------------------------------------------------- losses
 def bce(p, target):
-    """nn.BCELoss (mean) with torch's log clamp at -100."""
-    lp = torch.clamp(torch.log(p), min=-100.0)
-    l1p = torch.clamp(torch.log(1.0 - p), min=-100.0)
-    return -(target * lp + (1.0 - target) * l1p).mean()
+    """nn.BCELoss (mean), as the reference calls it (miscc/losses.py:158-168): torch clamps the logs at -100 in the forward
+    pass and differentiates (p - t) / max(p (1 - p), 1e-12) in the backward pass.  (A composition of torch.log and
+    torch.clamp has the same forward but a NaN gradient, 0 * inf, wherever a saturated discriminator outputs exactly 0 or
+    1 -- which it does after a few dozen steps on one synthetic batch, bench.py's parity leg.)"""
+    return F.binary_cross_entropy(p, target.to(p.dtype).expand_as(p))
 
 
 def discriminator_loss(i, net, real, fake, cond, batch, cfg):

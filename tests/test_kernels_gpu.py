@@ -335,6 +335,16 @@ def test_losses_bce_kl():
     # torch's clamp of log at -100
     pd = torch.tensor([0.0, 1.0, 0.5], device=DEV)
     assert abs(float(ops.bce(pd, 1.0)) - (100 + 0 + np.log(2)) / 3) < 1e-4
+    # saturated probabilities (a discriminator that has seen one batch for 30 steps): torch's backward is
+    # (p - t) / max(p (1 - p), 1e-12), not the derivative of the clamped logs
+    sat = torch.tensor([0.0, 1.0, 1e-13, 1.0 - 6e-8, 3e-20, 0.3], dtype=torch.float32)
+    for tgt in (0.0, 1.0):
+        pr = sat.clone().requires_grad_(True)
+        F.binary_cross_entropy(pr, torch.full_like(pr, tgt)).backward()
+        ph = sat.to(DEV).requires_grad_(True)
+        ops.bce(ph, tgt).backward()
+        assert torch.isfinite(ph.grad).all()
+        np.testing.assert_allclose(ph.grad.cpu().numpy(), pr.grad.numpy(), rtol=1e-5, atol=0)
     mu = T("klm", (16, 100), 0.5).requires_grad_(True)
     lv = T("kll", (16, 100), 0.5).requires_grad_(True)
     ref = O.kl_loss(mu.double(), lv.double())

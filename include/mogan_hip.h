@@ -10,11 +10,17 @@
  * Conventions
  *   - all tensors are dense fp32, NCHW, device pointers, borrowed for the duration of the call
  *     (the caller -- PyTorch -- owns the memory); uint8 masks / int32 lengths where stated;
- *   - every call is asynchronous on `stream` (pass torch.cuda.current_stream().cuda_stream),
- *     allocates nothing and keeps no state: scratch comes from the caller as (ws, ws_bytes);
- *     a null/short workspace only disables split-K (slower, never wrong) unless stated;
+ *   - every call is asynchronous on `stream` (pass torch.cuda.current_stream().cuda_stream) and
+ *     allocates nothing: scratch comes from the caller as (ws, ws_bytes); a null/short workspace
+ *     only disables split-K (slower, never wrong) unless stated;
  *   - return 0 on success, negative MOGAN_ERR_* otherwise (no exceptions cross the boundary);
- *   - thread-safe and re-entrant.
+ *   - operators keep no state between calls and are thread-safe / re-entrant.  What the library does
+ *     hold is TUNING state, never data: a split-K block target (process default + per-stream override,
+ *     mogan_gemm_set_split_target / mogan_stream_set_split_target) and the tuned (tile, split-K) table
+ *     (mogan_gemm_tune_set), both read under a mutex -- results do not depend on them beyond the
+ *     summation order across K-splits; plus the test / measurement hooks marked as such below
+ *     (mogan_gemm_debug_force, mogan_wino22_debug_min_tiles, mogan_prof_*), which are process-wide and
+ *     not meant for concurrent use.
  */
 #ifndef MOGAN_HIP_H
 #define MOGAN_HIP_H
@@ -46,6 +52,10 @@ int mogan_abi_version(void);
 /* split-K of the implicit-GEMM kernels aims at `blocks` workgroups per launch (default 768 = three per CU for a kernel
  * that has the GPU to itself; a caller that keeps several streams busy lowers it to 384: fewer slabs to reduce). */
 int mogan_gemm_set_split_target(int blocks);
+/* the same per stream (0 = back to the process default): launches on `stream` use this target.  The owner of a stream
+ * knows whether its kernels run alone (768) or beside other streams' kernels (384); two engines / threads with their own
+ * streams do not interfere. */
+int mogan_stream_set_split_target(hipStream_t stream, int blocks);
 
 /* Tuned dispatch of the implicit-GEMM kernel: for the GEMM (mode 0 conv fwd / 1 conv dgrad / 2 conv wgrad / 3 bmm; M, N, K,
  * nz = batch or parity classes, exactly as the kernel sees them) use tile config `cfg` (0..4) and split-K factor `split`
@@ -152,6 +162,11 @@ int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
  * BN+residual: 75,80. */
 int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const float* residual, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream);
+/* training-mode BatchNorm + activation (+ residual) in two launches (partial sums; apply with the finalize folded in):
+ * = mogan_bn_stats followed by mogan_bn_act_fwd, same arithmetic; mean / invstd (C each) are written for the backward pass */
+int mogan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                       float* invstd, float* running_mean, float* running_var, int B, int C, int HW, int act, float slope,
+                       float eps, float momentum, void* ws, size_t ws_bytes, hipStream_t stream);
 /* dy (B,Cy,HW) -> dx (B,C,HW), dgamma[C], dbeta[C] (accumulate != 0 adds into dgamma/dbeta).
  * The residual branch's gradient is dy itself. ws REQUIRED (mogan_bn_ws_bytes). */
 int mogan_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,

@@ -214,7 +214,7 @@ class TrainEngine:
             from ..hip import lib
             t = os.environ.get("MOGAN_ENC_SPLIT_TARGET")
             if t:
-                lib.call("mogan_gemm_set_split_target", int(t))
+                lib.call("mogan_stream_set_split_target", lib.stream_ptr(), int(t))
             g = torch.cuda.make_graphed_callables(lambda x: enc(x), (sample,))
             self._enc_graphs[key] = g
         return g
@@ -261,8 +261,18 @@ class TrainEngine:
         netG, netsD = self.netG, self.netsD
         B = b["z"].shape[0]
         from ..hip import lib
-        lib.call("mogan_gemm_set_split_target",                                      # see include/mogan_hip.h
-                 int(os.environ.get("MOGAN_SPLIT_TARGET", 384 if self.multi_stream else 768)))
+        # split-K block target of this engine's streams (per stream, include/mogan_hip.h): 384 when the branches run side by
+        # side, 768 when one stream has the GPU to itself
+        target = int(os.environ.get("MOGAN_SPLIT_TARGET", 384 if self.multi_stream else 768))
+        if getattr(self, "_split_target", None) != target:
+            self._split_target = target
+            from ..hip import ops as _ops
+            streams = [torch.cuda.current_stream()] + list(self.side)
+            streams += [_ops._wgrad_streams[s.cuda_stream] for s in streams if s.cuda_stream in _ops._wgrad_streams]
+            for s in streams:
+                lib.call("mogan_stream_set_split_target", s.cuda_stream, target)
+            # streams this engine does not own (torch's internal capture stream of the encoder graph) follow the default
+            lib.call("mogan_gemm_set_split_target", target)
         real_labels = b["z"].new_ones(B)
         fake_labels = b["z"].new_zeros(B)
         match_labels = b["match_labels"]

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -550,7 +551,19 @@ namespace {
 // split-K aims at this many blocks per launch (mogan_gemm_set_split_target): 768 = three per CU when the kernel has the
 // GPU to itself; a caller that keeps several streams busy asks for 384 (fewer slabs to reduce, the other branches fill the
 // chip): +2 % on the multi-stream train step, -7 % on the kernel alone.
-static int g_split_target = 768;
+static std::atomic<int> g_split_target{768};        // process default
+// per-stream override (mogan_stream_set_split_target): the owner of a stream knows whether its kernels have the GPU to
+// themselves; keyed by the stream handle, read under a mutex (a few hundred lookups per step)
+static std::unordered_map<hipStream_t, int> g_stream_target;
+static std::mutex g_stream_mu;
+static int split_target_of(hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        auto it = g_stream_target.find(st);
+        if (it != g_stream_target.end()) return it->second;
+    }
+    return g_split_target.load(std::memory_order_relaxed);
+}
 
 // tuned dispatch (mogan_gemm_tune_set): key = the GEMM as run_gemm sees it
 struct TuneKey { int mode, M, N, K, nz; bool operator==(const TuneKey& o) const { return mode == o.mode && M == o.M && N == o.N && K == o.K && nz == o.nz; } };
@@ -580,7 +593,7 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     const long long tiles = cdiv(p.M, bm) * cdiv(p.N, bn) * nz;
     int nsplit = 1;
     const int ktiles = (int)cdiv(p.K, 32);
-    const int split_target = g_split_target;
+    const int split_target = split_target_of(st);
     if (tiles < 512 && ktiles >= 8) {             // fewer than two blocks per CU and a K loop worth cutting
         nsplit = (int)cdiv(split_target, tiles);
         nsplit = (int)std::min<long long>(nsplit, ktiles / 4);
@@ -666,7 +679,14 @@ extern "C" {
 
 int mogan_gemm_set_split_target(int blocks) {
     if (blocks < 64 || blocks > 8192) return MOGAN_ERR_SHAPE;
-    g_split_target = blocks;
+    g_split_target.store(blocks, std::memory_order_relaxed);
+    return 0;
+}
+
+int mogan_stream_set_split_target(hipStream_t stream, int blocks) {
+    if (blocks != 0 && (blocks < 64 || blocks > 8192)) return MOGAN_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    if (blocks == 0) g_stream_target.erase(stream); else g_stream_target[stream] = blocks;
     return 0;
 }
 

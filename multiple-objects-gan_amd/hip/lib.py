@@ -19,6 +19,7 @@ P, I, F, L, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 SIGNATURES = {
     "mogan_abi_version": [],
     "mogan_gemm_set_split_target": [I],
+    "mogan_stream_set_split_target": [P, I],
     "mogan_gemm_debug_force": [I, I],
     "mogan_wino22_debug_min_tiles": [I],
     "mogan_gemm_tune_set": [I, I, I, I, I, I, I],
@@ -41,6 +42,7 @@ SIGNATURES = {
     "mogan_bmm": [P, P, P, I, I, I, I] + [L] * 9 + [I, P, Z, P],
     "mogan_bn_ws_bytes": [I, I, I],
     "mogan_bn_stats": [P, I, I, I, F, F, P, P, P, P, P, Z, P],
+    "mogan_bn_train_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, P, Z, P],
     "mogan_bn_act_fwd": [P, P, P, P, P, P, P, I, I, I, I, F, P],
     "mogan_bn_act_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P, Z, P],
     "mogan_affine_act_fwd": [P, P, P, P, I, I, I, I, F, P],

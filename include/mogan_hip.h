@@ -162,11 +162,6 @@ int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
  * BN+residual: 75,80. */
 int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const float* residual, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream);
-/* training-mode BatchNorm + activation (+ residual) in two launches (partial sums; apply with the finalize folded in):
- * = mogan_bn_stats followed by mogan_bn_act_fwd, same arithmetic; mean / invstd (C each) are written for the backward pass */
-int mogan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
-                       float* invstd, float* running_mean, float* running_var, int B, int C, int HW, int act, float slope,
-                       float eps, float momentum, void* ws, size_t ws_bytes, hipStream_t stream);
 /* dy (B,Cy,HW) -> dx (B,C,HW), dgamma[C], dbeta[C] (accumulate != 0 adds into dgamma/dbeta).
  * The residual branch's gradient is dy itself. ws REQUIRED (mogan_bn_ws_bytes). */
 int mogan_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,

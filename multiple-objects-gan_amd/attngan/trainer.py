@@ -269,8 +269,9 @@ class TrainEngine:
             from ..hip import ops as _ops
             streams = [torch.cuda.current_stream()] + list(self.side)
             streams += [_ops._wgrad_streams[s.cuda_stream] for s in streams if s.cuda_stream in _ops._wgrad_streams]
-            for s in streams:
-                lib.call("mogan_stream_set_split_target", s.cuda_stream, target)
+            if os.environ.get("MOGAN_SPLIT_PER_STREAM", "0") != "0":      # (measured 1.4 % slower than the plain default)
+                for s in streams:
+                    lib.call("mogan_stream_set_split_target", s.cuda_stream, target)
             # streams this engine does not own (torch's internal capture stream of the encoder graph) follow the default
             lib.call("mogan_gemm_set_split_target", target)
         real_labels = b["z"].new_ones(B)

@@ -170,73 +170,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     if (VEC) *(float4*)py = make_float4(o[0], o[1], o[2], o[3]); else *py = o[0];
 }
 
-// The same apply pass for TRAINING mode with the statistics' finalize folded in: every block re-reduces the YS partial
-// sums of its channel(s) (YS <= a few dozen doubles), the first block of a channel also publishes mean / invstd and
-// updates the running statistics -- one launch less per BatchNorm call.  Arithmetic identical to bn_finalize + bn_act_fwd.
-template <int ACT, bool VEC>
-__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ x, const double* __restrict__ part,
-                                                           int YS, double n, float eps, float momentum,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ res, float* __restrict__ y,
-                                                           float* __restrict__ mean, float* __restrict__ invstd,
-                                                           float* __restrict__ rmean, float* __restrict__ rvar, int C,
-                                                           int HW, float slope, int publish) {
-    constexpr int W = VEC ? 4 : 1;
-    constexpr int WA = 4;
-    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
-    const int c = blockIdx.y % Cy, b = blockIdx.y / Cy;
-    __shared__ float s_aff[4];
-    if (threadIdx.x < (ACT == MOGAN_ACT_GLU ? 2 : 1)) {
-        const int cc = c + threadIdx.x * Cy;
-        double s = 0, q = 0;
-        for (int ys = 0; ys < YS; ++ys) { s += part[((size_t)cc * YS + ys) * 2]; q += part[((size_t)cc * YS + ys) * 2 + 1]; }
-        const double m = s / n;
-        double var = q / n - m * m; if (var < 0) var = 0;
-        const float fm = (float)m, fis = (float)(1.0 / sqrt(var + (double)eps));
-        if (publish && blockIdx.x == 0 && b == 0) {
-            mean[cc] = fm; invstd[cc] = fis;
-            if (rmean) rmean[cc] = (1.f - momentum) * rmean[cc] + momentum * fm;
-            if (rvar) {
-                const double unb = n > 1 ? var * n / (n - 1.0) : var;
-                rvar[cc] = (1.f - momentum) * rvar[cc] + momentum * (float)unb;
-            }
-        }
-        const float sc = gamma[cc] * fis;
-        s_aff[2 * threadIdx.x] = sc; s_aff[2 * threadIdx.x + 1] = beta[cc] - fm * sc;
-    }
-    __syncthreads();
-    const int i = (blockIdx.x * 256 + threadIdx.x) * W;
-    if (i >= HW) return;
-    const float sc = s_aff[0], sh = s_aff[1];
-    const float* px = x + ((size_t)b * C + c) * HW + i;
-    float v[WA], o[WA];
-    if (VEC) { const float4 t = *(const float4*)px; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    else v[0] = *px;
-    if (ACT == MOGAN_ACT_GLU) {
-        const float sc2 = s_aff[2], sh2 = s_aff[3];
-        float g[WA];
-        if (VEC) { const float4 t = *(const float4*)(px + (size_t)Cy * HW); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
-        else g[0] = px[(size_t)Cy * HW];
-#pragma unroll
-        for (int k = 0; k < W; ++k) o[k] = (v[k] * sc + sh) * sigmoidf_(g[k] * sc2 + sh2);
-    } else {
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            float t = v[k] * sc + sh;
-            if (ACT == MOGAN_ACT_RELU) t = t > 0.f ? t : 0.f;
-            if (ACT == MOGAN_ACT_LRELU) t = t > 0.f ? t : t * slope;
-            o[k] = t;
-        }
-    }
-    float* py = y + ((size_t)b * Cy + c) * HW + i;
-    if (res) {
-        const float* pr = res + ((size_t)b * Cy + c) * HW + i;
-        if (VEC) { const float4 t = *(const float4*)pr; o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
-        else o[0] += *pr;
-    }
-    if (VEC) *(float4*)py = make_float4(o[0], o[1], o[2], o[3]); else *py = o[0];
-}
-
 // -------------------------------------------------------------------------------- backward
 // dy_bn (gradient at the BN output) from dy (gradient at the activation output), recomputing the BN output.
 // Non-GLU: channel c.  GLU: pair (c, c+Cy): a = bn_c, g = bn_{c+Cy}; y = a*sig(g).
@@ -295,34 +228,40 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-// dx = gamma*invstd * (dy_bn - sum_dy/n - xhat * sum_dyxhat/n), the reduction of the per-block partial sums folded in
-// (every block re-reduces the YS x 4 doubles of its channel pair; the first block of a channel writes dgamma / dbeta)
+// -> sums[C][2] = (sum dy_bn, sum dy_bn*xhat) as float, dgamma/dbeta
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int YS,
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cy) return;
+    double a[4] = {0, 0, 0, 0};
+    for (int y = 0; y < YS; ++y)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += part[((size_t)c * YS + y) * 4 + k];
+    sums[c * 2] = (float)a[0]; sums[c * 2 + 1] = (float)a[1];
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a[0];
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a[1];
+    if (ACT == MOGAN_ACT_GLU) {
+        const int cg = c + Cy;
+        sums[cg * 2] = (float)a[2]; sums[cg * 2 + 1] = (float)a[3];
+        if (dbeta) dbeta[cg] = (accumulate ? dbeta[cg] : 0.f) + (float)a[2];
+        if (dgamma) dgamma[cg] = (accumulate ? dgamma[cg] : 0.f) + (float)a[3];
+    }
+}
+
+// dx = gamma*invstd * (dy_bn - sum_dy/n - xhat * sum_dyxhat/n)
 template <int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
-                                                           const double* __restrict__ part, int YS,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int accumulate, int publish, float* __restrict__ dx, int C,
+                                                           const float* __restrict__ sums, float* __restrict__ dx, int C,
                                                            int HW, float slope, float inv_n) {
     const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
     const int c = blockIdx.y % Cy, b = blockIdx.y / Cy;
-    __shared__ float s_sum[4];
-    if (threadIdx.x < 4) {
-        const int k = threadIdx.x;
-        double a = 0;
-        if (ACT == MOGAN_ACT_GLU || k < 2)
-            for (int ys = 0; ys < YS; ++ys) a += part[((size_t)c * YS + ys) * 4 + k];
-        s_sum[k] = (float)a;
-        if (publish && blockIdx.x == 0 && b == 0 && (ACT == MOGAN_ACT_GLU || k < 2)) {
-            const int cc = c + (k >> 1) * Cy;
-            float* dst = (k & 1) ? dgamma : dbeta;
-            if (dst) dst[cc] = (accumulate ? dst[cc] : 0.f) + (float)a;
-        }
-    }
-    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float mu = mean[c], is = invstd[c];
@@ -333,8 +272,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float xa = x[ia], xg = (ACT == MOGAN_ACT_GLU) ? x[ig] : 0.f;
     float da, dg, dummy = 0;
     act_bwd<ACT>(xa, xg, dy[((size_t)b * Cy + c) * HW + i], sc, sh, sc2, sh2, slope, da, dg, dummy);
-    dx[ia] = sc * (da - s_sum[0] * inv_n - (xa - mu) * is * s_sum[1] * inv_n);
-    if (ACT == MOGAN_ACT_GLU) dx[ig] = sc2 * (dg - s_sum[2] * inv_n - (xg - mu2) * is2 * s_sum[3] * inv_n);
+    dx[ia] = sc * (da - sums[c * 2] * inv_n - (xa - mu) * is * sums[c * 2 + 1] * inv_n);
+    if (ACT == MOGAN_ACT_GLU) {
+        const int cg = c + Cy;
+        dx[ig] = sc2 * (dg - sums[cg * 2] * inv_n - (xg - mu2) * is2 * sums[cg * 2 + 1] * inv_n);
+    }
 }
 
 // -------------------------------------------------------------------------------- eval affine
@@ -371,8 +313,11 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* mean, const
     Split s = make_split(B, C, HW);
     const int YS = s.bs * s.hs;
     double* part = (double*)ws;
+    float* sums = (float*)((char*)ws + (size_t)C * YS * 4 * sizeof(double));
     hipLaunchKernelGGL((bn_bwd_partial_kernel<ACT>), dim3(Cy, YS), dim3(256), 0, stream, x, dy, mean, invstd, gamma,
                        beta, B, C, HW, s, slope, part);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<ACT>), dim3((Cy + 255) / 256), dim3(256), 0, stream,
+                       (const double*)part, C, YS, sums, dgamma, dbeta, accumulate);
     const float inv_n = 1.f / ((float)B * (float)HW);
     const int bchunk = 65535 / Cy;
     if (bchunk < 1) return MOGAN_ERR_SHAPE;
@@ -380,8 +325,7 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* mean, const
         const int nb = B - b0 < bchunk ? B - b0 : bchunk;
         hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT>), dim3((HW + 255) / 256, nb * Cy), dim3(256), 0, stream,
                            x + (size_t)b0 * C * HW, dy + (size_t)b0 * Cy * HW, mean, invstd, gamma, beta,
-                           (const double*)part, YS, dgamma, dbeta, accumulate, b0 == 0 ? 1 : 0,
-                           dx + (size_t)b0 * C * HW, C, HW, slope, inv_n);
+                           (const float*)sums, dx + (size_t)b0 * C * HW, C, HW, slope, inv_n);
     }
     return ok_launch();
 }
@@ -470,57 +414,6 @@ int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, con
         MOGAN_FWD_CASE(MOGAN_ACT_LRELU)
         MOGAN_FWD_CASE(MOGAN_ACT_GLU)
         default: return MOGAN_ERR_SHAPE;
-    }
-    return ok_launch();
-}
-
-#define MOGAN_TRAIN_CASE(A)                                                                                         \
-    case A:                                                                                                         \
-        if (vec) hipLaunchKernelGGL((bn_train_fwd_kernel<A, true>), grid, dim3(256), 0, stream, px, (const double*)part, YS, \
-                                    n, eps, momentum, gamma, beta, pres, py, mean, invstd, running_mean, running_var, C, HW, \
-                                    slope, publish);                                                                \
-        else hipLaunchKernelGGL((bn_train_fwd_kernel<A, false>), grid, dim3(256), 0, stream, px, (const double*)part, YS, n, \
-                                eps, momentum, gamma, beta, pres, py, mean, invstd, running_mean, running_var, C, HW, slope, \
-                                publish);                                                                           \
-        break;
-
-// Training-mode BatchNorm + activation (+ residual) in TWO launches: per-block partial sums, then the apply pass with the
-// finalize folded in (mean / invstd published for the backward pass, running statistics updated like nn.BatchNorm).
-int mogan_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
-                       float* invstd, float* running_mean, float* running_var, int B, int C, int HW, int act, float slope,
-                       float eps, float momentum, void* ws, size_t ws_bytes, hipStream_t stream) {
-    if (B <= 0 || C <= 0 || HW <= 0 || (act == MOGAN_ACT_GLU && (C & 1))) return MOGAN_ERR_SHAPE;
-    if (!ws || ws_bytes < mogan_bn_ws_bytes(B, C, HW)) return MOGAN_ERR_WS;
-    double* part = (double*)ws;
-    int YS = 1;
-    if (HW == 1) {
-        hipLaunchKernelGGL(bn1d_partial_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, x, B, C, part);
-    } else {
-        const Split s = make_split(B, C, HW);
-        YS = s.bs * s.hs;
-        if (YS > 65535) return MOGAN_ERR_SHAPE;
-        hipLaunchKernelGGL(bn_partial_kernel, dim3(C, YS), dim3(256), 0, stream, x, B, C, HW, s, part);
-    }
-    const int Cy = act == MOGAN_ACT_GLU ? C / 2 : C;
-    const bool vec = (HW & 3) == 0;
-    const int per = vec ? 1024 : 256;
-    const double n = (double)B * HW;
-    const int bchunk = 65535 / Cy;
-    if (bchunk < 1) return MOGAN_ERR_SHAPE;
-    for (int b0 = 0; b0 < B; b0 += bchunk) {
-        const int nb = B - b0 < bchunk ? B - b0 : bchunk;
-        dim3 grid((HW + per - 1) / per, nb * Cy);
-        const float* px = x + (size_t)b0 * C * HW;
-        const float* pres = residual ? residual + (size_t)b0 * Cy * HW : nullptr;
-        float* py = y + (size_t)b0 * Cy * HW;
-        const int publish = b0 == 0 ? 1 : 0;
-        switch (act) {
-            MOGAN_TRAIN_CASE(MOGAN_ACT_NONE)
-            MOGAN_TRAIN_CASE(MOGAN_ACT_RELU)
-            MOGAN_TRAIN_CASE(MOGAN_ACT_LRELU)
-            MOGAN_TRAIN_CASE(MOGAN_ACT_GLU)
-            default: return MOGAN_ERR_SHAPE;
-        }
     }
     return ok_launch();
 }

@@ -307,6 +307,20 @@ int mogan_copy_strided(const float* src, long long src_bstride, float* dst, long
 int mogan_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 int mogan_bilinear_bwd(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 
+/* ---------------------------------------------------------------- input pipeline (device side)
+ * datasets.py:70-137 (get_imgs / crop_imgs) after the JPEG decode + resize to `ori` x `ori` (268): the host uploads u8
+ * HWC images and the (column offset h1, row offset w1, flip) it drew per sample.
+ * crop_flip: src (B,ori,ori,3) u8, params (B,3) int32 -> q (B,size,size,3) u8 (the crop, = ToPILImage of it) and
+ *            out (B,3,size,size) f32 = ((u8/255) - 0.5) / 0.5 (ToTensor + Normalize).
+ * resample:  Pillow's antialiased BILINEAR resize of the square u8 image `in` (B,S,S,3) to OS x OS (transforms.Resize),
+ *            then ToTensor + Normalize -> out (B,3,OS,OS) f32.  bounds (OS,2) / kk (OS,ksize): Pillow's coefficient
+ *            tables (precompute_coeffs + normalize_coeffs_8bpc, 22-bit fixed point; the same table serves both passes of
+ *            a square resize), built by the host (attngan/feeder.py); tmp (B,S,OS,3) u8 scratch.  Bit-identical to PIL. */
+int mogan_feed_crop_flip(const uint8_t* src, const int32_t* params, uint8_t* q, float* out, int B, int ori, int size,
+                         hipStream_t stream);
+int mogan_feed_resample(const uint8_t* in, uint8_t* tmp, float* out, const int32_t* bounds, const int32_t* kk, int ksize,
+                        int B, int S, int OS, hipStream_t stream);
+
 /* ---------------------------------------------------------------- optimizer
  * One fused Adam step over a flat fp32 bucket (trainer.py:137-148: lr 2e-4, betas (0.5,0.999), eps 1e-8),
  * optionally followed by the EMA of trainer.py:341-342: ema = ema_decay*ema + (1-ema_decay)*p (ema nullable).

@@ -41,6 +41,35 @@ def prepare_data(batch, device=None, eval=False):
     return out
 
 
+def prepare_data_raw(batch, feeder, rng=np.random, eval=False):
+    """prepare_data for TextDataset(raw=True) batches: per sample the crop offsets / flip are drawn and the boxes rescaled
+    on the host (feeder.draw_crop = the arithmetic of crop_imgs), the images are cropped / flipped / resampled /
+    normalised on the device (feeder.DeviceFeeder).  Same return structure as prepare_data."""
+    from .feeder import draw_crop
+    u8, captions, captions_lens, class_ids, keys, bboxes, label = batch
+    B = u8.shape[0]
+    params, scaled = [], []
+    for b in range(B):
+        p, sb = draw_crop(bboxes[b].numpy(), rng)
+        params.append(p)
+        scaled.append(sb)
+    slot = feeder.upload(u8, np.asarray(params, dtype=np.int32))        # starts the H2D copy; the rest overlaps it
+    scaled = torch.from_numpy(np.stack(scaled).astype(np.float32))
+    tmi = compute_transformation_matrix_inverse(scaled.view(-1, 4)).view(B, -1, 2, 3)
+    tm = compute_transformation_matrix(scaled.view(-1, 4)).view(B, -1, 2, 3)
+    device = feeder.device
+    sorted_cap_lens, order = torch.sort(captions_lens, 0, True)
+    imgs = feeder.process(slot)
+    od = order.to(device)
+    real_imgs = [im.index_select(0, od) for im in imgs]
+    keys = [keys[i] for i in order.numpy()]
+    out = [real_imgs, captions[order].squeeze(-1).to(device), sorted_cap_lens.to(device), class_ids[order].numpy(), keys,
+           [tm[order].to(device), tmi[order].to(device)], label[order].to(device)]
+    if eval:
+        out.append(scaled[order])
+    return out
+
+
 def crop_imgs(image, bbox, max_objects=3, rng=np.random):
     """image (3,268,268) float tensor, bbox (max_objects,4) relative (x,y,w,h) or -1 -> random 256 crop,
     random horizontal flip, bbox rescaled to the crop with the reference's clamp (x+w > 0.999 -> w = 1-x-0.001)."""
@@ -103,9 +132,12 @@ class _Base(data.Dataset):
 
 class TextDataset(_Base):
     def __init__(self, data_dir, img_dir, split='train', base_size=64, transform=None, target_transform=None,
-                 eval=False):
+                 eval=False, raw=False):
+        """raw=True: the workers stop after the JPEG decode + resize; a sample then carries the 268x268 u8 image and the
+        UNSCALED boxes, and crop / flip / multi-scale / normalise run on the device (feeder.DeviceFeeder via
+        prepare_data_raw)."""
         self.embeddings_num = cfg.TEXT.CAPTIONS_PER_IMAGE
-        self.img_dir, self.data_dir, self.eval = img_dir, data_dir, eval
+        self.img_dir, self.data_dir, self.eval, self.raw = img_dir, data_dir, eval, raw
         self.split_dir = os.path.join(data_dir, split)
         self.imsize = [base_size << i for i in range(cfg.TREE.BRANCH_NUM)]
         with open(os.path.join(self.split_dir, 'bboxes.pickle'), 'rb') as f:
@@ -143,6 +175,12 @@ class TextDataset(_Base):
         from PIL import Image
         key = self.filenames[index]
         img = Image.open('%s/%s.jpg' % (self.img_dir, key)).convert('RGB').resize((268, 268), Image.BILINEAR)
+        if self.raw:
+            sent_ix = np.random.randint(0, self.embeddings_num)
+            caps, cap_len = self.get_caption(index * self.embeddings_num + sent_ix)
+            return (torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()), caps, cap_len, self.class_id[index], key,
+                    torch.from_numpy(np.asarray(self.bbox[index], dtype=np.float32).copy()),
+                    self._one_hot(self.labels[index]))
         img, bbox_scaled = crop_imgs(_to_tensor(img), self.bbox[index])
         imgs = _multi_scale(img, self.imsize)
         tms = self._matrices(bbox_scaled)

@@ -81,6 +81,8 @@ SIGNATURES = {
     "mogan_avgpool_bwd_ex": [P, P, P, I, I, I, I, I, I, I, P],
     "mogan_copy_strided": [P, L, P, L, I, L, P],
     "mogan_relu_bwd": [P, P, P, L, I, P],
+    "mogan_feed_crop_flip": [P, P, P, P, I, I, I, P],
+    "mogan_feed_resample": [P, P, P, P, P, I, I, I, I, P],
     "mogan_damsm_words_fwd": [P, P, P, I, I, I, I, I, F, F, F, P, P, P, P, P, P],
     "mogan_damsm_words_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, F, F, P, P, P],
     "mogan_damsm_ce_fwd": [P, P, P, I, I, P, P, P, P, P],

@@ -790,6 +790,12 @@ class condGANTrainer(object):
         nz = cfg.GAN.Z_DIM
         gen_iterations = 0
         fixed_noise = None
+        feeder = None
+        if getattr(self.data_loader.dataset, "raw", False):      # TextDataset(raw=True): augmentation on the device
+            from .datasets import prepare_data_raw
+            from .feeder import DeviceFeeder
+            feeder = DeviceFeeder(self.device, self.batch_size, sizes=tuple(cfg.TREE.BASE_SIZE << i
+                                                                            for i in range(cfg.TREE.BRANCH_NUM)))
         for epoch in range(start_epoch, self.max_epoch):
             start_t = time.time()
             logs = {}
@@ -797,7 +803,10 @@ class condGANTrainer(object):
             if hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)                   # DistributedSampler: a new partition of the epoch per epoch
             for data in self.data_loader:
-                imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data(data, self.device)
+                if feeder is not None:
+                    imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data_raw(data, feeder)
+                else:
+                    imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data(data, self.device)
                 batch = dict(imgs=imgs, captions=captions, cap_lens=cap_lens, cap_lens_cpu=cap_lens.cpu(),
                              class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot,
                              z=torch.randn(captions.shape[0], nz, device=self.device))

@@ -90,3 +90,16 @@ def test_synthetic_dataset_matches_the_same_contract():
     assert len(out) == 7 and out[1].shape == (4, 12) and out[6].shape == (4, 3, 81)
     bt = synthetic.make_batch(4)
     assert [tuple(t.shape) for t in out[0]] == [tuple(t.shape) for t in bt["imgs"]]
+
+
+def test_text_dataset_raw_mode_structure(fake_coco):
+    """TextDataset(raw=True): what the device feeder consumes -- the decoded 268x268 u8 image, the UNSCALED boxes, the same
+    caption / label fields as the host-augmenting mode."""
+    data_dir, img_dir, n = fake_coco
+    cfg.TREE.BRANCH_NUM, cfg.TEXT.WORDS_NUM, cfg.TEXT.CAPTIONS_PER_IMAGE = 3, 12, 5
+    ds = datasets.TextDataset(data_dir, img_dir, split="train", base_size=64, raw=True)
+    dl = torch.utils.data.DataLoader(ds, batch_size=3, drop_last=True, shuffle=False)
+    u8, caps, lens, cls, keys, bbox, onehot = next(iter(dl))
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (3, 268, 268, 3)
+    assert tuple(caps.shape) == (3, 12, 1) and tuple(bbox.shape) == (3, 3, 4) and tuple(onehot.shape) == (3, 3, 81)
+    np.testing.assert_allclose(bbox.numpy(), np.asarray(ds.bbox[:3], dtype=np.float32))

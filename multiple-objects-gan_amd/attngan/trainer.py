@@ -64,8 +64,12 @@ class FlatAdam:
         self.ema = self.p.clone() if with_ema else None
         self.state = torch.zeros(3, dtype=torch.float32, device=dev)     # device-resident step counter
 
+    on_zero = None          # set by ChunkedReducer: a new accumulation round of this bucket begins
+
     def zero_grad(self):
         self.g.zero_()
+        if self.on_zero is not None:
+            self.on_zero()
 
     def step(self, grad_scale=1.0):
         ops.adam_step(self.p, self.g, self.m, self.v, self.ema, self.lr, 0.5, 0.999, 1e-8,
@@ -131,6 +135,95 @@ def allreduce_flat(flat_g, comm_stream=None):
     return done
 
 
+class ChunkedReducer:
+    """Overlap of a big gradient bucket's all-reduce with the backward pass that fills it (replaces
+    the per-call gather of nn.parallel.data_parallel, trainer.py:296, miscc/losses.py:146-193).
+
+    The flat bucket is cut at parameter boundaries into chunks of >= chunk_bytes.  The kernels that write a parameter's
+    gradient report in through hip/ops.GRAD_HOOKS; how many contributions each parameter receives per backward (two for a
+    D update: real and fake; three for the conditional head; one where both are merged into one launch) is learned in the
+    first step.  From the second step on, the moment the last contribution of a chunk has been QUEUED, events are recorded
+    on the stream that runs the backward and on its weight-gradient side stream, the communication stream waits for both
+    and starts the chunk's all-reduce -- the deep layers of D_NET256 (produced first, 3/4 of its 643 MB) travel while the
+    shallow layers are still being differentiated.  finish() reduces whatever is left (everything, in the first step) and
+    makes the caller's stream wait for all chunks.  Same sums as one all-reduce of the whole bucket; the order of the
+    collectives is a function of the model's structure only, hence identical on every rank."""
+
+    def __init__(self, flat, chunk_bytes, comm_stream):
+        self.flat, self.comm = flat, comm_stream
+        base = flat.g.data_ptr()
+        self.base = base
+        bounds, start = [], flat.numel
+        # from the end of the bucket (the heads / deep layers, whose gradients are complete first) towards the front
+        cuts = [flat.numel]
+        for p, o in list(zip(flat.params, flat.offsets))[::-1]:
+            if (cuts[-1] - o) * 4 >= chunk_bytes:
+                cuts.append(o)
+        if cuts[-1] != 0:
+            cuts.append(0)
+        if len(cuts) > 2 and (cuts[-2] - cuts[-1]) * 4 < chunk_bytes // 4:     # a crumb at the front joins its neighbour
+            del cuts[-2]
+        self.chunks = [(cuts[i + 1], cuts[i]) for i in range(len(cuts) - 1)]    # (lo, hi) element ranges, deep first
+        self.chunk_of, self.members = {}, [[] for _ in self.chunks]
+        for p, o in zip(flat.params, flat.offsets):
+            for ci, (lo, hi) in enumerate(self.chunks):
+                if lo <= o < hi:
+                    self.chunk_of[base + 4 * o] = ci
+                    self.members[ci].append(base + 4 * o)
+        self.expected, self.counts, self.done, self.launched, self.early = None, {}, [], set(), 0
+        self.active = False
+        ops.GRAD_HOOKS.append((base, base + 4 * flat.numel, self.hit))
+        flat.on_zero = self.begin
+
+    def begin(self):
+        self.counts, self.done, self.launched, self.active, self.early = {}, [], set(), True, 0
+
+    def hit(self, ptr, stream):
+        if not self.active:
+            return
+        self.counts[ptr] = self.counts.get(ptr, 0) + 1
+        if self.expected is None:
+            return
+        ci = self.chunk_of.get(ptr)
+        if ci is None or ci in self.launched:
+            return
+        if all(self.counts.get(q, 0) >= self.expected.get(q, 1 << 30) for q in self.members[ci]):
+            self._launch(ci)
+            self.early += 1                  # (diagnostic: chunks that left before the backward pass had finished)
+
+    def _launch(self, ci):
+        cur = torch.cuda.current_stream()
+        side = ops._wgrad_streams.get(cur.cuda_stream)
+        for st in (cur, side):
+            if st is not None:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.comm.wait_event(ev)
+        lo, hi = self.chunks[ci]
+        with torch.cuda.stream(self.comm):
+            dist.all_reduce(self.flat.g[lo:hi])
+            ev = torch.cuda.Event()
+            ev.record()
+        self.done.append(ev)
+        self.launched.add(ci)
+
+    def finish(self):
+        """after the backward (and the weight-gradient join): reduce the chunks not yet on their way, then make the current
+        stream wait for all of them"""
+        self.active = False
+        if self.expected is None:
+            self.expected = dict(self.counts)                  # calibration step
+        elif any(self.counts.get(q, 0) != n for q, n in self.expected.items()):
+            self.expected = dict(self.counts)                  # the call pattern changed: re-learn, reduce the rest now
+        for ci in range(len(self.chunks)):
+            if ci not in self.launched:
+                self._launch(ci)
+        cur = torch.cuda.current_stream()
+        for ev in self.done:
+            cur.wait_event(ev)
+        return len(self.chunks)
+
+
 class TrainEngine:
     """Device-side state of one rank: networks, flat optimizers, DP communicator, optional hipGraph."""
 
@@ -162,9 +255,17 @@ class TrainEngine:
             ops.precreate_wgrad_stream(self.side[i])
         ops.precreate_wgrad_stream(torch.cuda.current_stream())
         self.comm_stream = None          # collectives are issued on the branch streams (see _allreduce_async)
+        self._debug_no_ar = bool(os.environ.get("MOGAN_DEBUG_NO_ALLREDUCE"))   # diagnostic: cost of the collectives' ordering
         if self.distributed and self.world > 1:
             self.sync_replicas()
-        self._debug_no_ar = bool(os.environ.get("MOGAN_DEBUG_NO_ALLREDUCE"))   # diagnostic: cost of the collectives' ordering
+        # buckets above 2 x MOGAN_DP_CHUNK_MB (default 96 MB: only D_NET256's 643 MB bucket) are reduced in chunks while
+        # their backward is still running (ChunkedReducer); 0 = one all-reduce per bucket after the backward
+        self.reducers = {}
+        chunk = int(float(os.environ.get("MOGAN_DP_CHUNK_MB", "96")) * (1 << 20))
+        if self.distributed and chunk > 0 and not self._debug_no_ar:
+            for o in [self.optG] + self.optDs:
+                if o.numel * 4 >= 2 * chunk:
+                    self.reducers[id(o)] = ChunkedReducer(o, chunk, torch.cuda.Stream())
 
     def sync_replicas(self, src=0):
         """Every rank starts from rank `src`'s weights, EMA shadow, optimizer state and BatchNorm buffers: the step only
@@ -186,6 +287,10 @@ class TrainEngine:
     # -- data parallel: sum all-reduce of a flat gradient bucket over RCCL on a side stream ----------
     def _allreduce_async(self, flat):
         if not self.distributed or self._debug_no_ar:
+            return None
+        red = self.reducers.get(id(flat))
+        if red is not None:                      # most of it is already on its way (started during the backward)
+            red.finish()
             return None
         # issued on the branch's own stream: the process group's internal stream orders the collective behind the work
         # queued on it and the branch continues (Adam) behind the collective; a dedicated communication stream only adds

@@ -27,6 +27,20 @@ ACT_TRACE = None
 DIRECT_GRAD = True
 
 
+# Data-parallel overlap hook (attngan/trainer.ChunkedReducer): address ranges of flat gradient buckets whose owner wants to
+# know when a parameter's .grad has just received a contribution (the kernel is queued on `stream`).  Empty unless N > 1.
+GRAD_HOOKS = []
+
+
+def _grad_hit(g, stream=None):
+    if GRAD_HOOKS:
+        p = g.data_ptr()
+        for lo, hi, cb in GRAD_HOOKS:
+            if lo <= p < hi:
+                cb(p, stream)
+                break
+
+
 def _grad_buf(param):
     if not DIRECT_GRAD or param is None:
         return None
@@ -68,8 +82,10 @@ def _wgrad_launch(dy, x, w_shape, geom, g):
         with torch.cuda.stream(side):
             conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=g, accumulate=True)
         _wgrad_keep.append((dy, x))               # freed only after the join (see join_wgrad)
+        _grad_hit(g, side)
     else:
         conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=g, accumulate=True)
+        _grad_hit(g)
 
 
 def _wgrad_accumulate(dy, x, w, geom, g):
@@ -251,6 +267,7 @@ class Conv2dFn(torch.autograd.Function):
                  1 if g is not None else 0, stream_ptr())
             if g is not None:
                 db = None
+                _grad_hit(g)
         return dx, dw, db, None, None, None, None
 
 
@@ -365,6 +382,7 @@ class LinearFn(torch.autograd.Function):
             g = _grad_buf(w)
             if g is not None:
                 bmm_raw(dy.t().unsqueeze(0), x.unsqueeze(0), g.unsqueeze(0), accumulate=True)
+                _grad_hit(g)
             else:
                 dw = torch.empty(w.shape, dtype=torch.float32, device=x.device)
                 bmm_raw(dy.t().unsqueeze(0), x.unsqueeze(0), dw.unsqueeze(0))
@@ -375,6 +393,7 @@ class LinearFn(torch.autograd.Function):
                  stream_ptr())
             if g is not None:
                 db = None
+                _grad_hit(g)
         return dx, dw, db
 
 
@@ -439,6 +458,8 @@ class BNActFn(torch.autograd.Function):
         call("mogan_bn_act_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(dx),
              ptr(dg), ptr(db), B, C, HW, act, slope, 1 if direct else 0, wsp, wsn, stream_ptr())
         if direct:
+            _grad_hit(gg)
+            _grad_hit(gb)
             dg = db = None
         return dx, dg, db, (dy if has_res else None), None, None, None, None, None, None
 

@@ -58,7 +58,8 @@ def main():
     torch.cuda.synchronize()
     sd = {"G": {k: v.cpu() for k, v in G.state_dict().items()},
           "D": [{k: v.cpu() for k, v in D.state_dict().items()} for D in Ds],
-          "ema": eng.optG.ema.cpu(), "logs": {k: float(v) for k, v in logs.items() if v.dim() == 0}}
+          "ema": eng.optG.ema.cpu(), "logs": {k: float(v) for k, v in logs.items() if v.dim() == 0},
+          "reducers": [(len(r.chunks), r.early) for r in eng.reducers.values()]}
     torch.save(sd, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

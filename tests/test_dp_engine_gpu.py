@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _oracle_mean_gradient_step():
+def _oracle_mean_gradient_step(steps=1):
     cfg = O.Cfg(gf_dim=4, df_dim=4, emb_dim=16, r_num=2, words_num=5)
     from helpers import det_fill_state
     G = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."))
@@ -39,24 +39,29 @@ def _oracle_mean_gradient_step():
     st = O.TrainState(G, Ds, cfg)
     init = {"G": {k: v.detach().clone() for k, v in G.items()},
             "D": [{k: v.detach().clone() for k, v in d.items()} for d in Ds]}
-    batches = [synthetic.make_batch(4, words_num=5, nef=16, seed=100 + r) for r in range(2)]
-    outs = [O.g_net(st.g, cfg, b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b["eps"])
-            for b in batches]
-    for i, d in enumerate(st.ds):
-        O.zero_grad(d)
+    for step in range(steps):
+        batches = [synthetic.make_batch(4, words_num=5, nef=16, seed=100 + 10 * step + r) for r in range(2)]
+        outs = [O.g_net(st.g, cfg, b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b["eps"])
+                for b in batches]
+        for i, d in enumerate(st.ds):
+            O.zero_grad(d)
+            for b, o in zip(batches, outs):
+                (O.discriminator_loss(i, d, b["imgs"][i], o[0][i], b["sent_emb"], b, cfg) / 2.0).backward()
+            O.adam_step(d, st.opt_ds[i], cfg.lr_d)
+        O.zero_grad(st.g)
         for b, o in zip(batches, outs):
-            (O.discriminator_loss(i, d, b["imgs"][i], o[0][i], b["sent_emb"], b, cfg) / 2.0).backward()
-        O.adam_step(d, st.opt_ds[i], cfg.lr_d)
-    O.zero_grad(st.g)
-    for b, o in zip(batches, outs):
-        err_g, _ = O.generator_loss(st.ds, enc, o[0], b, cfg)
-        ((err_g + O.kl_loss(o[2], o[3])) / 2.0).backward()
-    O.adam_step(st.g, st.opt_g, cfg.lr_g)
+            err_g, _ = O.generator_loss(st.ds, enc, o[0], b, cfg)
+            ((err_g + O.kl_loss(o[2], o[3])) / 2.0).backward()
+        O.adam_step(st.g, st.opt_g, cfg.lr_g)
     return init, st
 
 
-def test_two_rank_engine_step_equals_oracle_mean_gradient_step(tmp_path):
-    env = dict(os.environ, MOGAN_DIST_BACKEND="gloo", MOGAN_STREAMS=os.environ.get("MOGAN_STREAMS", "1"))
+@pytest.mark.parametrize("chunk_mb", ["0", "0.05"], ids=["whole-bucket", "chunked-overlap"])
+def test_two_rank_engine_step_equals_oracle_mean_gradient_step(tmp_path, chunk_mb):
+    """chunk_mb 0.05: every bucket of the reduced-width networks is cut into several chunks whose all-reduces start during
+    the backward pass (trainer.ChunkedReducer); two steps, so that the second one runs with the learned schedule."""
+    env = dict(os.environ, MOGAN_DIST_BACKEND="gloo", MOGAN_STREAMS=os.environ.get("MOGAN_STREAMS", "1"),
+               MOGAN_DP_CHUNK_MB=chunk_mb, DP_STEPS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "tests", "dp_worker.py"),
            str(tmp_path)]
@@ -74,12 +79,19 @@ def test_two_rank_engine_step_equals_oracle_mean_gradient_step(tmp_path):
                 assert torch.equal(v, r1["D"][i][k]), "D%d %s differs between the ranks" % (i, k)
     assert torch.equal(r0["ema"], r1["ema"])
     assert r0["logs"]["errD0"] != r1["logs"]["errD0"]            # ... although they saw different batches
+    if chunk_mb != "0":
+        # every bucket was cut into several chunks and, in the second step, all but (at most) the last one left while the
+        # backward pass was still being queued
+        assert len(r0["reducers"]) == 4 and all(n >= 2 and early >= n - 1 for n, early in r0["reducers"]), r0["reducers"]
+        print("chunks (count, started during the backward):", r0["reducers"])
+    else:
+        assert r0["reducers"] == []
     # (2) = the oracle's step on the mean gradient
-    init, st = _oracle_mean_gradient_step()
-    lr = 2e-4
+    init, st = _oracle_mean_gradient_step(steps=2)
+    lr, nsteps = 2e-4, 2
     report, failures = [], []
-    for name, got_sd, want_net, init_net, max_bad in [("G", r0["G"], st.g, init["G"], 0.15)] + \
-            [("D%d" % i, r0["D"][i], st.ds[i], init["D"][i], 0.05) for i in range(3)]:
+    for name, got_sd, want_net, init_net, max_bad in [("G", r0["G"], st.g, init["G"], 0.02)] + \
+            [("D%d" % i, r0["D"][i], st.ds[i], init["D"][i], 0.01) for i in range(3)]:
         n = bad = moved = 0
         for k, w in want_net.items():
             if not (torch.is_tensor(w) and w.requires_grad):
@@ -87,15 +99,15 @@ def test_two_rank_engine_step_equals_oracle_mean_gradient_step(tmp_path):
             d_got = (got_sd[k].double() - init_net[k].double()).flatten()
             d_want = (w.detach().double() - init_net[k].double()).flatten()
             n += d_want.numel()
-            bad += int(((d_got - d_want).abs() > 0.25 * lr).sum())
+            bad += int(((d_got - d_want).abs() > 0.5 * lr).sum())
             moved += int((d_want.abs() > 0.5 * lr).sum())
-            if float(d_got.abs().max()) > lr * 1.001:
+            if float(d_got.abs().max()) > nsteps * lr * 1.2:      # (Adam's second step can exceed lr slightly)
                 failures.append("%s %s moved by more than lr" % (name, k))
-        report.append("%s: %d parameters, %.2f%% of the deltas off by > lr/4 (allowed %.0f%%), %.0f%% moved by > lr/2"
+        report.append("%s: %d parameters, %.2f%% of the deltas off by > lr/2 (allowed %.0f%%), %.0f%% moved by > lr/2"
                       % (name, n, 100.0 * bad / n, 100 * max_bad, 100.0 * moved / n))
         if moved <= 0.5 * n:
             failures.append("%s: the oracle moved only %d of %d elements" % (name, moved, n))
         if bad > max_bad * n:
-            failures.append("%s: %d of %d parameter deltas differ from the mean-gradient step by > lr/4" % (name, bad, n))
+            failures.append("%s: %d of %d parameter deltas differ from the mean-gradient step by > lr/2" % (name, bad, n))
     print("\n".join(report))
     assert not failures, "; ".join(failures) + " | " + " | ".join(report)

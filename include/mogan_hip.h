@@ -78,6 +78,8 @@ int mogan_wino22_debug_min_tiles(int n);
 
 /* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
 int mogan_gemm_debug_force(int cfg, int split);
+/* tuning hook: grouped launches (mogan_conv2d_*_group) with fewer tiles than this run their members one by one (default 1600, see csrc/mogan_gemm.hip) */
+int mogan_gemm_group_min_tiles(int tiles);
 
 /* measurement hook (bench.py roofline leg): with profiling enabled every gemm_kernel launch is bracketed by
  * HIP events on its own stream; collect() returns rows of 5 doubles {mode (0 fwd,1 dgrad,2 wgrad,3 bmm),
@@ -104,6 +106,22 @@ int mogan_conv2d_affine_fwd(const float* x, const float* w, const float* scale, 
 int mogan_affine_relu_bwd_out(const float* y, const float* dy, const float* scale, float* dx, int B, int C, int HW,
                               hipStream_t stream);
 /* dx: gradient w.r.t. the conv input in the H x W domain, (B,Cin,H,W); for up=1 follow with mogan_down2_sum */
+/* Grouped launches for the frozen trunk: up to 4 INDEPENDENT convolutions of one dependency level of a Mixed block (same
+ * direction, arbitrary geometries) run as one launch whose 1-D grid is the concatenation of the problems' tile grids -- at
+ * B = 16 each of them alone needs split-K (+ a reduction launch) to fill the chip.  Field meaning = the arguments of
+ * mogan_conv2d_affine_fwd_ex / mogan_conv2d_dgrad_ex.  Outputs of a group must not overlap. */
+typedef struct MoganConvFwdArgs {
+    const float* x; long long x_bstride; const float* w; const float* scale; const float* shift;
+    float* y; long long y_bstride; float* y2; long long y2_bstride; int msplit;
+    int B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, relu;
+} MoganConvFwdArgs;
+typedef struct MoganConvDgradArgs {
+    const float* dy; long long dy_bstride; const float* w; float* dx; long long dx_bstride;
+    const float* relu_of; long long relu_bstride; int accumulate;
+    int B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw;
+} MoganConvDgradArgs;
+int mogan_conv2d_affine_fwd_group(int n, const MoganConvFwdArgs* args, void* ws, size_t ws_bytes, hipStream_t stream);
+int mogan_conv2d_dgrad_group(int n, const MoganConvDgradArgs* args, void* ws, size_t ws_bytes, hipStream_t stream);
 /* Channel-slice addressing for the frozen Inception trunk (model.py:258-299): x is a slice (batch stride x_bstride
  * elements) of a larger NCHW tensor; output channels [0, msplit) go to y (batch stride y_bstride, -1 = dense), channels
  * [msplit, Cout) to y2 (y2 nullable: everything to y).  One launch then serves a group of same-input 1x1 convolutions whose

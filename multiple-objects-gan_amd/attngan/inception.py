@@ -279,44 +279,81 @@ class _FrozenConv:
         return ((H + 2 * self.pad[0] - self.k[0]) // self.stride + 1, (W + 2 * self.pad[1] - self.k[1]) // self.stride + 1)
 
 
+class _Op:
+    """one launch-able piece of the trunk: a convolution (BasicConv2d, eval-mode BN folded), or a pooling"""
+    __slots__ = ("kind", "fc", "x", "y", "y2", "relu_in", "plain", "k", "s", "pad", "idx")
+
+    def __init__(self, kind, x, y, fc=None, y2=None, relu_in=True, plain=False, k=0, s=0, pad=0):
+        self.kind, self.fc, self.x, self.y, self.y2, self.relu_in, self.plain = kind, fc, x, y, y2, relu_in, plain
+        self.k, self.s, self.pad, self.idx = k, s, pad, None
+
+
+GROUPED = os.environ.get("MOGAN_INCEPTION_GROUPED", "1") != "0"      # 0: one launch per convolution (A/B measurements)
+
+
 class _Tape:
-    """forward launches + what the backward pass needs; one per forward call"""
+    """forward launches + what the backward pass needs; one per forward call.  Work is issued in LEVELS: the operations of
+    a level are independent, its convolutions go out as ONE grouped launch (mogan_conv2d_*_group)."""
 
     def __init__(self, B, device):
-        self.B, self.dev, self.ops, self.grads = B, device, [], {}
+        self.B, self.dev, self.grads, self.bwd_levels = B, device, {}, []
 
     def new(self, C, H, W):
         return torch.empty((self.B, C, H, W), dtype=torch.float32, device=self.dev)
 
-    # ---- forward ----------------------------------------------------------------------------------------------
     def conv(self, fc, x, y, y2=None, relu_in=True, plain=False):
-        """y (and y2: channels >= y.C of a grouped convolution) = relu(bn(conv(x))).  relu_in: x is a ReLU output (its
-        zeros gate the data gradient).  plain: dense in/out through the ordinary entry point (fast paths allowed)."""
-        from ..hip.lib import call, stream_ptr, workspace
-        wsp, wsn = workspace(x.t.device)
         assert x.C == fc.cin and y.C + (y2.C if y2 is not None else 0) == fc.cout
-        if plain:
-            assert x.dense and y.dense and y2 is None
-            call("mogan_conv2d_affine_fwd", x.ptr, fc.w.data_ptr(), fc.scale.data_ptr(), fc.shift.data_ptr(), y.ptr, self.B,
-                 fc.cin, x.H, x.W, fc.cout, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 1, wsp, wsn, stream_ptr())
-        else:
-            call("mogan_conv2d_affine_fwd_ex", x.ptr, x.bstride, fc.w.data_ptr(), fc.scale.data_ptr(), fc.shift.data_ptr(),
-                 y.ptr, y.bstride, y2.ptr if y2 is not None else None, y2.bstride if y2 is not None else 0, y.C, self.B,
-                 fc.cin, x.H, x.W, fc.cout, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 1, wsp, wsn, stream_ptr())
-        self.ops.append(("conv", fc, x, y, y2, relu_in, plain))
+        return _Op("conv", x, y, fc=fc, y2=y2, relu_in=relu_in, plain=plain)
 
-    def avgpool(self, x, y, k, s, pad, relu_in=True):
-        from ..hip.lib import call, stream_ptr
+    @staticmethod
+    def avgpool(x, y, k, s, pad, relu_in=True):
         assert x.dense and y.dense
-        call("mogan_avgpool_fwd", x.ptr, y.ptr, self.B * x.C, x.H, x.W, k, s, pad, stream_ptr())
-        self.ops.append(("avgpool", x, y, k, s, pad, relu_in))
+        return _Op("avgpool", x, y, relu_in=relu_in, k=k, s=s, pad=pad)
 
-    def maxpool(self, x, y, k, s, relu_in=True):
-        from ..hip.lib import call, stream_ptr
+    @staticmethod
+    def maxpool(x, y, k, s, relu_in=True):
         assert x.dense
-        idx = torch.empty((self.B, x.C, y.H, y.W), dtype=torch.uint8, device=self.dev)
-        call("mogan_maxpool_fwd_ex", x.ptr, y.ptr, y.bstride, idx.data_ptr(), self.B, x.C, x.H, x.W, k, s, stream_ptr())
-        self.ops.append(("maxpool", x, y, idx, k, s, relu_in))
+        return _Op("maxpool", x, y, relu_in=relu_in, k=k, s=s)
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def _fwd_args(self, op):
+        from ..hip.lib import ConvFwdArgs
+        fc, x, y, y2 = op.fc, op.x, op.y, op.y2
+        return ConvFwdArgs(x.ptr, x.bstride, fc.w.data_ptr(), fc.scale.data_ptr(), fc.shift.data_ptr(), y.ptr, y.bstride,
+                           y2.ptr if y2 is not None else None, y2.bstride if y2 is not None else 0, y.C, self.B, fc.cin,
+                           x.H, x.W, fc.cout, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 1)
+
+    def run(self, level):
+        """issue one level of the forward pass"""
+        import ctypes
+        from ..hip.lib import ConvFwdArgs, call, stream_ptr, workspace
+        convs = []
+        for op in level:
+            if op.kind == "avgpool":
+                call("mogan_avgpool_fwd", op.x.ptr, op.y.ptr, self.B * op.x.C, op.x.H, op.x.W, op.k, op.s, op.pad, stream_ptr())
+            elif op.kind == "maxpool":
+                op.idx = torch.empty((self.B, op.x.C, op.y.H, op.y.W), dtype=torch.uint8, device=self.dev)
+                call("mogan_maxpool_fwd_ex", op.x.ptr, op.y.ptr, op.y.bstride, op.idx.data_ptr(), self.B, op.x.C, op.x.H,
+                     op.x.W, op.k, op.s, stream_ptr())
+            elif op.plain:
+                fc, x, y = op.fc, op.x, op.y
+                assert x.dense and y.dense and op.y2 is None
+                wsp, wsn = workspace(self.dev)
+                call("mogan_conv2d_affine_fwd", x.ptr, fc.w.data_ptr(), fc.scale.data_ptr(), fc.shift.data_ptr(), y.ptr,
+                     self.B, fc.cin, x.H, x.W, fc.cout, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 1, wsp, wsn,
+                     stream_ptr())
+            else:
+                convs.append(op)
+        wsp, wsn = workspace(self.dev)
+        for chunk in ([convs] if GROUPED else [[c] for c in convs]):
+            for i in range(0, len(chunk), 4):
+                part = chunk[i:i + 4]
+                arr = (ConvFwdArgs * len(part))(*[self._fwd_args(op) for op in part])
+                call("mogan_conv2d_affine_fwd_group", len(part), ctypes.cast(arr, ctypes.c_void_p), wsp, wsn, stream_ptr())
+
+    def plan_backward(self, levels):
+        """the backward schedule of what was just run: levels from the outputs towards the inputs"""
+        self.bwd_levels.append(levels)
 
     # ---- backward ---------------------------------------------------------------------------------------------
     def grad_of(self, t):
@@ -340,56 +377,63 @@ class _Tape:
         g = g.contiguous()
         call("mogan_relu_bwd", t.data_ptr(), g.data_ptr(), dst.ptr, t.numel(), 1 if acc else 0, stream_ptr())
 
-    def backward(self):
-        from ..hip.lib import call, stream_ptr, workspace
-        for op in reversed(self.ops):
-            kind = op[0]
-            if kind == "conv":
-                _, fc, x, y, y2, relu_in, plain = op
-                wsp, wsn = workspace(self.dev)
-                gy, _ = self.grad_of(y.t)
-                if y2 is not None:
-                    # the group's gradient = [slice of the block-output gradient | gradient of the scratch tensor]: bring
-                    # the first part next to the second (the scratch gradient was allocated with room in front)
-                    g2, _ = self.grad_of(y2.t)
-                    full = g2._mogan_full
-                    call("mogan_copy_strided", _Slice(gy, y.c0, y.C).ptr, y.bstride, full.data_ptr(),
-                         full.shape[1] * full.shape[2] * full.shape[3], self.B, y.C * y.H * y.W, stream_ptr())
-                    dy = _Slice(full)
-                else:
-                    dy = _Slice(gy, y.c0, y.C)
-                dx, acc = self._dst(x)
-                if plain:
-                    assert not acc and dx.dense and dy.dense
-                    call("mogan_conv2d_dgrad", dy.ptr, fc.wb.data_ptr(), dx.ptr, self.B, fc.cin, x.H, x.W, fc.cout, fc.k[0],
-                         fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 0, wsp, wsn, stream_ptr())
-                    if relu_in:
-                        call("mogan_relu_bwd", x.t.data_ptr(), dx.ptr, dx.ptr, x.t.numel(), 0, stream_ptr())
-                else:
-                    call("mogan_conv2d_dgrad_ex", dy.ptr, dy.bstride, fc.wb.data_ptr(), dx.ptr, dx.bstride,
-                         x.ptr if relu_in else None, x.bstride, 1 if acc else 0, self.B, fc.cin, x.H, x.W, fc.cout, fc.k[0],
-                         fc.k[1], fc.stride, fc.pad[0], fc.pad[1], wsp, wsn, stream_ptr())
-            elif kind == "avgpool":
-                _, x, y, k, s, pad, relu_in = op
-                gy, _ = self.grad_of(y.t)
-                dx, acc = self._dst(x)
-                call("mogan_avgpool_bwd_ex", gy.data_ptr(), dx.ptr, x.ptr if relu_in else None, 1 if acc else 0,
-                     self.B * x.C, x.H, x.W, k, s, pad, stream_ptr())
+    def _bwd_level(self, level):
+        import ctypes
+        from ..hip.lib import ConvDgradArgs, call, stream_ptr, workspace
+        wsp, wsn = workspace(self.dev)
+        group = []
+        for op in level:
+            gy, _ = self.grad_of(op.y.t)
+            if op.kind == "avgpool":
+                dx, acc = self._dst(op.x)
+                call("mogan_avgpool_bwd_ex", gy.data_ptr(), dx.ptr, op.x.ptr if op.relu_in else None, 1 if acc else 0,
+                     self.B * op.x.C, op.x.H, op.x.W, op.k, op.s, op.pad, stream_ptr())
+                continue
+            if op.kind == "maxpool":
+                dy = _Slice(gy, op.y.c0, op.y.C)
+                dx, acc = self._dst(op.x)
+                call("mogan_maxpool_bwd_ex", op.idx.data_ptr(), dy.ptr, dy.bstride, dx.ptr, op.x.ptr if op.relu_in else None,
+                     1 if acc else 0, self.B, op.x.C, op.x.H, op.x.W, op.k, op.s, stream_ptr())
+                continue
+            fc, x, y, y2 = op.fc, op.x, op.y, op.y2
+            if y2 is not None:
+                # the group's gradient = [slice of the block-output gradient | gradient of the scratch tensor]: bring the
+                # first part next to the second (the scratch gradient was allocated with room in front)
+                g2, _ = self.grad_of(y2.t)
+                full = g2._mogan_full
+                call("mogan_copy_strided", _Slice(gy, y.c0, y.C).ptr, y.bstride, full.data_ptr(), full.stride(0), self.B,
+                     y.C * y.H * y.W, stream_ptr())
+                dy = _Slice(full)
             else:
-                _, x, y, idx, k, s, relu_in = op
-                gy, _ = self.grad_of(y.t)
                 dy = _Slice(gy, y.c0, y.C)
-                dx, acc = self._dst(x)
-                call("mogan_maxpool_bwd_ex", idx.data_ptr(), dy.ptr, dy.bstride, dx.ptr, x.ptr if relu_in else None,
-                     1 if acc else 0, self.B, x.C, x.H, x.W, k, s, stream_ptr())
+            dx, acc = self._dst(x)
+            if op.plain:
+                assert not acc and dx.dense and dy.dense
+                call("mogan_conv2d_dgrad", dy.ptr, fc.wb.data_ptr(), dx.ptr, self.B, fc.cin, x.H, x.W, fc.cout, fc.k[0],
+                     fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 0, wsp, wsn, stream_ptr())
+                if op.relu_in:
+                    call("mogan_relu_bwd", x.t.data_ptr(), dx.ptr, dx.ptr, x.t.numel(), 0, stream_ptr())
+                continue
+            group.append(ConvDgradArgs(dy.ptr, dy.bstride, fc.wb.data_ptr(), dx.ptr, dx.bstride,
+                                       x.ptr if op.relu_in else None, x.bstride, 1 if acc else 0, self.B, fc.cin, x.H, x.W,
+                                       fc.cout, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1]))
+        for chunk in ([group] if GROUPED else [[a] for a in group]):
+            for i in range(0, len(chunk), 4):
+                part = chunk[i:i + 4]
+                arr = (ConvDgradArgs * len(part))(*part)
+                call("mogan_conv2d_dgrad_group", len(part), ctypes.cast(arr, ctypes.c_void_p), wsp, wsn, stream_ptr())
+
+    def backward(self):
+        for levels in reversed(self.bwd_levels):
+            for level in levels:
+                self._bwd_level(level)
 
     def scratch_for_group(self, n_front, C, H, W):
         """scratch tensor of a grouped 1x1 convolution whose first n_front output channels live in the block output: its
         GRADIENT buffer gets n_front channels of room in front, so that the group's data gradient reads one tensor"""
         t = self.new(C, H, W)
         full = torch.empty((self.B, n_front + C, H, W), dtype=torch.float32, device=self.dev)
-        # the scratch gradient as a channel slice of `full`: (storage shared, batch stride of `full`)
-        g = full[:, n_front:]
+        g = full[:, n_front:]                    # the scratch gradient as a channel slice of `full`
         g._mogan_full = full
         self.grads[id(t)] = [g, set()]
         return t
@@ -422,75 +466,88 @@ class FrozenTrunk:
                            d2=g("branch3x3dbl_2"), da=g("branch3x3dbl_3a"), db=g("branch3x3dbl_3b"), bp=g("branch_pool"))
             self.blocks.append((name, type(blk).__name__, fcs))
 
-    # each block: x (dense _Slice) -> dense output tensor
+    # each block: x (dense _Slice) -> dense output tensor.  Forward levels run as they are built; the backward levels list
+    # the same operations from the outputs towards the input, grouped so that no two members of a level write the same
+    # gradient elements (the members of a level run concurrently in one launch).
     @staticmethod
     def _block(tp, kind, f, x):
-        B, H, W = tp.B, x.H, x.W
+        H, W = x.H, x.W
         if kind == "InceptionA":
             n1, n5, nd = 64, 48, 64
             O = tp.new(n1 + f["b5"].cout + f["d3"].cout + f["bp"].cout, H, W)
             T = tp.scratch_for_group(n1, n5 + nd, H, W)
-            tp.conv(f["g1"], x, _Slice(O, 0, n1), _Slice(T))
-            tp.conv(f["b5"], _Slice(T, 0, n5), _Slice(O, n1, 64))
-            U = tp.new(96, H, W)
-            tp.conv(f["d2"], _Slice(T, n5, nd), _Slice(U))
-            tp.conv(f["d3"], _Slice(U), _Slice(O, n1 + 64, 96))
-            P = tp.new(x.C, H, W)
-            tp.avgpool(x, _Slice(P), 3, 1, 1)
-            tp.conv(f["bp"], _Slice(P), _Slice(O, n1 + 64 + 96, f["bp"].cout), relu_in=False)
+            U, P = tp.new(96, H, W), tp.new(x.C, H, W)
+            g1 = tp.conv(f["g1"], x, _Slice(O, 0, n1), _Slice(T))
+            pool = tp.avgpool(x, _Slice(P), 3, 1, 1)
+            b5 = tp.conv(f["b5"], _Slice(T, 0, n5), _Slice(O, n1, 64))
+            d2 = tp.conv(f["d2"], _Slice(T, n5, nd), _Slice(U))
+            bp = tp.conv(f["bp"], _Slice(P), _Slice(O, n1 + 64 + 96, f["bp"].cout), relu_in=False)
+            d3 = tp.conv(f["d3"], _Slice(U), _Slice(O, n1 + 64, 96))
+            for level in ([g1, pool], [b5, d2, bp], [d3]):
+                tp.run(level)
+            tp.plan_backward([[bp, b5, d3], [d2], [pool, g1]])
             return O
         if kind == "InceptionB":
             oh, ow = f["b3"].out_hw(H, W)
             O = tp.new(384 + 96 + x.C, oh, ow)
-            tp.conv(f["b3"], x, _Slice(O, 0, 384))
             T, U = tp.new(64, H, W), tp.new(96, H, W)
-            tp.conv(f["d1"], x, _Slice(T))
-            tp.conv(f["d2"], _Slice(T), _Slice(U))
-            tp.conv(f["d3"], _Slice(U), _Slice(O, 384, 96))
-            tp.maxpool(x, _Slice(O, 480, x.C), 3, 2)
+            b3 = tp.conv(f["b3"], x, _Slice(O, 0, 384))
+            d1 = tp.conv(f["d1"], x, _Slice(T))
+            mp = tp.maxpool(x, _Slice(O, 480, x.C), 3, 2)
+            d2 = tp.conv(f["d2"], _Slice(T), _Slice(U))
+            d3 = tp.conv(f["d3"], _Slice(U), _Slice(O, 384, 96))
+            for level in ([b3, d1, mp], [d2], [d3]):
+                tp.run(level)
+            tp.plan_backward([[mp, d3], [d2], [d1], [b3]])          # d1 and b3 both add into dX: separate levels
             return O
         if kind == "InceptionC":
             c7 = f["s2"].cin
             O = tp.new(768, H, W)
             T = tp.scratch_for_group(192, 2 * c7, H, W)
-            tp.conv(f["g1"], x, _Slice(O, 0, 192), _Slice(T))
-            V = tp.new(c7, H, W)
-            tp.conv(f["s2"], _Slice(T, 0, c7), _Slice(V))
-            tp.conv(f["s3"], _Slice(V), _Slice(O, 192, 192))
-            W1, W2, W3 = tp.new(c7, H, W), tp.new(c7, H, W), tp.new(c7, H, W)
-            tp.conv(f["d2"], _Slice(T, c7, c7), _Slice(W1))
-            tp.conv(f["d3"], _Slice(W1), _Slice(W2))
-            tp.conv(f["d4"], _Slice(W2), _Slice(W3))
-            tp.conv(f["d5"], _Slice(W3), _Slice(O, 384, 192))
+            V, W1, W2, W3 = (tp.new(c7, H, W) for _ in range(4))
             P = tp.new(x.C, H, W)
-            tp.avgpool(x, _Slice(P), 3, 1, 1)
-            tp.conv(f["bp"], _Slice(P), _Slice(O, 576, 192), relu_in=False)
+            g1 = tp.conv(f["g1"], x, _Slice(O, 0, 192), _Slice(T))
+            pool = tp.avgpool(x, _Slice(P), 3, 1, 1)
+            s2 = tp.conv(f["s2"], _Slice(T, 0, c7), _Slice(V))
+            d2 = tp.conv(f["d2"], _Slice(T, c7, c7), _Slice(W1))
+            bp = tp.conv(f["bp"], _Slice(P), _Slice(O, 576, 192), relu_in=False)
+            s3 = tp.conv(f["s3"], _Slice(V), _Slice(O, 192, 192))
+            d3 = tp.conv(f["d3"], _Slice(W1), _Slice(W2))
+            d4 = tp.conv(f["d4"], _Slice(W2), _Slice(W3))
+            d5 = tp.conv(f["d5"], _Slice(W3), _Slice(O, 384, 192))
+            for level in ([g1, pool], [s2, d2, bp], [s3, d3], [d4], [d5]):
+                tp.run(level)
+            tp.plan_backward([[bp, s3, d5], [s2, d4], [d3], [d2], [pool, g1]])
             return O
         if kind == "InceptionD":
             oh, ow = f["b2"].out_hw(H, W)
             O = tp.new(320 + 192 + x.C, oh, ow)
-            T = tp.new(384, H, W)
-            tp.conv(f["g1"], x, _Slice(T))
-            tp.conv(f["b2"], _Slice(T, 0, 192), _Slice(O, 0, 320))
-            V1, V2 = tp.new(192, H, W), tp.new(192, H, W)
-            tp.conv(f["s2"], _Slice(T, 192, 192), _Slice(V1))
-            tp.conv(f["s3"], _Slice(V1), _Slice(V2))
-            tp.conv(f["s4"], _Slice(V2), _Slice(O, 320, 192))
-            tp.maxpool(x, _Slice(O, 512, x.C), 3, 2)
+            T, V1, V2 = tp.new(384, H, W), tp.new(192, H, W), tp.new(192, H, W)
+            g1 = tp.conv(f["g1"], x, _Slice(T))
+            mp = tp.maxpool(x, _Slice(O, 512, x.C), 3, 2)
+            b2 = tp.conv(f["b2"], _Slice(T, 0, 192), _Slice(O, 0, 320))
+            s2 = tp.conv(f["s2"], _Slice(T, 192, 192), _Slice(V1))
+            s3 = tp.conv(f["s3"], _Slice(V1), _Slice(V2))
+            s4 = tp.conv(f["s4"], _Slice(V2), _Slice(O, 320, 192))
+            for level in ([g1, mp], [b2, s2], [s3], [s4]):
+                tp.run(level)
+            tp.plan_backward([[mp, b2, s4], [s3], [s2], [g1]])
             return O
         # InceptionE
         O = tp.new(2048, H, W)
         T = tp.scratch_for_group(320, 384 + 448, H, W)
-        tp.conv(f["g1"], x, _Slice(O, 0, 320), _Slice(T))
-        tp.conv(f["a"], _Slice(T, 0, 384), _Slice(O, 320, 384))
-        tp.conv(f["b"], _Slice(T, 0, 384), _Slice(O, 704, 384))
-        U = tp.new(384, H, W)
-        tp.conv(f["d2"], _Slice(T, 384, 448), _Slice(U))
-        tp.conv(f["da"], _Slice(U), _Slice(O, 1088, 384))
-        tp.conv(f["db"], _Slice(U), _Slice(O, 1472, 384))
-        P = tp.new(x.C, H, W)
-        tp.avgpool(x, _Slice(P), 3, 1, 1)
-        tp.conv(f["bp"], _Slice(P), _Slice(O, 1856, 192), relu_in=False)
+        U, P = tp.new(384, H, W), tp.new(x.C, H, W)
+        g1 = tp.conv(f["g1"], x, _Slice(O, 0, 320), _Slice(T))
+        pool = tp.avgpool(x, _Slice(P), 3, 1, 1)
+        a = tp.conv(f["a"], _Slice(T, 0, 384), _Slice(O, 320, 384))
+        b = tp.conv(f["b"], _Slice(T, 0, 384), _Slice(O, 704, 384))
+        d2 = tp.conv(f["d2"], _Slice(T, 384, 448), _Slice(U))
+        bp = tp.conv(f["bp"], _Slice(P), _Slice(O, 1856, 192), relu_in=False)
+        da = tp.conv(f["da"], _Slice(U), _Slice(O, 1088, 384))
+        db = tp.conv(f["db"], _Slice(U), _Slice(O, 1472, 384))
+        for level in ([g1, pool], [a, b, d2, bp], [da, db]):
+            tp.run(level)
+        tp.plan_backward([[bp, a, da], [b, db], [d2], [pool, g1]])    # a/b both add into dT[:, :384], da/db into dU
         return O
 
     def forward(self, x299):
@@ -503,7 +560,7 @@ class FrozenTrunk:
         for step in plan:
             if step == "pool":
                 y = _Slice(tp.new(cur.C, (cur.H - 3) // 2 + 1, (cur.W - 3) // 2 + 1))
-                tp.maxpool(cur, y, 3, 2)
+                op = tp.maxpool(cur, y, 3, 2)
             else:
                 name, relu_in, plain_bwd = step
                 fc = st[name]
@@ -511,9 +568,11 @@ class FrozenTrunk:
                 y = _Slice(tp.new(fc.cout, oh, ow))
                 # forward through the ordinary entry point (Winograd / streaming kernels where they apply); `plain` also
                 # keeps the backward on it where that matters (first convolution: streaming kernel; 4a: Winograd)
-                tp.conv(fc, cur, y, relu_in=relu_in, plain=True)
-                if not plain_bwd:
-                    tp.ops[-1] = tp.ops[-1][:6] + (False,)
+                op = tp.conv(fc, cur, y, relu_in=relu_in, plain=True)
+            tp.run([op])
+            if op.kind == "conv" and not plain_bwd:
+                op.plain = False
+            tp.plan_backward([[op]])
             cur = y
         feats = None
         for name, kind, fcs in self.blocks:

@@ -100,7 +100,7 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, unsigned idx, bo
 // per 32-row tile (bank-conflict free at this stride), staging writes are ds_write_b128 of 4 consecutive k.
 // MFMA k assignment inside a K-tile: lane half h = lane>>5 owns k in [16h, 16h+16); step kk uses k = 16h+kk.
 template <int MODE, int WM, int WN, int TM, int TN, bool AVEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+__device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, const unsigned by, const unsigned bz) {
     constexpr bool SCHED = true;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, LD = BK + 4;
     constexpr int QA = BM / 32, QB = BN / 32;            // quads (4 consecutive k of one row) per thread
@@ -112,19 +112,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k is given a
-    // CONTIGUOUS range of the tile sequence (n fastest): the blocks that share one A (weight) panel then hit the same L2
-    // instead of fetching it once per XCD.
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-#if !defined(LAB) || LAB != 9
-    {
-        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
-        const unsigned L = bx + gx * (by + gy * bz);
-        const unsigned k = L & 7u, j = L >> 3, q = total >> 3, r = total & 7u;
-        const unsigned V = k * q + (k < r ? k : r) + j;
-        bx = V % gx; const unsigned t2 = V / gx; by = t2 % gy; bz = t2 / gy;
-    }
-#endif
     const int m0 = by * BM, n0 = bx * BN;
     const int zb = bz / p.nsplit, sp = bz % p.nsplit;
     const int kbeg = sp * p.kchunk;
@@ -455,6 +442,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k is given a
+// CONTIGUOUS range of the tile sequence (n fastest): the blocks that share one A (weight) panel then hit the same L2
+// instead of fetching it once per XCD.
+__device__ __forceinline__ unsigned xcd_order(unsigned L, unsigned total) {
+    const unsigned k = L & 7u, j = L >> 3, q = total >> 3, r = total & 7u;
+    return k * q + (k < r ? k : r) + j;
+}
+
+template <int MODE, int WM, int WN, int TM, int TN, bool AVEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#if !defined(LAB) || LAB != 9
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const unsigned V = xcd_order(bx + gx * (by + gy * bz), total);
+        bx = V % gx; const unsigned t2 = V / gx; by = t2 % gy; bz = t2 / gy;
+    }
+#endif
+    gemm_block<MODE, WM, WN, TM, TN, AVEC>(p, bx, by, bz);
+}
+
+// Several independent convolutions (same mode and tile shape, different operands / geometry) as ONE launch: the tile
+// sequences of the problems are laid end to end over a 1-D grid.  The frozen Inception trunk's Mixed blocks consist of
+// 2-4 small convolutions per dependency level (1-3 GFLOP each at B = 16): launched one by one each of them needs split-K
+// (+ a reduction launch) to fill 256 CUs; laid side by side their tiles fill the chip without it.
+constexpr int MAXG = 4;
+struct GroupArgs { GemmP p[MAXG]; int tile_end[MAXG]; int gx[MAXG], gy[MAXG]; int nprob; };
+
+template <int MODE, int WM, int WN, int TM, int TN, bool AVEC>
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GroupArgs g) {
+    const unsigned V = xcd_order(blockIdx.x, gridDim.x);
+    int pi = 0;
+#pragma unroll
+    for (int i = 0; i < MAXG - 1; ++i) if (i + 1 < g.nprob && V >= (unsigned)g.tile_end[i]) pi = i + 1;
+    const unsigned local = V - (pi ? (unsigned)g.tile_end[pi - 1] : 0u);
+    const unsigned gx = g.gx[pi], gy = g.gy[pi];
+    const unsigned bx = local % gx, t2 = local / gx;
+    gemm_block<MODE, WM, WN, TM, TN, AVEC>(g.p[pi], bx, t2 % gy, t2 / gy);
+}
+
 // out[dst(i)] = (acc ? out[dst(i)] : 0) + sum_s ws[s*slab + i]: fixed summation order (deterministic).  One element per
 // thread (small outputs still give hundreds of blocks), 8 independent slab loads in flight per thread.  The dense slab
 // index i = (img, m, pos) is mapped to the (possibly strided / two-part) destination like the kernel's own epilogue.
@@ -513,6 +540,16 @@ static void launch_cfg(int c, dim3 grid, hipStream_t st, const GemmP& p) {
     if constexpr (MODE == CONV_DGRAD) launch_cfg2<MODE, false>(c, grid, st, p);
     else if (p.avec) launch_cfg2<MODE, true>(c, grid, st, p);
     else launch_cfg2<MODE, false>(c, grid, st, p);
+}
+
+template <int MODE, bool AVEC>
+static void launch_group2(int c, unsigned nblocks, hipStream_t st, const GroupArgs& g) {
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_group_kernel<MODE, 2, 2, 2, 2, AVEC>), dim3(nblocks), dim3(256), 0, st, g); break;
+        case 5: hipLaunchKernelGGL((gemm_group_kernel<MODE, 2, 2, 2, 1, AVEC>), dim3(nblocks), dim3(256), 0, st, g); break;
+        case 6: hipLaunchKernelGGL((gemm_group_kernel<MODE, 2, 2, 1, 2, AVEC>), dim3(nblocks), dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_group_kernel<MODE, 2, 2, 1, 1, AVEC>), dim3(nblocks), dim3(256), 0, st, g); break;
+    }
 }
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -649,6 +686,73 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 
+// One launch for up to MAXG prepared problems of one mode (no split-K).  Tile shape: among 128x128 / 128x64 / 64x128 / 64x64
+// the one with the least padded work, small tiles and under-filled grids penalised.
+// measured on the B = 16 train step (img/s by threshold): 384: 291.7, 800: 294.1, 1600: 298.1, never group: 297.1 -- the members
+// launched singly use the tuned (tile, split-K) table, a group uses one generic tile shape and no split-K, so grouping only
+// pays where every member is wide (the 35x35 maps of Mixed_5b-d: 19600 columns)
+static int g_group_min_tiles = 1600;
+static int run_group(int mode, GemmP* ps, const int* nz, int n, hipStream_t st) {
+    static const int cand[4] = {0, 5, 6, 4};
+    int best = 4; double bestw = 1e300;
+    for (int ci = 0; ci < 4; ++ci) {
+        const int c = cand[ci];
+        const int bm = kCfgs[c].wm * kCfgs[c].tm * 32, bn = kCfgs[c].wn * kCfgs[c].tn * 32;
+        double w = 0; long long tiles = 0;
+        for (int i = 0; i < n; ++i) {
+            const long long t = cdiv(ps[i].M, bm) * cdiv(ps[i].N, bn) * nz[i];
+            tiles += t;
+            w += (double)t * bm * bn * (double)ps[i].K;
+        }
+        w *= (bm * bn >= 128 * 128) ? 1.0 : (bm * bn >= 128 * 64 ? 1.04 : 1.10);
+        if (tiles < 512) w *= 512.0 / (double)(tiles < 64 ? 64 : tiles);      // fewer than two blocks per CU
+        if (w < bestw) { bestw = w; best = c; }
+    }
+    if (g_force_cfg == 0 || g_force_cfg == 4 || g_force_cfg == 5 || g_force_cfg == 6) best = g_force_cfg;
+    const int bm = kCfgs[best].wm * kCfgs[best].tm * 32, bn = kCfgs[best].wn * kCfgs[best].tn * 32;
+    {
+        // a group that cannot fill the chip (the 8x8 maps of Mixed_7b/c: 1024 columns) is better served by its members one
+        // by one, each with split-K: return 1 = "launch them singly"
+        long long tiles = 0;
+        for (int i = 0; i < n; ++i) tiles += cdiv(ps[i].M, bm) * cdiv(ps[i].N, bn) * nz[i];
+        if (tiles < g_group_min_tiles && g_force_cfg < 0) return 1;
+    }
+    GroupArgs g{};
+    g.nprob = n;
+    long long end = 0; bool avec = true;
+    for (int i = 0; i < n; ++i) {
+        GemmP& p = ps[i];
+        p.kchunk = (int)cdiv(p.K, 32) * 32; p.nsplit = 1; p.slab = 0; p.ws = nullptr;
+        g.gx[i] = (int)cdiv(p.N, bn); g.gy[i] = (int)cdiv(p.M, bm);
+        end += (long long)g.gx[i] * g.gy[i] * nz[i];
+        g.tile_end[i] = (int)end;
+        avec = avec && p.avec;
+        g.p[i] = p;
+    }
+    if (end <= 0 || end > 0x7fffffff) return MOGAN_ERR_SHAPE;
+    const bool prof = g_prof_on;
+    ProfRec rec{};
+    if (prof) {                      // one record for the group: summed flops, geometry of the first problem
+        rec.mode = mode; rec.cfg = best; rec.M = ps[0].M; rec.N = ps[0].N; rec.K = ps[0].K; rec.nz = n; rec.nsplit = 1;
+        rec.Cin = ps[0].Cin; rec.Cout = ps[0].Cout; rec.H = ps[0].H; rec.W = ps[0].W; rec.KH = ps[0].KH; rec.KW = ps[0].KW;
+        rec.s = ps[0].s; rec.up = 0; rec.Bn = ps[0].Bn;
+        for (int i = 0; i < n; ++i) {
+            const double ncols = mode == CONV_DGRAD ? (double)ps[i].Bn * ps[i].H * ps[i].W : (double)ps[i].N * nz[i];
+            rec.flops += 2.0 * (double)ps[i].M * ncols * (double)ps[i].K;
+        }
+        hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
+        hipEventRecord(rec.e0, st);
+    }
+    if (mode == CONV_FWD) { if (avec) launch_group2<CONV_FWD, true>(best, (unsigned)end, st, g); else launch_group2<CONV_FWD, false>(best, (unsigned)end, st, g); }
+    else launch_group2<CONV_DGRAD, false>(best, (unsigned)end, st, g);
+    if (prof) {
+        hipEventRecord(rec.e1, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
 static int conv_geom(GemmP& p, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int s, int ph, int pw, int up) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Hs <= 0 || Ws <= 0 || KH <= 0 || KW <= 0 || s <= 0 || up < 0 || up > 1)
         return MOGAN_ERR_SHAPE;
@@ -714,6 +818,7 @@ int mogan_gemm_tune_clear(void) {
 }
 
 int mogan_gemm_debug_force(int cfg, int split) { g_force_cfg = cfg; g_force_split = split; return 0; }
+int mogan_gemm_group_min_tiles(int tiles) { if (tiles < 0) return MOGAN_ERR_SHAPE; g_group_min_tiles = tiles; return 0; }
 
 int mogan_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -843,6 +948,76 @@ int mogan_conv2d_affine_fwd_ex(const float* x, long long x_bstride, const float*
     p.xbs = (unsigned)x_bstride; p.ybs = y_bstride;
     if (two) { p.C2 = y2; p.ybs2 = y2_bstride; p.msplit = msplit; }
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
+}
+
+}  // extern "C"
+namespace {
+// GemmP of one strided / fused forward convolution (the arguments of mogan_conv2d_affine_fwd_ex); 0 or an error
+static int prep_fwd(GemmP& p, const MoganConvFwdArgs& a) {
+    int rc = conv_geom(p, a.B, a.Cin, a.Hs, a.Ws, a.Cout, a.KH, a.KW, a.stride, a.ph, a.pw, 0); if (rc) return rc;
+    if (!a.scale || !a.shift) return MOGAN_ERR_SHAPE;
+    const long long xd = (long long)a.Cin * a.Hs * a.Ws, yd = (long long)a.Cout * p.OH * p.OW;
+    const long long ybs = a.y_bstride < 0 ? yd : a.y_bstride;
+    if (a.x_bstride < xd || (long long)(a.B - 1) * a.x_bstride + xd >= (1ll << 30)) return MOGAN_ERR_SHAPE;
+    p.A = a.w; p.B = a.x; p.C = a.y; p.M = a.Cout; p.N = a.B * p.OH * p.OW; p.K = a.Cin * a.KH * a.KW; p.accumulate = 0;
+    p.a_bytes = 4u * a.Cout * a.Cin * a.KH * a.KW; p.b_bytes = 4u * (unsigned)((long long)(a.B - 1) * a.x_bstride + xd);
+    p.avec = (p.K % 4 == 0) && (((uintptr_t)a.w & 15) == 0);
+    p.ep_scale = a.scale; p.ep_shift = a.shift; p.ep_relu = a.relu;
+    dense_io(p, CONV_FWD);
+    p.xbs = (unsigned)a.x_bstride; p.ybs = ybs;
+    if (a.y2 != nullptr && a.msplit > 0 && a.msplit < a.Cout) { p.C2 = a.y2; p.ybs2 = a.y2_bstride; p.msplit = a.msplit; }
+    return 0;
+}
+static int prep_dgrad(GemmP& p, const MoganConvDgradArgs& a, int* nz) {
+    int rc = conv_geom(p, a.B, a.Cin, a.Hs, a.Ws, a.Cout, a.KH, a.KW, a.stride, a.ph, a.pw, 0); if (rc) return rc;
+    const long long yd = (long long)a.Cout * p.OH * p.OW, xd = (long long)a.Cin * a.Hs * a.Ws;
+    if (a.dy_bstride < yd || a.dx_bstride < xd || (long long)(a.B - 1) * a.dy_bstride + yd >= (1ll << 30)) return MOGAN_ERR_SHAPE;
+    if (a.stride > a.KH || a.stride > a.KW) return MOGAN_ERR_SHAPE;
+    p.A = a.w; p.B = a.dy; p.C = a.dx; p.M = a.Cin; p.K = a.Cout * p.nkh * p.nkw; p.accumulate = a.accumulate;
+    p.a_bytes = 4u * a.Cout * a.Cin * a.KH * a.KW; p.b_bytes = 4u * (unsigned)((long long)(a.B - 1) * a.dy_bstride + yd);
+    const int Hc = (p.H + a.stride - 1) / a.stride, Wc = (p.W + a.stride - 1) / a.stride;
+    p.N = a.B * Hc * Wc;
+    dense_io(p, CONV_DGRAD);
+    p.xbs = (unsigned)a.dy_bstride; p.ybs = a.dx_bstride; p.mask = a.relu_of; p.mbs = a.relu_bstride;
+    *nz = a.stride * a.stride;
+    return 0;
+}
+}  // namespace
+extern "C" {
+
+// n <= 4 independent forward convolutions (arguments as mogan_conv2d_affine_fwd_ex) in ONE launch, no split-K.  The outputs
+// must not overlap.  n == 1 falls back to the single-problem entry point (tile heuristics, split-K).
+int mogan_conv2d_affine_fwd_group(int n, const MoganConvFwdArgs* args, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (n <= 0 || n > MAXG || !args) return MOGAN_ERR_SHAPE;
+    if (n == 1) {
+        const MoganConvFwdArgs& a = args[0];
+        return mogan_conv2d_affine_fwd_ex(a.x, a.x_bstride, a.w, a.scale, a.shift, a.y, a.y_bstride, a.y2, a.y2_bstride, a.msplit,
+                                          a.B, a.Cin, a.Hs, a.Ws, a.Cout, a.KH, a.KW, a.stride, a.ph, a.pw, a.relu, ws, ws_bytes,
+                                          stream);
+    }
+    GemmP ps[MAXG]; int nz[MAXG];
+    for (int i = 0; i < n; ++i) { ps[i] = GemmP{}; int rc = prep_fwd(ps[i], args[i]); if (rc) return rc; nz[i] = 1; }
+    int rc = run_group(CONV_FWD, ps, nz, n, stream);
+    if (rc != 1) return rc;
+    for (int i = 0; i < n; ++i) { rc = mogan_conv2d_affine_fwd_group(1, args + i, ws, ws_bytes, stream); if (rc) return rc; }
+    return 0;
+}
+
+// n <= 4 independent data gradients (arguments as mogan_conv2d_dgrad_ex) in ONE launch.  Two problems of a group must not
+// write (or accumulate into) the same dx elements.
+int mogan_conv2d_dgrad_group(int n, const MoganConvDgradArgs* args, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (n <= 0 || n > MAXG || !args) return MOGAN_ERR_SHAPE;
+    if (n == 1) {
+        const MoganConvDgradArgs& a = args[0];
+        return mogan_conv2d_dgrad_ex(a.dy, a.dy_bstride, a.w, a.dx, a.dx_bstride, a.relu_of, a.relu_bstride, a.accumulate, a.B,
+                                     a.Cin, a.Hs, a.Ws, a.Cout, a.KH, a.KW, a.stride, a.ph, a.pw, ws, ws_bytes, stream);
+    }
+    GemmP ps[MAXG]; int nz[MAXG];
+    for (int i = 0; i < n; ++i) { ps[i] = GemmP{}; int rc = prep_dgrad(ps[i], args[i], &nz[i]); if (rc) return rc; }
+    int rc = run_group(CONV_DGRAD, ps, nz, n, stream);
+    if (rc != 1) return rc;
+    for (int i = 0; i < n; ++i) { rc = mogan_conv2d_dgrad_group(1, args + i, ws, ws_bytes, stream); if (rc) return rc; }
+    return 0;
 }
 
 int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,

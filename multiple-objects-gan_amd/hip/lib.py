@@ -21,6 +21,7 @@ SIGNATURES = {
     "mogan_gemm_set_split_target": [I],
     "mogan_stream_set_split_target": [P, I],
     "mogan_gemm_debug_force": [I, I],
+    "mogan_gemm_group_min_tiles": [I],
     "mogan_wino22_debug_min_tiles": [I],
     "mogan_gemm_tune_set": [I, I, I, I, I, I, I],
     "mogan_gemm_tune_clear": [],
@@ -76,6 +77,8 @@ SIGNATURES = {
     "mogan_adam_step": [P, P, P, P, P, L, F, F, F, F, I, P, I, F, F, P],
     "mogan_conv2d_affine_fwd_ex": [P, L, P, P, P, P, L, P, L, I] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_dgrad_ex": [P, L, P, P, L, P, L, I] + [I] * 10 + [P, Z, P],
+    "mogan_conv2d_affine_fwd_group": [I, P, P, Z, P],
+    "mogan_conv2d_dgrad_group": [I, P, P, Z, P],
     "mogan_maxpool_fwd_ex": [P, P, L, P, I, I, I, I, I, I, P],
     "mogan_maxpool_bwd_ex": [P, P, L, P, P, I, I, I, I, I, I, I, P],
     "mogan_avgpool_bwd_ex": [P, P, P, I, I, I, I, I, I, I, P],
@@ -92,6 +95,19 @@ SIGNATURES = {
     "mogan_scalar_sum": [P, P, I, P, P],
     "mogan_scalar_scale": [P, P, I, P, P],
 }
+
+
+class ConvFwdArgs(ctypes.Structure):            # MoganConvFwdArgs (include/mogan_hip.h)
+    _fields_ = [("x", P), ("x_bstride", L), ("w", P), ("scale", P), ("shift", P), ("y", P), ("y_bstride", L), ("y2", P),
+                ("y2_bstride", L), ("msplit", I)] + [(k, I) for k in ("B", "Cin", "Hs", "Ws", "Cout", "KH", "KW", "stride",
+                                                                      "ph", "pw", "relu")]
+
+
+class ConvDgradArgs(ctypes.Structure):          # MoganConvDgradArgs
+    _fields_ = [("dy", P), ("dy_bstride", L), ("w", P), ("dx", P), ("dx_bstride", L), ("relu_of", P), ("relu_bstride", L),
+                ("accumulate", I)] + [(k, I) for k in ("B", "Cin", "Hs", "Ws", "Cout", "KH", "KW", "stride", "ph", "pw")]
+
+
 _RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
@@ -119,6 +135,8 @@ def load():
             fn.restype = _RESTYPE.get(name, I)
         _lib = lib
         _register_tuned(lib)
+        if os.environ.get("MOGAN_GROUP_MIN_TILES"):
+            lib.mogan_gemm_group_min_tiles(int(os.environ["MOGAN_GROUP_MIN_TILES"]))
     return _lib
 
 

@@ -61,11 +61,13 @@ def make_device_batch(B, seed, device):
 
 
 def load_traffic():
-    """HBM bytes per launch per kernel family from the committed PMC pass (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch per kernel family from the newest committed PMC pass (profiles/r<NN>_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command); launch-weighted over the instantiations."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.isfile(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not found:
         return {}
+    path = found[-1]
     acc = {}
     for name, v in json.load(open(path))["kernels"].items():
         fam = name.split("<")[0]

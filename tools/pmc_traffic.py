@@ -22,6 +22,7 @@ KEEP = ("gemm_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel", "wino_fwd_kerne
 
 
 def short(name):
+    name = name.replace("gemm_group_kernel", "gemm_kernel")      # grouped launches of the same tile kernel
     m = re.search(r"(gemm_kernel|dconv_fwd_kernel|dconv_wgrad_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))

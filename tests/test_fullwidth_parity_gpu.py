@@ -271,10 +271,18 @@ def test_tuned_table_entries_match_the_heuristic_at_every_bench_shape():
     benchmark's layers.  For every GEMM-backed launch geometry of one full-width B = 16 step (eager, single stream, the
     Inception trunk launched eagerly so that its launches are seen) the result with the table registered must equal the
     result of the heuristic's choice: same products, only the K-split summation order differs (rel-L2 <= 1e-5)."""
+    from mogan_amd.attngan import inception
     from mogan_amd.hip import lib
     eng, bt = _bench_engine(16)
     eng.multi_stream, eng.graph_encoder = False, False
-    geos = _record_geometries(lambda: eng.step(dict(bt)))
+    # the frozen encoder module by module for the recording: its explicit forward/backward (inception.FrozenTrunk) goes to the
+    # same implicit-GEMM kernel with the same (M, N, K) keys for every convolution it does not group, through entry points
+    # this replay does not decode
+    fast, inception.FAST_TRUNK = inception.FAST_TRUNK, False
+    try:
+        geos = _record_geometries(lambda: eng.step(dict(bt)))
+    finally:
+        inception.FAST_TRUNK = fast
     del eng
     torch.cuda.empty_cache()
     assert len(geos) > 150, len(geos)

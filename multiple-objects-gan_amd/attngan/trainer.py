@@ -577,6 +577,9 @@ class TrainEngine:
             with torch.cuda.graph(self._graph):
                 # the generator's weight gradients may fork their side stream from the capture stream (a depth-1 fork);
                 # the D branches keep theirs in line: a fork of a fork crashes hipStreamEndCapture (ROCm 7.2)
+                # (round 2: forking every branch AND weight-gradient stream from the capture stream itself before any work --
+                # so that the later branch -> wgrad waits are only extra edges, not forks of forks -- segfaults in
+                # hipStreamEndCapture just the same)
                 ops.CAPTURE_WGRAD_OK.add(torch.cuda.current_stream().cuda_stream)
                 ops.precreate_wgrad_stream(torch.cuda.current_stream())
                 self._graph_out = self.device_step(st)

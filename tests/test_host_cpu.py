@@ -195,3 +195,33 @@ def test_hw_queue_configuration_respects_the_user(monkeypatch):
     monkeypatch.setenv("MOGAN_RESERVED_STREAMS", "0")
     lib.reserve_hw_queues()
     assert lib._reserved == []
+
+
+def test_flat_adam_state_dict_is_torch_adam_layout_and_roundtrips():
+    """--resume must bring back the Adam moments and step counters; checkpoints carry torch.optim.Adam's own
+    state_dict layout (what the reference saves as optimG / optimD, trainer.py:188-196), and both that layout -- e.g. from a
+    real torch.optim.Adam -- and the round-1 flat layout load."""
+    import torch.nn as nn
+    from mogan_amd.attngan.trainer import FlatAdam
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(5, 4), nn.Tanh(), nn.Linear(4, 3))
+    ref = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    for _ in range(3):
+        ref.zero_grad()
+        net(torch.randn(6, 5)).pow(2).sum().backward()
+        ref.step()
+    want = ref.state_dict()
+    flat = FlatAdam(net, lr=1e-3)
+    flat.load_state_dict(want)                                   # torch layout in
+    assert float(flat.state[0]) == 3.0 and flat.lr == 2e-4
+    for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
+        torch.testing.assert_close(flat.m[o:o + p.numel()].view_as(p), want["state"][i]["exp_avg"])
+        torch.testing.assert_close(flat.v[o:o + p.numel()].view_as(p), want["state"][i]["exp_avg_sq"])
+    got = flat.state_dict()                                      # torch layout out
+    assert set(got) == {"state", "param_groups"} and got["param_groups"][0]["betas"] == (0.5, 0.999)
+    ref2 = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    ref2.load_state_dict(got)                                    # ... which a real torch optimizer accepts
+    assert float(ref2.state_dict()["state"][0]["step"]) == 3.0
+    flat2 = FlatAdam(net, lr=2e-4)
+    flat2.load_state_dict({"step": 3.0, "exp_avg": flat.m.clone(), "exp_avg_sq": flat.v.clone(), "lr": 2e-4})   # round-1 layout
+    assert torch.equal(flat2.m, flat.m) and float(flat2.state[0]) == 3.0

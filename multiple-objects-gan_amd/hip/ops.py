@@ -14,7 +14,7 @@ from .lib import call, ptr, stream_ptr, workspace
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GLU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 
-# Test hook: when set to a list, every (Leaky)ReLU launch appends its OUTPUT tensor.  A gradient check against a CPU
+# Test hook: when set to a list, every (Leaky)ReLU launch appends (activation code, its OUTPUT tensor).  A gradient check against a CPU
 # reference can then hand the reference the same sign decisions: with millions of pre-activations per layer a few land
 # within fp32 noise of the kink, and one flipped decision moves the weight gradients below it by ~1e-3 (tests/
 # test_fullwidth_parity_gpu.py).  None (the default) costs one global lookup per launch.
@@ -435,7 +435,7 @@ class BNActFn(torch.autograd.Function):
         call("mogan_bn_act_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(res), ptr(y),
              B, C, HW, act, slope, stream_ptr())
         if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
-            ACT_TRACE.append(y)
+            ACT_TRACE.append((act, y))
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (act, slope, residual is not None)
         return y
@@ -509,7 +509,7 @@ class ActFn(torch.autograd.Function):
         y = torch.empty((B, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         call("mogan_act_fwd", ptr(x), ptr(y), B, C, HW, act, slope, stream_ptr())
         if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
-            ACT_TRACE.append(y)
+            ACT_TRACE.append((act, y))
         ctx.save_for_backward(x)
         ctx.cfg = (act, slope)
         return y

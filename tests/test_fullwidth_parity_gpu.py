@@ -140,7 +140,7 @@ def test_full_width_gnet_forward_and_dnet256_loss_backward():
                    [("att%d" % (64 << i), atts[i], oatts[i]) for i in range(2)]:
         rep[k] = max_abs(a, b)
         assert rep[k] <= 1e-4, "%s differs from the fp64 oracle by %.3e" % (k, rep[k])
-    O.LRELU_MASKS = [(t > 0).cpu() for t in trace]
+    O.LRELU_MASKS = [(t > 0).cpu() for a, t in trace if a == ops.ACT_LRELU]
     try:
         # the same fake image as the HIP pass (so that the decisions belong to the same function)
         oerr = O.discriminator_loss(2, od, c64["imgs"][2], imgs[2].detach().cpu().to(dt), c64["sent_emb"], c64, ocfg)

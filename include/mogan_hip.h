@@ -131,6 +131,13 @@ int mogan_conv2d_affine_fwd_ex(const float* x, long long x_bstride, const float*
                                float* y, long long y_bstride, float* y2, long long y2_bstride, int msplit, int B, int Cin,
                                int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int relu, void* ws,
                                size_t ws_bytes, hipStream_t stream);
+/* Plain forward convolution with channel-slice addressing, a ReLU mask on the result (relu_of: shaped like y, nullable) and
+ * accumulation into y.  Used as the data gradient of the frozen trunk's stride-1 convolutions: dX = conv(dY, flipped and
+ * (ci,co)-transposed filters, pad K-1-pad) reads the filter operand K-contiguously (the data-gradient mode gathers it with a
+ * stride of KH*KW floats). */
+int mogan_conv2d_fwd_ex(const float* x, long long x_bstride, const float* w, float* y, long long y_bstride,
+                        const float* relu_of, long long relu_bstride, int accumulate, int B, int Cin, int Hs, int Ws,
+                        int Cout, int KH, int KW, int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream);
 /* Data gradient with channel-slice addressing and a fused ReLU backward: dy is a slice with batch stride dy_bstride, the
  * result is written (accumulate 0) or added (1) to the slice dx (batch stride dx_bstride); where relu_of[...] <= 0 (a
  * slice shaped like dx with batch stride relu_bstride; nullable) the new contribution is zeroed first. */

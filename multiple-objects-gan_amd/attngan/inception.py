@@ -258,6 +258,9 @@ class _Slice:
         return self.c0 == 0 and self.C == self.t.shape[1] and self.t.is_contiguous()
 
 
+FLIPPED_DGRAD = os.environ.get("MOGAN_INCEPTION_FLIPPED_DGRAD", "1") != "0"
+
+
 class _FrozenConv:
     """one BasicConv2d (or a group of same-input 1x1 ones) with eval-mode BN folded: forward (w, scale, shift), backward w * scale"""
 
@@ -273,6 +276,11 @@ class _FrozenConv:
             self.scale = torch.cat([f[0] for f in folded]).contiguous()
             self.shift = torch.cat([f[1] for f in folded]).contiguous()
             self.wb = (self.w * self.scale.view(-1, 1, 1, 1)).contiguous()
+            # stride-1 convolutions with a spatial extent: the data gradient runs as a FORWARD convolution of dY with the
+            # flipped, (ci, co)-transposed filters (K-contiguous filter operand instead of a stride-KH*KW gather)
+            self.wflip = None
+            if FLIPPED_DGRAD and self.stride == 1 and self.k != (1, 1):
+                self.wflip = self.wb.flip(2, 3).transpose(0, 1).contiguous()
         self.cout, self.cin = self.w.shape[0], self.w.shape[1]
 
     def out_hw(self, H, W):
@@ -413,6 +421,11 @@ class _Tape:
                      fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 0, wsp, wsn, stream_ptr())
                 if op.relu_in:
                     call("mogan_relu_bwd", x.t.data_ptr(), dx.ptr, dx.ptr, x.t.numel(), 0, stream_ptr())
+                continue
+            if fc.wflip is not None:
+                call("mogan_conv2d_fwd_ex", dy.ptr, dy.bstride, fc.wflip.data_ptr(), dx.ptr, dx.bstride,
+                     x.ptr if op.relu_in else None, x.bstride, 1 if acc else 0, self.B, fc.cout, y.H, y.W, fc.cin, fc.k[0],
+                     fc.k[1], 1, fc.k[0] - 1 - fc.pad[0], fc.k[1] - 1 - fc.pad[1], wsp, wsn, stream_ptr())
                 continue
             group.append(ConvDgradArgs(dy.ptr, dy.bstride, fc.wb.data_ptr(), dx.ptr, dx.bstride,
                                        x.ptr if op.relu_in else None, x.bstride, 1 if acc else 0, self.B, fc.cin, x.H, x.W,

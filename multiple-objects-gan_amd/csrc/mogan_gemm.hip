@@ -399,6 +399,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
             const int img = nn / OHW, pix = nn - img * OHW;
             cms = OHW;
             cden = (size_t)img * p.M * OHW + pix; cstr = (size_t)img * p.ybs + pix; cstr2 = (size_t)img * p.ybs2 + pix;
+            mb = (size_t)img * p.mbs + pix;
         } else if constexpr (MODE == CONV_DGRAD) {
             nok = n < Ncls;
             const int nn = nok ? n : 0;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
                     if constexpr (MODE == CONV_FWD) {
                         if (m >= p.msplit) dst = p.C2 + cstr2 + (size_t)(m - p.msplit) * cms;
                     }
-                    if constexpr (MODE == CONV_DGRAD) {
+                    if constexpr (MODE == CONV_DGRAD || MODE == CONV_FWD) {
                         if (p.mask != nullptr && !(p.mask[mb + (size_t)m * cms] > 0.f)) v = 0.f;
                     }
                     if (addc) v += *dst;
@@ -678,7 +679,7 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
         if (mode == CONV_FWD || mode == CONV_DGRAD) {
             q.cms = mode == CONV_FWD ? (long long)p.OH * p.OW : (long long)p.H * p.W;
             q.Mcms = (long long)p.M * q.cms; q.ybs = p.ybs; q.msplit = p.msplit; q.out2 = p.C2; q.ybs2 = p.ybs2;
-            q.mask = mode == CONV_DGRAD ? p.mask : nullptr; q.mbs = p.mbs;
+            q.mask = p.mask; q.mbs = p.mbs;
             if (mode == CONV_FWD) { q.ep_scale = p.ep_scale; q.ep_shift = p.ep_shift; q.ep_relu = p.ep_relu; }
         }
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)ws, p.C, q);
@@ -947,6 +948,26 @@ int mogan_conv2d_affine_fwd_ex(const float* x, long long x_bstride, const float*
     dense_io(p, CONV_FWD);
     p.xbs = (unsigned)x_bstride; p.ybs = y_bstride;
     if (two) { p.C2 = y2; p.ybs2 = y2_bstride; p.msplit = msplit; }
+    return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
+}
+
+// Plain forward convolution with channel-slice addressing, a ReLU mask on the result and accumulation: the data
+// gradient of a STRIDE-1 convolution evaluated as the forward convolution of dY with the spatially flipped, (ci, co)
+// transposed filters (pad' = K - 1 - pad).  In the implicit GEMM's forward mode the filter operand is K-contiguous
+// (16-byte coalesced loads); its data-gradient mode has to gather W[co][ci][tap] with a stride of KH*KW floats between
+// consecutive rows.  For FROZEN weights the flipped copy is made once (attngan/inception.py).
+int mogan_conv2d_fwd_ex(const float* x, long long x_bstride, const float* w, float* y, long long y_bstride,
+                        const float* relu_of, long long relu_bstride, int accumulate, int B, int Cin, int Hs, int Ws,
+                        int Cout, int KH, int KW, int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
+    GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0); if (rc) return rc;
+    const long long xd = (long long)Cin * Hs * Ws, yd = (long long)Cout * p.OH * p.OW;
+    if (y_bstride < 0) y_bstride = yd;
+    if (x_bstride < xd || y_bstride < yd || (long long)(B - 1) * x_bstride + xd >= (1ll << 30)) return MOGAN_ERR_SHAPE;
+    p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = accumulate;
+    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * (unsigned)((long long)(B - 1) * x_bstride + xd);
+    p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    dense_io(p, CONV_FWD);
+    p.xbs = (unsigned)x_bstride; p.ybs = y_bstride; p.mask = relu_of; p.mbs = relu_bstride;
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
 }
 

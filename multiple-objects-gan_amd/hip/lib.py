@@ -76,6 +76,7 @@ SIGNATURES = {
     "mogan_bilinear_bwd": [P, P, I, I, I, I, I, P],
     "mogan_adam_step": [P, P, P, P, P, L, F, F, F, F, I, P, I, F, F, P],
     "mogan_conv2d_affine_fwd_ex": [P, L, P, P, P, P, L, P, L, I] + [I] * 11 + [P, Z, P],
+    "mogan_conv2d_fwd_ex": [P, L, P, P, L, P, L, I] + [I] * 10 + [P, Z, P],
     "mogan_conv2d_dgrad_ex": [P, L, P, P, L, P, L, I] + [I] * 10 + [P, Z, P],
     "mogan_conv2d_affine_fwd_group": [I, P, P, Z, P],
     "mogan_conv2d_dgrad_group": [I, P, P, Z, P],

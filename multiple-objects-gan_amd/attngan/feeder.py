@@ -135,6 +135,8 @@ class DeviceFeeder:
         self.turn = (self.turn + 1) % len(self.slots)
         B = u8_batch.shape[0]
         assert B <= self.B and tuple(u8_batch.shape[1:]) == (self.ori, self.ori, 3) and u8_batch.dtype == torch.uint8
+        if slot.get("pending"):                         # uploaded but never processed: its copy may still be in flight
+            slot["ready"].synchronize()
         slot["free"].synchronize()                      # the kernels that last read this slot's device buffers are done
         slot["pin"][:B].copy_(u8_batch)
         slot["pin_par"][:B].copy_(torch.as_tensor(params, dtype=torch.int32).reshape(B, 3))
@@ -142,7 +144,7 @@ class DeviceFeeder:
             slot["dev"][:B].copy_(slot["pin"][:B], non_blocking=True)
             slot["par"][:B].copy_(slot["pin_par"][:B], non_blocking=True)
             slot["ready"].record()
-        slot["n"] = B
+        slot["n"], slot["pending"] = B, True
         return slot
 
     def process(self, slot):
@@ -158,6 +160,7 @@ class DeviceFeeder:
             call("mogan_feed_resample", slot["q"].data_ptr(), slot["tmp"].data_ptr(), outs[i].data_ptr(), bounds.data_ptr(),
                  kk.data_ptr(), ksize, B, self.S, s, sp())
         slot["free"].record()
+        slot["pending"] = False
         return outs
 
     def __call__(self, u8_batch, params):

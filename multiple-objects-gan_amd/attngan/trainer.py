@@ -247,6 +247,11 @@ class TrainEngine:
         self._enc_graphs = {}
         self.multi_stream = os.environ.get("MOGAN_STREAMS", "1") != "0"
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
+        bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
+        if bmap:
+            ids = [int(v) for v in bmap.split(",")]
+            pool = {k: torch.cuda.Stream() for k in sorted(set(ids))}
+            self.side = [pool[k] for k in ids]
         # stream creation order fixes the stream -> hardware-queue map (see ops.precreate_wgrad_stream): branch streams,
         # then the weight-gradient streams in the order the branches run (D256, D128, D64, generator), communication
         # streams last -- measured: with the communication streams created in between, the generator's wgrad stream landed

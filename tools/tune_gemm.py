@@ -47,7 +47,7 @@ for k, (cnt, cfg0, ns0, gM, gN, gK, gnz) in shapes.items():
     base = t(fn)
     best = (base, int(cfg0), int(ns0))
     for c in range(7):
-        for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48):
+        for sp in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 32, 48):
             L.mogan_gemm_debug_force(c, sp)
             try:
                 v = t(fn, 4)

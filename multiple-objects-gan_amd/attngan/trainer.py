@@ -325,7 +325,8 @@ class TrainEngine:
             t = os.environ.get("MOGAN_ENC_SPLIT_TARGET")
             if t:
                 lib.call("mogan_stream_set_split_target", lib.stream_ptr(), int(t))
-            g = torch.cuda.make_graphed_callables(lambda x: enc(x), (sample,))
+            with lib.capture_guard():
+                g = torch.cuda.make_graphed_callables(lambda x: enc(x), (sample,))
             self._enc_graphs[key] = g
         return g
 
@@ -579,7 +580,8 @@ class TrainEngine:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            from ..hip import lib as _lib
+            with _lib.capture_guard(), torch.cuda.graph(self._graph):
                 # the generator's weight gradients may fork their side stream from the capture stream (a depth-1 fork);
                 # the D branches keep theirs in line: a fork of a fork crashes hipStreamEndCapture (ROCm 7.2)
                 # (round 2: forking every branch AND weight-gradient stream from the capture stream itself before any work --

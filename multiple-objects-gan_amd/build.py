@@ -13,6 +13,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 
 
+EXTRA = os.environ.get("MOGAN_CFLAGS", "").split()       # e.g. -DMOGAN_X6=0: the native fp32-MFMA form of every kernel
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -29,12 +32,13 @@ def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     srcs = sources()
+    hdrs = [hdr] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
 
     def cc(pair):
         src, obj = pair
-        if force or _stale(obj, [src, hdr]):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + EXTRA + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

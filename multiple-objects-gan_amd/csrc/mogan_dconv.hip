@@ -21,6 +21,7 @@
 #include <algorithm>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
+#include "mogan_mma.h"
 
 namespace {
 
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     constexpr int NWQ = (BM * (KC / 4) + 255) / 256;              // weight quads per thread
     constexpr int NBUF = DB ? 2 : 1, XSZ = CK * CPL, WSZ = BM * LDW;
     constexpr int NSTEP = (CK / 2) * KHW, FIRST = NSTEP / 2;      // stores of the next chunk ride on steps >= FIRST
-    constexpr int XPS = (NXE + (NSTEP - FIRST) - 1) / (NSTEP - FIRST), WPS = (NWQ + (NSTEP - FIRST) - 1) / (NSTEP - FIRST);
+    constexpr int NGRP = (NSTEP + 7) / 8, GFIRST = NGRP / 2;       // groups of 8 k-steps; stores of the next chunk ride on groups >= GFIRST
+    constexpr int XPG = (NXE + (NGRP - GFIRST) - 1) / (NGRP - GFIRST), WPG = (NWQ + (NGRP - GFIRST) - 1) / (NGRP - GFIRST);
     static_assert(WM * WN == 4 && KC % 4 == 0 && CK % 2 == 0 && PX == 128, "tile");
     __shared__ __attribute__((aligned(16))) float Xs[NBUF * XSZ];
     __shared__ __attribute__((aligned(16))) float Wl[NBUF * WSZ];
@@ -208,50 +210,48 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
             const float* Wc = Wl + cur * WSZ;
             float* Xn = Xs + (cur ^ (NBUF - 1)) * XSZ;
             float* Wn = Wl + (cur ^ (NBUF - 1)) * WSZ;
+            // k-steps (channel pair c2, tap kh, kw) in groups of eight = one mma_k16 (mogan_mma.h); a short last group is
+            // padded with zeros
 #pragma unroll
-            for (int c2 = 0; c2 < CK / 2; ++c2) {
+            for (int g = 0; g < NGRP; ++g) {
+                float a[TM][8], b[TN][8];
 #pragma unroll
-                for (int kh = 0; kh < KH; ++kh) {
+                for (int i = 0; i < 8; ++i) {
+                    const int step = 8 * g + i;                             // compile-time after unrolling
+                    const int c2 = step / KHW, tap = step % KHW, kh = tap / KW, kw = tap % KW;
 #pragma unroll
-                    for (int kw = 0; kw < KW; ++kw) {
-                        float a[TM], b[TN];
+                    for (int t = 0; t < TM; ++t) a[t][i] = step < NSTEP ? Wc[abase + t * 32 * LDW + 2 * c2 * KHW + kh * KW + kw] : 0.f;
 #pragma unroll
-                        for (int t = 0; t < TM; ++t) a[t] = Wc[abase + t * 32 * LDW + 2 * c2 * KHW + kh * KW + kw];
+                    for (int t = 0; t < TN; ++t)
+                        b[t][i] = step < NSTEP
+                            ? Xc[bbase[t] + 2 * c2 * CPL + kh * WWP + (S == 2 ? (kw & 1) * (WWP / 2) + (kw >> 1) : kw)] : 0.f;
+                }
+                mma_k16<TM, TN>(a, b, acc);
+                if constexpr (DB) {
+                    if (g >= GFIRST && more) {
+                        const int s0 = g - GFIRST;
 #pragma unroll
-                        for (int t = 0; t < TN; ++t)
-                            b[t] = Xc[bbase[t] + 2 * c2 * CPL + kh * WWP + (S == 2 ? (kw & 1) * (WWP / 2) + (kw >> 1) : kw)];
+                        for (int j = 0; j < XPG; ++j)
+                            if (s0 * XPG + j < NXE) store_x(s0 * XPG + j, Xn);
 #pragma unroll
-                        for (int ta = 0; ta < TM; ++ta)
-#pragma unroll
-                            for (int tb = 0; tb < TN; ++tb)
-                                acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
-                        if constexpr (DB) {
-                            constexpr int dummy = 0; (void)dummy;
-                            const int step = (c2 * KH + kh) * KW + kw;       // compile-time after unrolling
-                            if (step >= FIRST && more) {
-                                const int s0 = step - FIRST;
-#pragma unroll
-                                for (int j = 0; j < XPS; ++j)
-                                    if (s0 * XPS + j < NXE) store_x(s0 * XPS + j, Xn);
-#pragma unroll
-                                for (int j = 0; j < WPS; ++j)
-                                    if (s0 * WPS + j < NWQ) store_w(s0 * WPS + j, Wn);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                        for (int j = 0; j < WPG; ++j)
+                            if (s0 * WPG + j < NWQ) store_w(s0 * WPG + j, Wn);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if constexpr (!DB) {
                 // issue-order template (see dconv_wgrad_kernel): one global load of the next chunk behind each of the
                 // first k-steps instead of a load phase in front of the MFMA loop.  +2..4 % over the double-buffered
                 // variant on the 3x3 / 2x2 / 4x4-s2 layers (e.g. dgrad 96->192 at 128x128: 134 vs 129 TFLOP/s).
+#if !MOGAN_X6
 #pragma unroll
                 for (int g = 0; g < NSTEP; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
                     if (g < (WIDE ? NXQ : NXE) + NWQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
+#endif
             }
             __syncthreads();
             if constexpr (DB) {
@@ -321,8 +321,9 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
     constexpr bool PIPE = (S == 2);
     constexpr int NBUF = DBW ? 2 : 1, YSZ = BM * LDY, XSZ = CKW * CPLW;
     constexpr int NSTEP = PXK / 2, FIRST = NSTEP / 2;
-    constexpr int XPS = (NXE + (NSTEP - FIRST) - 1) / (NSTEP - FIRST), YPS = (NYQ + (NSTEP - FIRST) - 1) / (NSTEP - FIRST);
-    static_assert(WM * WN == 4 && BN == 128, "tile");
+    constexpr int NGRP = NSTEP / 8, GFIRST = NGRP / 2;                     // groups of 8 k-steps (one mma_k16 each)
+    constexpr int XPG = (NXE + (NGRP - GFIRST) - 1) / (NGRP - GFIRST), YPG = (NYQ + (NGRP - GFIRST) - 1) / (NGRP - GFIRST);
+    static_assert(WM * WN == 4 && BN == 128 && NSTEP % 8 == 0, "tile");
     __shared__ __attribute__((aligned(16))) float Ys[NBUF * YSZ];
     __shared__ __attribute__((aligned(16))) float Xs[NBUF * XSZ];
 
@@ -463,32 +464,29 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
             float* Xn = Xs + (cur ^ (NBUF - 1)) * XSZ;
             float* Yn = Ys + (cur ^ (NBUF - 1)) * YSZ;
 #pragma unroll
-            for (int pp = 0; pp < PXK / 2; ++pp) {
-                constexpr int dummy = 0; (void)dummy;
-                const int ry = (2 * pp) / CW, rxx = (2 * pp) % CW;
-                float a[TM], b[TN];
+            for (int g = 0; g < NSTEP / 8; ++g) {
+                float a[TM][8], b[TN][8];
 #pragma unroll
-                for (int q = 0; q < TM; ++q) a[q] = Yc[abase + q * 32 * LDY + 2 * pp];
+                for (int i = 0; i < 8; ++i) {
+                    const int pp = 8 * g + i;                               // pixel pair: compile-time after unrolling
+                    const int ry = (2 * pp) / CW, rxx = (2 * pp) % CW;
 #pragma unroll
-                for (int q = 0; q < TN; ++q) b[q] = Xc[bbase[q] + ry * S * WWP + rxx * S];
+                    for (int q = 0; q < TM; ++q) a[q][i] = Yc[abase + q * 32 * LDY + 2 * pp];
 #pragma unroll
-                for (int ta = 0; ta < TM; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < TN; ++tb)
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                    for (int q = 0; q < TN; ++q) b[q][i] = Xc[bbase[q] + ry * S * WWP + rxx * S];
+                }
+                mma_k16<TM, TN>(a, b, acc);
                 if constexpr (DBW) {
-                    if (pp >= FIRST && more) {
-                        const int s0 = pp - FIRST;
+                    if (g >= GFIRST && more) {
+                        const int s0 = g - GFIRST;
 #pragma unroll
-                        for (int j = 0; j < XPS; ++j)
-                            if (s0 * XPS + j < NXE) store_x(s0 * XPS + j, Xn);
+                        for (int j = 0; j < XPG; ++j)
+                            if (s0 * XPG + j < NXE) store_x(s0 * XPG + j, Xn);
 #pragma unroll
-                        for (int j = 0; j < YPS; ++j)
-                            if (s0 * YPS + j < NYQ) store_y(s0 * YPS + j, Yn);
+                        for (int j = 0; j < YPG; ++j)
+                            if (s0 * YPG + j < NYQ) store_y(s0 * YPG + j, Yn);
                     }
-#if !defined(LAB) || LAB != 5
                     __builtin_amdgcn_sched_barrier(0);
-#endif
                 }
             }
             if constexpr (PIPE) {
@@ -496,12 +494,14 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
                 // NXE+NYQ global loads of the next tile behind each of the first k-steps (instead of all of them in
                 // front of the MFMA loop, where both blocks of a CU sit in their load phase at the same time).
                 // Measured on the 4x4 s2 layers: 83 -> 97 TFLOP/s; no gain on the 3x3 variant (fewer halo loads).
+#if !MOGAN_X6
 #pragma unroll
                 for (int g = 0; g < PXK / 2; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
                     if (g < NXE + NYQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
+#endif
             }
 #if defined(LAB) && LAB == 4
             // lab: no store phase, no barriers (stale LDS)

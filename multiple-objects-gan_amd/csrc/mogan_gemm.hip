@@ -32,6 +32,7 @@
 #include <vector>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
+#include "mogan_mma.h"
 
 namespace {
 
@@ -201,7 +202,10 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
 
     float ra[QA][4], rb[QB][4];
     constexpr int NEA = QA * 4, NEB = QB * 4, NE = NEA + NEB;     // elements staged per thread per K-tile
-    constexpr int NSL = 16;                                       // slices: the first NSL of the 16 k-steps carry
+#ifndef MOGAN_NSL
+#define MOGAN_NSL (MOGAN_X6 ? 12 : 16)
+#endif
+    constexpr int NSL = MOGAN_NSL;                                // slices: the first NSL of the 16 k-steps carry
     constexpr int EPS = (NE + NSL - 1) / NSL;                     // the gather, the rest cover the load latency
 
     // per-quad / per-tile decode kept in registers between the element slices
@@ -361,6 +365,41 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
             for (int q = 0; q < TN; ++q)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) bf[q][v] = *(const float4*)&Bs[cur][brow + q * 32 * LD + 4 * v];
+#if MOGAN_X6
+            // fp32 product from three bf16 pieces per operand (x = x1 + x2 + x3 exactly, 8 significant bits each) and the
+            // six partial products above 2^-24: v_mfma_f32_32x32x16_bf16 runs at 16x the fp32-MFMA rate, so 12 of them
+            // replace 16 v_mfma_f32_32x32x2_f32 at 3/8 of the matrix-pipe time.  k assignment: step s uses the lane's
+            // k = 16h + 8s .. +8 (the same 16 values the fp32 form walks through one at a time).
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                X6Frag a3[TM], b3[TN];
+#pragma unroll
+                for (int q = 0; q < TM; ++q) {
+                    const float4 lo = af[q][2 * s2], hi = af[q][2 * s2 + 1];
+                    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    a3[q] = x6_split8(x);
+                }
+#pragma unroll
+                for (int q = 0; q < TN; ++q) {
+                    const float4 lo = bf[q][2 * s2], hi = bf[q][2 * s2 + 1];
+                    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    b3[q] = x6_split8(x);
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+#pragma unroll
+                    for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < TN; ++tb) acc[ta][tb] = x6_mfma(a3[ta], b3[tb], term, acc[ta][tb]);
+                    const int sl = s2 * 6 + term;
+#pragma unroll
+                    for (int x = 0; x < EPS; ++x)
+                        if (sl * EPS + x < NE) stage_elem(sl * EPS + x, kt + BK, cur ^ 1);
+                    if (sl == 11) decode_k(kt + 2 * BK, cur);
+                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int s16 = 0; s16 < 16; ++s16) {
                 const int v = s16 >> 2, c = s16 & 3;
@@ -379,6 +418,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
                 if (s16 == 15) decode_k(kt + 2 * BK, cur);       // table `cur` was last read while staging tile t
                 if (SCHED) __builtin_amdgcn_sched_barrier(0);    // (a sched_group_barrier template instead: no gain, lab 8)
             }
+#endif
             store_tile(cur ^ 1);                                 // buffer cur^1 was last read in iteration t-1
             __syncthreads();
         }

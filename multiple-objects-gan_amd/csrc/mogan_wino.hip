@@ -16,6 +16,7 @@
 #include <algorithm>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
+#include "mogan_mma.h"
 
 namespace {
 
@@ -204,6 +205,61 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
         __syncthreads();
     };
 
+#if MOGAN_X6
+    // Split-bf16 form (mogan_mma.h): one v_mfma_f32_32x32x16_bf16 takes 8 k-values per lane, a chunk supplies 4 (8 input
+    // channels over the two lane halves), so the MFMAs of a chunk PAIR are issued in its second (odd) step: the lane's
+    // operand is [even chunk kk = 0..3, odd chunk kk = 0..3] for A and B alike.  The even step keeps its B values and
+    // does only the staging work.
+    float bve[2][CK / 2];
+    auto step_even = [&](int c, f32x4 (&an)[6]) {
+        const float* Vc = Vs;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) bve[j][kk] = Vc[((wave * 2 + j) * CK + 2 * kk + h) * NT + l31];
+        load_a(an, ubase, c + 1);
+        store_x(rx, Xs, 2 * XSZ);
+        load_x(rx, xg, (c + 3) * CK);
+        transform(Xs + XSZ, Vs + VSZ);
+        __syncthreads();
+    };
+    auto step_odd = [&](int c, f32x4 (&ae)[6], const f32x4 (&ao)[6]) {
+        const float* Vc = Vs + VSZ;
+        // position j = 0: split + MFMAs, then j = 1 (12 fragment registers x 4 live at a time instead of x 8)
+        auto do_j = [&](int j) {
+            X6Frag fa[3], fb;
+            float b8[8];
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+                b8[kk] = bve[j][kk];
+                b8[4 + kk] = Vc[((wave * 2 + j) * CK + 2 * kk + h) * NT + l31];
+            }
+            fb = x6_split8(b8);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float a8[8];
+#pragma unroll
+                for (int kk = 0; kk < CK / 2; ++kk) {
+                    const int v = (j * 4 + kk) * 3 + a;
+                    a8[kk] = ae[v >> 2][v & 3]; a8[4 + kk] = ao[v >> 2][v & 3];
+                }
+                fa[a] = x6_split8(a8);
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[j][a] = x6_mfma(fa[a], fb, term, acc[j][a]);
+        };
+        do_j(0);
+        store_x(rx, Xs + XSZ, XSZ);
+        load_x(rx, xg, (c + 3) * CK);
+        do_j(1);
+        load_a(ae, ubase, c + 1);
+        transform(Xs, Vs);
+        __syncthreads();
+    };
+#endif
+
     // Persistent blocks (one per CU): the first loads of the NEXT tile (X chunks 0 and 1, the weights of chunk 0) are issued
     // before the epilogue of the current one, so no tile but the first waits for global memory before its first MFMA, and
     // there is no block launch gap between tiles.
@@ -227,8 +283,13 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
         transform(Xs, Vs);
         __syncthreads();
         for (int c = 0; c < nchunk; c += 2) {                   // nchunk is even (host)
+#if MOGAN_X6
+            step_even(c, a1);
+            step_odd(c + 1, a0, a1);
+#else
             step(c, 0, a0, a1);
             step(c + 1, 1, a1, a0);
+#endif
         }
         const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
         if (tile + (int)gridDim.x < ntile) {
@@ -428,6 +489,66 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const float* __restrict
         store_x(Xs + XSZ, XSZ);
         load_x(k_beg + 2);
         __syncthreads();
+#if MOGAN_X6
+        // split-bf16 form: the MFMAs of a chunk pair are issued in its second iteration (8 k-values per lane = 4 of the even
+        // + 4 of the odd chunk); chunks past k_end are staged as zeros, so an unpaired last chunk is simply paired with zeros
+        float ave[2][WCT / 2][3], bve[2][WCT / 2];
+        for (int k = k_beg; k < k_end; k += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int cur = par, nxt = cur ^ 1, kc = k + par;
+                const float* Qc = Qs + cur * QSZ;
+                const float* Vc = Vs + cur * VSZ;
+                float av[2][WCT / 2][3], bv[2][WCT / 2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < WCT / 2; ++kk) {
+                        const int row = (wave * 2 + j) * WCT + 2 * kk + h;
+                        bv[j][kk] = Vc[row * WBN + l31];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) av[j][kk][a] = Qc[row * LDQ + a * 32 + l31];
+                    }
+                auto do_j = [&](int j) {
+                    X6Frag fa[3], fb;
+                    float b8[8];
+#pragma unroll
+                    for (int kk = 0; kk < WCT / 2; ++kk) { b8[kk] = bve[j][kk]; b8[4 + kk] = bv[j][kk]; }
+                    fb = x6_split8(b8);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float a8[8];
+#pragma unroll
+                        for (int kk = 0; kk < WCT / 2; ++kk) { a8[kk] = ave[j][kk][a]; a8[4 + kk] = av[j][kk][a]; }
+                        fa[a] = x6_split8(a8);
+                    }
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) acc[j][a] = x6_mfma(fa[a], fb, term, acc[j][a]);
+                };
+                if (par == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int kk = 0; kk < WCT / 2; ++kk) {
+                            bve[j][kk] = bv[j][kk];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) ave[j][kk][a] = av[j][kk][a];
+                        }
+                } else {
+                    do_j(0);
+                }
+                transform_q(Qs + nxt * QSZ);                        // dY(kc+1) (in registers since the last iteration)
+                load_y(kc + 2);
+                store_x(Xs + cur * XSZ, 2 * XSZ - cur * XSZ);       // X(kc+2)
+                load_x(kc + 3);
+                if (par == 1) do_j(1);
+                transform_v(Xs + nxt * XSZ, Vs + nxt * VSZ);        // X(kc+1) -> V(kc+1)
+                __syncthreads();
+            }
+        }
+#else
         for (int k = k_beg; k < k_end; ++k) {
             const int cur = (k - k_beg) & 1, nxt = cur ^ 1;
             const float* Qc = Qs + cur * QSZ;
@@ -456,6 +577,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const float* __restrict
                         acc[j][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][kk][a], bv[j][kk], acc[j][a], 0, 0, 0);
             __syncthreads();
         }
+#endif
     }
     // partial dU[sp][xi][co][ci]
     float* out = part + (size_t)sp * 16 * Cout * Cin;

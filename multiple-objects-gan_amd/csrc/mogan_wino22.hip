@@ -20,6 +20,7 @@
 #include <algorithm>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
+#include "mogan_mma.h"
 
 namespace {
 
@@ -221,6 +222,21 @@ __global__ __launch_bounds__(NTHR) void wino22_kernel(const W22P p) {
         store_x(rx, Xs + cur * XSZ);                        // X(c+2)
         load_x(rx, c + 3);
         transform(Xs + nxt * XSZ, Vs + nxt * VSZ);          // X(c+1) -> V(c+1)
+#if MOGAN_X6
+        // the chunk's 8 k-steps of a unit = one 16-k group of the split-bf16 form (mogan_mma.h)
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu) {        // unit by unit: 24 fragment registers live at a time
+            float a8[8], b8[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int v = uu * 8 + kk;
+                a8[kk] = ac[v >> 2][v & 3]; b8[kk] = vb[uu][2 * kk * NT];
+            }
+            const X6Frag fa = x6_split8(a8), fb = x6_split8(b8);
+#pragma unroll
+            for (int term = 0; term < 6; ++term) acc[uu] = x6_mfma(fa, fb, term, acc[uu]);
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
@@ -228,6 +244,7 @@ __global__ __launch_bounds__(NTHR) void wino22_kernel(const W22P p) {
                 const int v = uu * 8 + kk;
                 acc[uu] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[v >> 2][v & 3], vb[uu][2 * kk * NT], acc[uu], 0, 0, 0);
             }
+#endif
         __syncthreads();
     };
 
@@ -428,6 +445,51 @@ __global__ __launch_bounds__(NTHR) void wino22_wgrad_kernel(const float* __restr
         store_x(Xs + XSZ2);
         load_x(k_beg + 2);
         __syncthreads();
+#if MOGAN_X6 && defined(MOGAN_X6_W22_WGRAD)
+        // (off: with 12 waves = 170 registers per lane the pair form spills -- 6 accumulators + the kept operands of the even
+        // chunk + the fragments -- and ran 3.5x slower than the native form below; measured round 2)
+        // split-bf16 form: a chunk supplies 4 k-values per lane, the MFMAs of a chunk pair are issued in its second
+        // iteration; chunks past k_end are staged as zeros, so an unpaired last chunk is paired with zeros
+        float ae[3][WT / 2], b0e[3][WT / 2], b1e[3][WT / 2];
+        for (int k = k_beg; k < k_end; k += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int cur = par, nxt = cur ^ 1, kc = k + par;
+                const float* Qc = Qs + cur * QSZ;
+                const float* Vc = Vs + cur * VSZ2;
+                auto do_pr = [&](int pr) {
+                    float a8[8], b08[8], b18[8];
+#pragma unroll
+                    for (int kk = 0; kk < WT / 2; ++kk) {
+                        const float a = Qc[uq[pr] + 2 * kk * LDQ2];
+                        const float b0 = Vc[uv[pr] + 2 * kk * LDV2], b1 = Vc[uv[pr] + 2 * kk * LDV2 + 32];
+                        if (par == 0) { ae[pr][kk] = a; b0e[pr][kk] = b0; b1e[pr][kk] = b1; }
+                        else {
+                            a8[kk] = ae[pr][kk]; b08[kk] = b0e[pr][kk]; b18[kk] = b1e[pr][kk];
+                            a8[4 + kk] = a; b08[4 + kk] = b0; b18[4 + kk] = b1;
+                        }
+                    }
+                    if (par == 1) {
+                        const X6Frag fa = x6_split8(a8), fb0 = x6_split8(b08), fb1 = x6_split8(b18);
+#pragma unroll
+                        for (int term = 0; term < 6; ++term) {
+                            acc[pr * 2] = x6_mfma(fa, fb0, term, acc[pr * 2]);
+                            acc[pr * 2 + 1] = x6_mfma(fa, fb1, term, acc[pr * 2 + 1]);
+                        }
+                    }
+                };
+                do_pr(0);
+                transform_q(Qs + nxt * QSZ);                        // dY(kc+1)
+                load_y(kc + 2);
+                do_pr(1);
+                store_x(Xs + cur * XSZ2);                           // X(kc+2)
+                load_x(kc + 3);
+                do_pr(2);
+                transform_v(Xs + nxt * XSZ2, Vs + nxt * VSZ2);      // X(kc+1) -> V(kc+1)
+                __syncthreads();
+            }
+        }
+#else
         for (int k = k_beg; k < k_end; ++k) {
             const int cur = (k - k_beg) & 1, nxt = cur ^ 1;
             const float* Qc = Qs + cur * QSZ;
@@ -448,6 +510,7 @@ __global__ __launch_bounds__(NTHR) void wino22_wgrad_kernel(const float* __restr
                 }
             __syncthreads();
         }
+#endif
     }
     // partial dU[sp][xi][co][4*Cin]
     const int N4 = 4 * Cin;

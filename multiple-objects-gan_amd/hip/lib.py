@@ -5,6 +5,7 @@ GPU tensor, this raises.  Importing the module is harmless on a CPU-only box (so
 `__graft_entry__.build()` and the CPU test-suite can import the package); the library is opened
 on first use.
 """
+import contextlib
 import ctypes
 import os
 
@@ -256,3 +257,21 @@ def call(name, *args):
 
 def bn_ws_bytes(B, C, HW):
     return int(load().mogan_bn_ws_bytes(B, C, HW))
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """Wrap every hipGraph capture (torch.cuda.graph / make_graphed_callables) in this.  Python's cyclic GC may fire at any
+    allocation; if it then finalises dead CUDA objects of an engine dropped earlier (graphs, events, a private memory pool)
+    their hipFree / destroy calls land inside the capture, which HIP rejects -- raised from a destructor that is std::terminate
+    (seen as "Fatal Python error: Aborted ... Garbage-collecting" in 2 of 5 full test-suite runs, never in a fresh process).
+    Collect first, keep the collector off while capturing."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()

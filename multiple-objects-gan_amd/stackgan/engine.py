@@ -139,7 +139,8 @@ class StackGANEngine:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            from ..hip import lib as _lib
+            with _lib.capture_guard(), torch.cuda.graph(self._graph):
                 self._graph_out = self.device_step(st)
             for t, s in zip(self._state_tensors(), snap):
                 t.copy_(s)

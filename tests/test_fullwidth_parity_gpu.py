@@ -25,6 +25,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from helpers import GOLDEN, big_probe_close, det_array, det_fill_state, load_pkg, max_abs, rel_l2
 
@@ -71,10 +72,27 @@ def test_full_width_block_vs_reference_fixture(tag):
     y.backward(T("fw.%s.g" % tag, gs).to(DEV))
     torch.cuda.synchronize()
     big_probe_close(y, g[tag + "_y"], tol_abs=1e-4, what=tag + " y")
-    big_probe_close(x.grad, g[tag + "_dx"], tol_rel_l2=1e-4, what=tag + " dx")
+    # downBlock ends in a LeakyReLU: one pre-activation within rounding of zero whose sign comes out differently than in
+    # the reference's fp32 run moves dx / dW by ~2e-4 (tools/diag_block_kinks.py: one such element of 3.1 M with the
+    # split-bf16 MFMA form, none with the native fp32 form).  The fixture comparison therefore carries a kink allowance,
+    # and the values are pinned to 2e-6 against fp64 with THIS run's sign decisions imposed (below).
+    kink = 10.0 if tag == "down" else 1.0
+    big_probe_close(x.grad, g[tag + "_dx"], tol_rel_l2=1e-4 * kink, what=tag + " dx")
     for k, p in mod.named_parameters():
-        tol = 1e-3 if p.dim() == 1 else 1e-4
+        tol = 1e-3 if p.dim() == 1 else 1e-4 * kink
         big_probe_close(p.grad, g["%s_d_%s" % (tag, k.replace(".", "__"))], tol_rel_l2=tol, what="%s d%s" % (tag, k))
+    if tag == "down":
+        sd = {k: v.detach().cpu().double() for k, v in mod.state_dict().items()}
+        xd = x.detach().cpu().double().requires_grad_(True)
+        wd = sd["0.weight"].clone().requires_grad_(True)
+        # (the running statistics in sd are the updated ones: batch_norm below runs in training mode and ignores them)
+        t = F.batch_norm(F.conv2d(xd, wd, None, 2, 1), None, None, sd["1.weight"], sd["1.bias"], True, 0.1, 1e-5)
+        mask = y.detach().cpu() > 0
+        flips = int((mask != (t.detach() > 0)).sum())
+        assert flips <= 8, "%d LeakyReLU decisions differ from fp64" % flips
+        torch.where(mask, t, 0.2 * t).backward(T("fw.%s.g" % tag, gs).double())
+        assert rel_l2(x.grad, xd.grad) < 2e-6 and rel_l2(mod[0].weight.grad, wd.grad) < 2e-6, \
+            (rel_l2(x.grad, xd.grad), rel_l2(mod[0].weight.grad, wd.grad))
     for k, v in mod.state_dict().items():
         if "running" in k:
             big_probe_close(v, g["%s_s_%s" % (tag, k.replace(".", "__"))], tol_abs=1e-5, what="%s %s" % (tag, k))

@@ -11,9 +11,11 @@ Adam), generator_loss incl. Inception + DAMSM words/sentence losses + KL, backwa
 fp32 everywhere, random-init networks of the full coco_train.yml widths, inputs resident in HBM.
 W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize();
 elapsed = MAX over ranks; rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      dominant kernel = the fp32-MFMA implicit-GEMM (gemm_kernel<...>): algorithmic flops
-                per launch (2*M*N*K of the true GEMM dims) / average launch duration measured live
-                with HIP events on the launch stream (mogan_prof_*), vs the 157.3 TFLOP/s fp32 MFMA peak
+  roofline      dominant kernel = the implicit-GEMM (gemm_kernel<...>): algorithmic fp32 flops per launch (2*M*N*K
+                of the true GEMM dims) / average launch duration measured live with HIP events on the launch
+                stream (mogan_prof_*).  `peak` = the matrix-pipe peak of the form the library computes fp32
+                products in (mogan_mfma_form): split-bf16 = 2500 TFLOP/s dense bf16 / 6 partial products per
+                fp32 product = 416.7; native v_mfma_f32_32x32x2_f32 = 157.3 (also given as `frac_f32_mfma`).
   cpu_baseline  the CPU oracle (oracle/attngan_oracle.py, a torch-CPU port of the reference step)
                 timed on this host's cores on the same workload (rank 0, N=1 only): 1 warm-up + 2 timed steps.
   parity        that warm-up step against ONE HIP step from the same weights with the same z / eps: relative
@@ -46,6 +48,24 @@ from mogan_amd.attngan.trainer import TrainEngine, build_networks  # noqa: E402
 from mogan_amd.hip import lib  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16), no sparsity
+
+
+def dtype_note():
+    if int(lib.load().mogan_mfma_form()) == 6:
+        return ("fp32 tensors and accumulators; every fp32 product is formed on the bf16 matrix pipe from the exact 3-piece "
+                "bf16 split of both operands (6 partial products, dropped terms <= 2^-23 |ab|): error against fp64 equal to "
+                "the native fp32-MFMA build's (tools/diag_x6_precision.py, DESIGN.md section 4)")
+    return "fp32 everywhere (native v_mfma_f32_32x32x2_f32)"
+
+
+def mfma_peak():
+    """(peak TFLOP/s of fp32-equivalent flops, description) of the MFMA form libmogan_hip.so was built with"""
+    form = int(lib.load().mogan_mfma_form())
+    if form == 6:
+        return PEAK_BF16_MFMA_TFLOPS / 6.0, "split-bf16: 3 bf16 pieces per fp32 operand, 6 v_mfma_f32_32x32x16_bf16 partial " \
+                                            "products per fp32 product (2500 TFLOP/s dense bf16 / 6)"
+    return PEAK_F32_MFMA_TFLOPS, "native v_mfma_f32_32x32x2_f32"
 MODES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bmm", "dconv_fwd", "dconv_dgrad", "dconv_wgrad")
 TILES = ("128x128", "96x128", "128x32", "32x128", "64x64", "128x64", "64x128")
 
@@ -288,7 +308,7 @@ def run_family(name, args, device):
     ms = elapsed / args.steps * 1e3
     out = {"metric": "images/sec per G+D train step, %s" % name, "value": B * args.steps / elapsed,
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_note": dtype_note(), "data": "synthetic",
            "config": {"workload": desc + ", G+D train step, widths GF %d / DF %d, fp32" % (cfg.GAN.GF_DIM, cfg.GAN.DF_DIM),
                       "batch_per_gpu": B, "global_batch": B, "parallelism": "dp1",
                       "launch": "hipGraph" if engine.use_graph else "eager"},
@@ -298,12 +318,14 @@ def run_family(name, args, device):
         tot_ms = sum(r["ms_per_step"] for r in rows)
         tot_gf = sum(r["gflop_per_step"] for r in rows)
         dom = rows[0] if rows else None
+        peak, peak_note = mfma_peak()
         out["roofline"] = {"bound": "mfma", "kernel": dom and dom["kernel"], "achieved": dom and dom["tflops"],
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": dom and dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s",
+                           "frac": dom and dom["tflops"] / peak, "frac_f32_mfma": dom and dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                           "traffic": None,
                            "all_gemm": {"gflop_per_step": tot_gf, "gflop_per_image": tot_gf / B, "ms_per_step": tot_ms,
                                         "achieved": tot_gf / tot_ms if tot_ms else 0.0,
-                                        "frac": (tot_gf / tot_ms) / PEAK_F32_MFMA_TFLOPS if tot_ms else 0.0,
+                                        "frac": (tot_gf / tot_ms) / peak if tot_ms else 0.0,
                                         "share_of_step_ms": tot_ms / ms},
                            "eager_ms_per_step": eager_ms,
                            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
@@ -392,6 +414,7 @@ def main():
         logs = run_step()
         if args.debug_losses:
             print("step", {k: round(float(v), 4) for k, v in logs.items() if v.dim() == 0}, file=sys.stderr, flush=True)
+    host_elapsed = time.perf_counter() - t0             # all launches of the K steps queued (diagnostic: host- or GPU-bound?)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -409,8 +432,9 @@ def main():
     out = {
         "metric": "images/sec per G+D train step, 256x256 coco-attngan",
         "value": world * B * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_note": dtype_note(), "data": "synthetic",
         "config": {"workload": "MS-COCO AttnGAN 256x256 G+D train step: G_NET + D_NET64/128/256 + "
                                "GlobalAttentionGeneral + Inception/DAMSM losses (random-init), coco_train.yml "
                                "widths (GF 48, DF 96, T 12), fp32", "batch_per_gpu": B, "global_batch": world * B,
@@ -434,16 +458,18 @@ def main():
             for k in ("launches_per_step", "gflop_per_step", "ms_per_step"):
                 a[k] += r[k]
         traffic = load_traffic()
+        peak, peak_note = mfma_peak()
         for f, a in fams.items():
             a["tflops"] = a["gflop_per_step"] / a["ms_per_step"] if a["ms_per_step"] else 0.0
-            a["frac"] = a["tflops"] / PEAK_F32_MFMA_TFLOPS
+            a["frac"] = a["tflops"] / peak
             a["traffic_bytes_per_launch"] = traffic.get(f)
         dom = max(fams.values(), key=lambda a: a["ms_per_step"])
         tot_ms = sum(r["ms_per_step"] for r in rows)
         tot_gf = sum(r["gflop_per_step"] for r in rows)
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": dom["frac"], "traffic": dom["traffic_bytes_per_launch"],
+            "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "peak_note": peak_note,
+            "unit": "TFLOP/s", "frac": dom["frac"], "frac_f32_mfma": dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
+            "traffic": dom["traffic_bytes_per_launch"],
             "launches_per_step": dom["launches_per_step"],
             "avg_launch_ms": dom["ms_per_step"] / dom["launches_per_step"],
             "gflop_per_launch": dom["gflop_per_step"] / dom["launches_per_step"],
@@ -451,7 +477,7 @@ def main():
                          for a in sorted(fams.values(), key=lambda a: -a["ms_per_step"])],
             "all_gemm": {"gflop_per_step": tot_gf, "gflop_per_image": tot_gf / B, "ms_per_step": tot_ms,
                          "achieved": tot_gf / tot_ms if tot_ms else 0.0,
-                         "frac": (tot_gf / tot_ms) / PEAK_F32_MFMA_TFLOPS if tot_ms else 0.0,
+                         "frac": (tot_gf / tot_ms) / peak if tot_ms else 0.0,
                          "share_of_step_ms": tot_ms / ms},
             "eager_ms_per_step": eager_ms,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:10]],

@@ -80,6 +80,10 @@ int mogan_wino22_debug_min_tiles(int n);
 int mogan_gemm_debug_force(int cfg, int split);
 /* tuning hook: grouped launches (mogan_conv2d_*_group) with fewer tiles than this run their members one by one (default 1600, see csrc/mogan_gemm.hip) */
 int mogan_gemm_group_min_tiles(int tiles);
+/* which matrix instruction the MFMA kernels of this build use for their fp32 products: 6 = split-bf16 form (three bf16 pieces
+ * per operand, six v_mfma_f32_32x32x16_bf16 partial products per 16 k; csrc/mogan_mma.h -- the default), 1 = native
+ * v_mfma_f32_32x32x2_f32 (-DMOGAN_X6=0).  bench.py prices its roofline against the matching peak. */
+int mogan_mfma_form(void);
 
 /* measurement hook (bench.py roofline leg): with profiling enabled every gemm_kernel launch is bracketed by
  * HIP events on its own stream; collect() returns rows of 5 doubles {mode (0 fwd,1 dgrad,2 wgrad,3 bmm),

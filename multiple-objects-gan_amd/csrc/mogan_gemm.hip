@@ -33,6 +33,11 @@
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
 #include "mogan_mma.h"
+// split-bf16 form of gemm_kernel: 1 = the operands are split when they are staged (bf16 pieces in LDS), 0 = when the
+// fragments are read (fp32 in LDS, the layout of the native form)
+#ifndef MOGAN_X6_STAGE
+#define MOGAN_X6_STAGE 1
+#endif
 
 namespace {
 
@@ -106,8 +111,17 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32, LD = BK + 4;
     constexpr int QA = BM / 32, QB = BN / 32;            // quads (4 consecutive k of one row) per thread
     static_assert(WM * WN == 4, "4 waves per block");
+#if MOGAN_X6 && MOGAN_X6_STAGE
+    // split-at-staging form: the LDS images hold the three bf16 pieces of every element, row = [piece 1: 32 k][piece 2]
+    // [piece 3] + 16 B pad = 208 B (an odd multiple of 16 B: the 16-byte fragment reads of 16 consecutive rows touch all 64
+    // banks once); ONE buffer, two barriers per K-tile (the fragments of a tile are in registers before its second half)
+    constexpr int RSB = 3 * 2 * BK + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char Ab[BM * RSB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bb[BN * RSB];
+#else
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+#endif
     __shared__ __attribute__((aligned(16))) int Kt[2][3][BK];   // per-K-tile decode of k (conv fwd / dgrad)
     __shared__ __attribute__((aligned(16))) int Nt[2][BN];      // per-block decode of the column n (conv wgrad)
 
@@ -214,7 +228,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
     int wg_e0[QB], wg_e1[QB];
 
     // stage ONE element e of the next K-tile (kt) into ra/rb; e is a compile-time constant after unrolling
-    auto stage_elem = [&](int e, int kt, int buf) {
+    auto stage_elem = [&](int e, int kt, int buf, float (&ra)[QA][4], float (&rb)[QB][4]) {
         const bool isA = e < NEA;
         const int i = isA ? e / 4 : (e - NEA) / 4, j = e & 3;
         if constexpr (MODE == CONV_WGRAD) {
@@ -314,6 +328,21 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
         }
     };
 
+#if MOGAN_X6 && MOGAN_X6_STAGE
+    // quad i of a register set -> its three 8-byte piece groups in the LDS image
+    auto store_quad = [&](int i, bool isA, const float (&v)[4]) {
+        const int q = tid + 256 * i;
+        const bool kf = isA ? a_kfast : b_kfast;
+        const int R = isA ? BM : BN;
+        const int row = kf ? (q >> 3) : (q % R), kq = kf ? (q & 7) : (q / R);
+        uint32_t w[3][2];
+        x6_split2(v[0], v[1], w[0][0], w[1][0], w[2][0]);
+        x6_split2(v[2], v[3], w[0][1], w[1][1], w[2][1]);
+        unsigned char* d = (isA ? Ab : Bb) + row * RSB + kq * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *(uint2*)(d + pl * 2 * BK) = make_uint2(w[pl][0], w[pl][1]);
+    };
+#else
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < QA; ++i) {
@@ -329,6 +358,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
         }
     };
 
+#endif
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -337,6 +367,79 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+#if MOGAN_X6 && MOGAN_X6_STAGE
+    // ---- main loop, split-at-staging form.  Tile t is in LDS as bf16 pieces; while its 2 x 6 MFMA groups run, the gather of
+    //      tile t+2 goes into one register set (first half: one slice per MFMA group) and tile t+1, gathered one iteration
+    //      earlier into the other set, is split and written to LDS (second half, after the barrier that says every wave has
+    //      its fragments of tile t).  Two tiles of load latency slack, the split arithmetic once per staged element instead
+    //      of once per fragment element (half as many), no VALU between the LDS fragment reads and the MFMAs.
+    const int arow = (wm * TM * 32 + (lane & 31)) * RSB + (lane >> 5) * 32;
+    const int brow = (wn * TN * 32 + (lane & 31)) * RSB + (lane >> 5) * 32;
+    const int ntile = (kend - kbeg + BK - 1) / BK;
+    float ra2[QA][4], rb2[QB][4];
+    constexpr int NQ = QA + QB;
+    constexpr int EPG = (NE + 5) / 6, QPG = (NQ + 5) / 6;          // gather elements / stored quads per MFMA group
+    auto frag = [&](const unsigned char* base, int off) {
+        X6Frag f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f.p[pl] = __builtin_bit_cast(mma_bf16x8, *(const uint4*)(base + off + pl * 2 * BK));
+        return f;
+    };
+    auto iter = [&](int t, float (&raC)[QA][4], float (&rbC)[QB][4], float (&raN)[QA][4], float (&rbN)[QB][4]) {
+        const int kt = kbeg + t * BK, tb = t & 1;
+        X6Frag fa[TM], fb[TN];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int q = 0; q < TM; ++q) fa[q] = frag(Ab, arow + q * 32 * RSB + s2 * 16);
+#pragma unroll
+            for (int q = 0; q < TN; ++q) fb[q] = frag(Bb, brow + q * 32 * RSB + s2 * 16);
+            if (s2 == 1) __syncthreads();                          // every wave holds its fragments of tile t
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int tb2 = 0; tb2 < TN; ++tb2) acc[ta][tb2] = x6_mfma(fa[ta], fb[tb2], term, acc[ta][tb2]);
+                if (s2 == 0) {
+#pragma unroll
+                    for (int x = 0; x < EPG; ++x)
+                        if (term * EPG + x < NE) stage_elem(term * EPG + x, kt + 2 * BK, tb, raN, rbN);   // past kend: zeros
+                } else {
+#pragma unroll
+                    for (int x = 0; x < QPG; ++x) {
+                        const int qi = term * QPG + x;
+                        if (qi < QA) store_quad(qi, true, raC[qi < QA ? qi : 0]);
+                        else if (qi < NQ) store_quad(qi - QA, false, rbC[qi >= QA && qi < NQ ? qi - QA : 0]);
+                    }
+                    if (term == 5) decode_k(kt + 3 * BK, tb ^ 1);  // table tb^1 was last read while gathering tile t+1
+                }
+                if (SCHED) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                           // tile t+1 is in LDS
+    };
+    if (ntile > 0) {
+        decode_k(kbeg, 0); decode_k(kbeg + BK, 1);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) stage_elem(e, kbeg, 0, ra, rb);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) stage_elem(e, kbeg + BK, 1, ra2, rb2);
+        __syncthreads();                                           // both tables read
+        decode_k(kbeg + 2 * BK, 0);
+#pragma unroll
+        for (int i = 0; i < QA; ++i) store_quad(i, true, ra[i]);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) store_quad(i, false, rb[i]);
+        __syncthreads();
+        for (int t = 0; t < ntile; t += 2) {
+            iter(t, ra2, rb2, ra, rb);
+            if (t + 1 < ntile) iter(t + 1, ra, rb, ra2, rb2);
+        }
+    }
+
+#else
     const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * (BK / 2);
     const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * (BK / 2);
 
@@ -350,7 +453,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
         decode_k(kbeg, 0);
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < NE; ++e) stage_elem(e, kbeg, 0);
+        for (int e = 0; e < NE; ++e) stage_elem(e, kbeg, 0, ra, rb);
         decode_k(kbeg + BK, 1);
         store_tile(0);
         __syncthreads();
@@ -394,7 +497,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
                     const int sl = s2 * 6 + term;
 #pragma unroll
                     for (int x = 0; x < EPS; ++x)
-                        if (sl * EPS + x < NE) stage_elem(sl * EPS + x, kt + BK, cur ^ 1);
+                        if (sl * EPS + x < NE) stage_elem(sl * EPS + x, kt + BK, cur ^ 1, ra, rb);
                     if (sl == 11) decode_k(kt + 2 * BK, cur);
                     if (SCHED) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -414,7 +517,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
                 }
 #pragma unroll
                 for (int x = 0; x < EPS; ++x)
-                    if (s16 * EPS + x < NE) stage_elem(s16 * EPS + x, kt + BK, cur ^ 1);   // past kend: masked to 0
+                    if (s16 * EPS + x < NE) stage_elem(s16 * EPS + x, kt + BK, cur ^ 1, ra, rb);   // past kend: masked to 0
                 if (s16 == 15) decode_k(kt + 2 * BK, cur);       // table `cur` was last read while staging tile t
                 if (SCHED) __builtin_amdgcn_sched_barrier(0);    // (a sched_group_barrier template instead: no gain, lab 8)
             }
@@ -424,6 +527,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
         }
     }
 
+#endif
     // ---------------------------------------------------------------- epilogue
     const bool split = p.nsplit > 1;
     float* __restrict__ slab = p.ws + (size_t)sp * p.slab;
@@ -859,6 +963,7 @@ int mogan_gemm_tune_clear(void) {
 }
 
 int mogan_gemm_debug_force(int cfg, int split) { g_force_cfg = cfg; g_force_split = split; return 0; }
+int mogan_mfma_form(void) { return MOGAN_X6 ? 6 : 1; }
 int mogan_gemm_group_min_tiles(int tiles) { if (tiles < 0) return MOGAN_ERR_SHAPE; g_group_min_tiles = tiles; return 0; }
 
 int mogan_prof_enable(int on) {

@@ -1,4 +1,4 @@
-// mogan_gemm.hip -- fp32 MFMA implicit-GEMM for gfx950 (CDNA4).
+// mogan_gemm.hip -- fp32 implicit GEMM on the matrix cores of gfx950 (CDNA4).
 //
 // One LDS-tiled kernel, four operand "gather modes":
 //   CONV_FWD    Y[n,co,oy,ox]  = sum_{ci,kh,kw} W[co,ci,kh,kw] * X[n,ci,oy*s-p+kh,ox*s-p+kw]
@@ -9,14 +9,17 @@
 //               GEMM: M=Cout, N=Cin*KH*KW, K=B*OH*OW
 //   BMM         generic strided batched GEMM (Linear fwd/dgrad/wgrad, attention / DAMSM products)
 //
-// Math is exact fp32: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, 157.3 TF peak on MI355X;
-// there is no TF32/xf32 on gfx950).  Block = 256 threads = 4 wave64; each wave owns TMxTN tiles of
-// 32x32; BK = 32.  A is staged as As[m][k] (row stride 33), B as Bs[k][n] (row stride BN+1): both
-// MFMA operand reads (`ds_read_b32`, 32-lane groups) are bank-conflict free.  Global->register
-// prefetch of K-tile t+1 is issued before the MFMAs of tile t (one LDS buffer, two barriers per
-// tile): with a 64-cycle MFMA the kernel is matrix-pipe bound, not load bound.
-// Split-K writes per-split slabs into the caller's workspace; a second kernel reduces them in a
-// fixed order (deterministic, no atomics).
+// Math: fp32 in, fp32 accumulate.  Default build (MOGAN_X6 = 1, mogan_mma.h): every fp32 product is formed on the bf16 matrix
+// pipe from the exact three-piece bf16 split of both operands -- six v_mfma_f32_32x32x16_bf16 partial products per 16 k, 6/16
+// of the matrix-pipe time of the native v_mfma_f32_32x32x2_f32 form (-DMOGAN_X6=0), same error against fp64.  Block = 256
+// threads = 4 wave64; each wave owns TMxTN tiles of 32x32; BK = 32.
+//   split form   : the operands are split when a K-tile is staged; LDS holds the bf16 pieces (row = 3 x 64 B + 16 B pad, ONE
+//                  buffer), fragments are 16-byte LDS reads.  While tile t's 2 x 6 MFMA groups run, tile t+2 is gathered into
+//                  registers (first half) and tile t+1 is split and stored (second half); two barriers per tile.
+//   native form  : As[m][k], Bs[n][k] fp32 with row stride 36 floats, double buffered, one barrier per tile, the gather of tile
+//                  t+1 sliced between the 16 MFMA k-steps of tile t.
+// Split-K writes per-split slabs into the caller's workspace; a second kernel reduces them in a fixed order (deterministic,
+// no atomics).
 //
 // Replaces (reference = stock torch ops): nn.Conv2d / nn.Upsample+conv3x3 / nn.Linear / torch.bmm
 // call sites of code/coco/attngan/model.py:35-55,364-380,598-611,664-680 and
@@ -153,6 +156,12 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
         if (n0 >= Ncls) return;     // block-uniform
         kh0 = (py + p.ph) % p.s; kw0 = (px + p.pw) % p.s;
     }
+#ifdef MOGAN_NO_DG44      // lab: A/B of the vector weight loads below
+    const bool dg44 = false;
+#else
+    const bool dg44 = MODE == CONV_DGRAD && p.s == 2 && p.KH == 4 && p.KW == 4 && (p.K & 3) == 0 &&
+                      (((uintptr_t)p.A) & 15) == 0;
+#endif
     // FWD / DGRAD: the QB rows (pixels) this thread stages are fixed: decode them once
     bool nvalid[QB]; unsigned nbase[QB]; int ny0[QB], nx0[QB];
     if constexpr (MODE == CONV_FWD) {
@@ -261,9 +270,23 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
             } else if constexpr (MODE == CONV_DGRAD) {
                 const int q = tid + 256 * i;
                 const int m = m0 + q % BM;
-                if (j == 0) qw[i] = *(const int4*)&Kt[buf][2][4 * (q / BM)];
-                const int w = j == 0 ? qw[i].x : j == 1 ? qw[i].y : j == 2 ? qw[i].z : qw[i].w;
-                ra[i][j] = ldg(rA, (unsigned)w + (unsigned)m * KHW, m < p.M && w >= 0);
+                if (dg44) {
+                    // 4x4 stride 2: the quad's four k are the taps (kh0 + 2a, kw0 + 2b) of ONE filter W[co][ci = m]: two
+                    // 16-byte loads (kernel rows kh0 and kh0 + 2) and a pick of the columns kw0, kw0 + 2, instead of four
+                    // dword loads that each touch a different 64-byte line per lane
+                    if (j == 0) {
+                        const int k = kt + 4 * (q / BM);
+                        const bool ok = m < p.M && k < kend;
+                        const unsigned base = ((unsigned)(k >> 2) * (unsigned)p.M + (unsigned)m) * 16u + (unsigned)kh0 * 4u;
+                        const f32x4 r0 = ldg4(rA, base, ok), r1 = ldg4(rA, base + 8u, ok);
+                        ra[i][0] = kw0 ? r0[1] : r0[0]; ra[i][1] = kw0 ? r0[3] : r0[2];
+                        ra[i][2] = kw0 ? r1[1] : r1[0]; ra[i][3] = kw0 ? r1[3] : r1[2];
+                    }
+                } else {
+                    if (j == 0) qw[i] = *(const int4*)&Kt[buf][2][4 * (q / BM)];
+                    const int w = j == 0 ? qw[i].x : j == 1 ? qw[i].y : j == 2 ? qw[i].z : qw[i].w;
+                    ra[i][j] = ldg(rA, (unsigned)w + (unsigned)m * KHW, m < p.M && w >= 0);
+                }
             } else if constexpr (MODE == CONV_WGRAD) {
                 const int m = m0 + (tid >> 3) + 32 * i;
                 if constexpr (AVEC) {       // OH*OW % 4 == 0: the 4 pixels of the quad share (img, co) and are contiguous

@@ -553,15 +553,27 @@ __global__ __launch_bounds__(64) void wino22_wgrad_finish(const float* __restric
 
 }  // namespace
 
+// The F(2x2,2x2) kernels are OFF by default since the split-bf16 MFMA form (mogan_mma.h): with the matrix pipe 2.7x cheaper the
+// direct / implicit-GEMM kernels take the 4x4 s2 layers faster than the 16/9 saving of the transform pays for (same-box A/B
+// of the B = 16 step: 336.5 vs 331.3 img/s with them off).  MOGAN_WINO22=1 turns them on; the test hook
+// mogan_wino22_debug_min_tiles(n >= 0) also does (and lowers their size threshold), -1 restores the default.
 static int g_w22_min_tiles = -1;
 extern "C" int mogan_wino22_debug_min_tiles(int n) { g_w22_min_tiles = n; return 0; }
+static int w22_min_tiles() {
+    static const int env_min = getenv("MOGAN_WINO22_MIN_TILES") ? atoi(getenv("MOGAN_WINO22_MIN_TILES")) : 1024;
+    return g_w22_min_tiles >= 0 ? g_w22_min_tiles : env_min;
+}
+static bool w22_on() {
+    static const int env_on = getenv("MOGAN_WINO22") ? atoi(getenv("MOGAN_WINO22")) : 0;
+    return env_on != 0 || g_w22_min_tiles >= 0;
+}
 
 // ---- internal entry point (hidden visibility): 1 = handled, 0 = not eligible, < 0 = error ----------------------------
 // y (B,Cout,H/2,W/2) = conv4x4 s2 p1 (x (B,Cin,H,W), w (Cout,Cin,4,4)).  Workspace: the transformed weights
 // (ceil(Cout/128)*128 * 36 * Cin floats) followed by nsplit output slabs when the K range is split.
 int mogan_wino22_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                          int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
-    static const int on = getenv("MOGAN_WINO22") ? atoi(getenv("MOGAN_WINO22")) : 1;
+    const bool on = w22_on();
     if (!on || !(KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0)) return 0;
     if ((Cin % (2 * CI)) || Cin < 64 || Cout < 96 || (H % 4) || (W % 4)) return 0;
     if ((((uintptr_t)y) & 15) != 0) return 0;
@@ -583,8 +595,7 @@ int mogan_wino22_fwd_try(const float* x, const float* w, float* y, int B, int Ci
     // The transformed weights are 36/16 of the raw ones and are rebuilt per call (write + read of 36 x Cout x Cin floats): that
     // only pays when every weight meets many tiles.  Measured at B = 16 (TFLOP/s direct-equivalent, this kernel vs the
     // implicit GEMM): 4096 tiles 156 vs 90, 1024 tiles 135 vs 99 / 105 vs 88, 256 tiles 73 vs 98 / 28 vs 88.
-    if (g_w22_min_tiles < 0) g_w22_min_tiles = getenv("MOGAN_WINO22_MIN_TILES") ? atoi(getenv("MOGAN_WINO22_MIN_TILES")) : 1024;
-    if (p.ntile < g_w22_min_tiles) return 0;
+    if (p.ntile < w22_min_tiles()) return 0;
     p.ntb = (p.ntile + NT - 1) / NT; p.mbs = (int)mbs; p.nchunk = Cin / CI;
     const long long blocks = (long long)p.ntb * mbs;
     // K-split: the persistent grid runs ceil(items / ncu) rounds; pick the split count whose last round is fullest
@@ -621,7 +632,7 @@ int mogan_wino22_fwd_try(const float* x, const float* w, float* y, int B, int Ci
 // dx (B,Cin,H,W) = data gradient of conv4x4 s2 p1 for dy (B,Cout,H/2,W/2): four output phases, one work-item class each
 int mogan_wino22_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                            int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
-    static const int on = getenv("MOGAN_WINO22") ? atoi(getenv("MOGAN_WINO22")) : 1;
+    const bool on = w22_on();
     static const int dg_on = getenv("MOGAN_WINO22_DGRAD") ? atoi(getenv("MOGAN_WINO22_DGRAD")) : 1;
     if (!on || !dg_on || !(KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0)) return 0;
     if ((Cout % (2 * KC)) || Cout < 64 || Cin < 96 || (H % 4) || (W % 4)) return 0;
@@ -644,8 +655,7 @@ int mogan_wino22_dgrad_try(const float* dy, const float* w, float* dx, int B, in
     }
     W22P p{};
     p.ntile = B * (OH / 2) * (OW / 2);
-    if (g_w22_min_tiles < 0) g_w22_min_tiles = getenv("MOGAN_WINO22_MIN_TILES") ? atoi(getenv("MOGAN_WINO22_MIN_TILES")) : 1024;
-    if (p.ntile < g_w22_min_tiles) return 0;
+    if (p.ntile < w22_min_tiles()) return 0;
     p.ntb = (p.ntile + NT - 1) / NT; p.mbs = (int)mbs; p.nchunk = Cout / KC;
     const long long blocks = (long long)p.ntb * mbs * 4;
     int nsplit = 1; double best = 1e30;
@@ -680,15 +690,14 @@ int mogan_wino22_dgrad_try(const float* dy, const float* w, float* dx, int B, in
 // dw (Cout,Cin,4,4) (+)= weight gradient of conv4x4 s2 p1; workspace: nsplit * 36 * Cout * Cin floats
 int mogan_wino22_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                            int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-    static const int on = getenv("MOGAN_WINO22") ? atoi(getenv("MOGAN_WINO22")) : 1;
+    const bool on = w22_on();
     static const int wg_on = getenv("MOGAN_WINO22_WGRAD") ? atoi(getenv("MOGAN_WINO22_WGRAD")) : 1;
     if (!on || !wg_on || !(KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0)) return 0;
     if ((Cin % WCI) || Cin < 64 || Cout < 96 || (H % 4) || (W % 4)) return 0;
     if ((((uintptr_t)dy) & 7) != 0) return 0;
     const int OH = H / 2, OW = W / 2;
     const long long ntile = (long long)B * (OH / 2) * (OW / 2);
-    if (g_w22_min_tiles < 0) g_w22_min_tiles = getenv("MOGAN_WINO22_MIN_TILES") ? atoi(getenv("MOGAN_WINO22_MIN_TILES")) : 1024;
-    if (ntile < g_w22_min_tiles || (ntile % WT) != 0) return 0;
+    if (ntile < w22_min_tiles() || (ntile % WT) != 0) return 0;
     if ((long long)B * Cin * H * W >= (1ll << 29) || (long long)B * Cout * OH * OW >= (1ll << 29)) return 0;
     static int ncu = 0;
     if (!ncu) {

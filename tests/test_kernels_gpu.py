@@ -92,11 +92,13 @@ def _conv_ref(x, w, stride, pad, up):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("force", [(-1, 0), (0, 3), (1, 1), (2, 2), (3, 1), (4, 5), (5, 2), (6, 3)])
+@pytest.mark.parametrize("force", [(-1, 0), (-2, 0), (0, 3), (1, 1), (2, 2), (3, 1), (4, 5), (5, 2), (6, 3)])
 def test_conv2d_fwd_dgrad_wgrad(case, force):
     B, Cin, H, W, Cout, k, s, pad, up = case
-    lib.load().mogan_gemm_debug_force(*force)
-    lib.load().mogan_wino22_debug_min_tiles(1)          # small shapes through the 4x4-s2 Winograd kernel too
+    # (-1, 0): default dispatch (direct / implicit GEMM for the 4x4 s2 shapes); (-2, 0): the same with the F(2x2,2x2) Winograd
+    # kernels (off by default) enabled from one tile on; the others force an implicit-GEMM tile config and split
+    lib.load().mogan_gemm_debug_force(-1 if force[0] == -2 else force[0], force[1])
+    lib.load().mogan_wino22_debug_min_tiles(1 if force[0] == -2 else -1)
     try:
         x = T("cx%s" % (case,), (B, Cin, H, W)).requires_grad_(True)
         w = T("cw%s" % (case,), (Cout, Cin) + k, 0.2).requires_grad_(True)

@@ -8,6 +8,10 @@
  * torch.autograd.Function (hip/ops.py).  INTEGRATION.md shows the binding.
  *
  * Conventions
+ *   - arithmetic: fp32 tensors, fp32 accumulation.  The matrix kernels form every fp32 product from the exact three-piece bf16
+ *     split of both operands on the bf16 MFMA pipe (six partial products, dropped terms <= 2^-23 |a b|; csrc/mogan_mma.h):
+ *     error against fp64 at the level of the native fp32 MFMA instruction, not bit-identical to an fmaf
+ *     chain.  mogan_mfma_form() reports the form; -DMOGAN_X6=0 builds the native one;
  *   - all tensors are dense fp32, NCHW, device pointers, borrowed for the duration of the call
  *     (the caller -- PyTorch -- owns the memory); uint8 masks / int32 lengths where stated;
  *   - every call is asynchronous on `stream` (pass torch.cuda.current_stream().cuda_stream) and

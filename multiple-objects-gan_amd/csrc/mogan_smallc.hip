@@ -316,11 +316,55 @@ __global__ __launch_bounds__(256) void sc_dgrad_k3s2(const float* __restrict__ d
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- full-map convolutions with <= 4 output channels (the discriminators' logits heads, model.py:664-680: Conv2d(8 ndf, 1,
+// kernel_size=4, stride=4) on a 4x4 map): the filter covers the whole input, the output is 1x1 -- per image one dot product
+// of K = Cin*KH*KW elements.  As an implicit GEMM this is M = 1, N = B, K = 12288: a 96-way split-K plus a reduction per call.
+__global__ __launch_bounds__(256) void sc_dot_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                  int K, int Cout) {
+    const int b = blockIdx.x / Cout, co = blockIdx.x % Cout;
+    const float* xb = x + (size_t)b * K; const float* wc = w + (size_t)co * K;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) acc = fmaf(xb[k], wc[k], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) y[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// dx[b][k] = sum_co dy[b][co] w[co][k]
+__global__ __launch_bounds__(256) void sc_dot_dgrad(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                    int K, int Cout, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / K), k = (int)(i - (long long)b * K);
+    float acc = 0.f;
+    for (int co = 0; co < Cout; ++co) acc = fmaf(dy[b * Cout + co], w[(size_t)co * K + k], acc);
+    dx[i] = acc;
+}
+// dw[co][k] (+)= sum_b dy[b][co] x[b][k]   (images in order: deterministic)
+__global__ __launch_bounds__(256) void sc_dot_wgrad(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                    int K, int Cout, int B, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * K) return;
+    const int co = i / K, k = i - co * K;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(dy[b * Cout + co], x[(size_t)b * K + k], acc);
+    dw[i] = accumulate ? dw[i] + acc : acc;
+}
+static inline bool is_full_map(int Hs, int Ws, int Cout, int KH, int KW, int ph, int pw, int up) {
+    return up == 0 && ph == 0 && pw == 0 && KH == Hs && KW == Ws && Cout >= 1 && Cout <= 4;
+}
+
 }  // namespace
 
 // ---- internal entry points (hidden visibility): 1 = handled, 0 = not eligible ------------------------------------
 int mogan_smallc_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
                          int stride, int ph, int pw, int up, hipStream_t st) {
+    if (is_full_map(Hs, Ws, Cout, KH, KW, ph, pw, up) && (long long)Cin * KH * KW < (1ll << 30)) {
+        hipLaunchKernelGGL(sc_dot_fwd, dim3((unsigned)(B * Cout)), dim3(256), 0, st, x, w, y, Cin * KH * KW, Cout);
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+    }
     if (!(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0 && Cout >= 1 && Cout <= 4)) return 0;
     const int tiles_x = cdiv(Ws, TC), tiles_y = cdiv(Hs, TR);
     const long long nb = (long long)B * tiles_x * tiles_y;
@@ -337,6 +381,12 @@ int mogan_smallc_fwd_try(const float* x, const float* w, float* y, int B, int Ci
 
 int mogan_smallc_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                            int KW, int stride, int ph, int pw, int up, hipStream_t st) {
+    if (is_full_map(Hs, Ws, Cout, KH, KW, ph, pw, up) && (long long)Cin * KH * KW < (1ll << 30)) {
+        const int K = Cin * KH * KW;
+        const long long total = (long long)B * K;
+        hipLaunchKernelGGL(sc_dot_dgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, w, dx, K, Cout, total);
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+    }
     if (up == 0 && ph == 0 && pw == 0 && KH == 3 && KW == 3 && stride == 2 && Cin >= 1 && Cin <= 4 && Hs >= 3 && Ws >= 3) {
         const int OH = (Hs - 3) / 2 + 1, OW = (Ws - 3) / 2 + 1;
         const int tiles_x = cdiv(cdiv(Ws, 2), TC), tiles_y = cdiv(cdiv(Hs, 2), TR);
@@ -386,6 +436,11 @@ int mogan_smallc_dgrad_try(const float* dy, const float* w, float* dx, int B, in
 int mogan_smallc_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                            int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
                            hipStream_t st) {
+    if (is_full_map(Hs, Ws, Cout, KH, KW, ph, pw, up) && (long long)Cout * Cin * KH * KW < (1ll << 30)) {
+        const int K = Cin * KH * KW;
+        hipLaunchKernelGGL(sc_dot_wgrad, dim3((unsigned)cdiv(Cout * K, 256)), dim3(256), 0, st, dy, x, dw, K, Cout, B, accumulate);
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+    }
     if (!(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0 && Cout >= 1 && Cout <= 4)) return 0;
     const int tiles_x = cdiv(Ws, TC), tiles_y = cdiv(Hs, TR);
     const long long nblk = (long long)B * tiles_y;

@@ -44,7 +44,8 @@ CONV_CASES = [
     (2, 6, 16, 16, 12, (4, 4), 2, (1, 1), 0),      # D down conv
     (2, 84, 16, 16, 24, (4, 4), 1, (1, 1), 0),     # D_NET64 local conv -> 15x15
     (3, 100, 16, 16, 50, (3, 3), 2, (1, 1), 0),    # BBOX_NET (3x3 s2)
-    (2, 12, 4, 4, 1, (4, 4), 4, (0, 0), 0),        # logits conv 4x4 s4
+    (2, 12, 4, 4, 1, (4, 4), 4, (0, 0), 0),        # logits conv 4x4 s4 (full-map dot kernels)
+    (5, 70, 4, 4, 3, (4, 4), 4, (0, 0), 0),        # the same with 3 outputs, K = 1120 (not a multiple of 256)
     (4, 20, 5, 1, 6, (1, 1), 1, (0, 0), 0),        # conv_context (1x1 on (B,cdf,T,1))
     (2, 3, 32, 32, 96, (4, 4), 2, (1, 1), 0),      # first D conv (Cin=3)
     (2, 48, 16, 16, 3, (3, 3), 1, (1, 1), 0),      # img head (Cout=3)

@@ -47,7 +47,40 @@ struct DConvP {
     long long slab;
     int accumulate;
     unsigned x_bytes, w_bytes;
+    const void* Wp; unsigned wp_bytes;       // split-bf16 build: the filters as bf16 pieces in fragment order (dconv_wprep_kernel)
 };
+
+#if MOGAN_X6
+// Filters for dconv_fwd_kernel, split-bf16 build: the three bf16 pieces (mogan_mma.h) of every filter value, laid out so that
+// a lane's 8-element A fragment of one 16-k group is ONE 16-byte LDS read and the global -> LDS staging is a straight copy:
+//   Wp[par][chunk][co][piece 0..2][h 0..1][group g][slot i]   (bf16)
+// slot i of group g = k-step 8g + i of the chunk = (channel pair c2, tap) with step = c2*KHW + tap; lane half h takes channel
+// 2*c2 + h; steps beyond the chunk's (CK/2)*KHW are zero.  w = [par][co][ci][KHW] fp32 (the conv's own filters, or the
+// flipped / parity-split ones of the data gradient).  One thread per (row, chunk, h, group).
+__global__ __launch_bounds__(256) void dconv_wprep_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int Cin,
+                                                          int KHW, int CK, int NGRP, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int g = (int)(t % NGRP); long long r = t / NGRP;
+    const int h = (int)(r & 1); r >>= 1;
+    const int nchunk = Cin / CK;
+    const int row = (int)(r % rows); const int chunk = (int)(r / rows);       // row = par*Cout + co; rows = npar*Cout
+    const int nstep = (CK / 2) * KHW;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int step = 8 * g + i;
+        const int c2 = step / KHW, tap = step - c2 * KHW;
+        v[i] = step < nstep ? w[((size_t)row * Cin + chunk * CK + 2 * c2 + h) * KHW + tap] : 0.f;
+    }
+    const X6Frag f = x6_split8(v);
+    // destination: ((chunk*rows + row) * 3 + piece) * 2*NGRP + h*NGRP + g      (16-byte units)
+    (void)nchunk;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        wp[(((size_t)chunk * rows + row) * 3 + pl) * (2 * NGRP) + h * NGRP + g] = __builtin_bit_cast(uint4, f.p[pl]);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------ forward
 // CW = tile width in output pixels (32 or 16; the tile is R = 128/CW rows).  DB = LDS double buffering: the halo and
@@ -74,10 +107,23 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     constexpr int NBUF = DB ? 2 : 1, XSZ = CK * CPL, WSZ = BM * LDW;
     constexpr int NSTEP = (CK / 2) * KHW, FIRST = NSTEP / 2;      // stores of the next chunk ride on steps >= FIRST
     constexpr int NGRP = (NSTEP + 7) / 8, GFIRST = NGRP / 2;       // groups of 8 k-steps; stores of the next chunk ride on groups >= GFIRST
-    constexpr int XPG = (NXE + (NGRP - GFIRST) - 1) / (NGRP - GFIRST), WPG = (NWQ + (NGRP - GFIRST) - 1) / (NGRP - GFIRST);
+#if MOGAN_X6
+    // filters: bf16 pieces in fragment order (dconv_wprep_kernel), row = 3 pieces x 2 lane halves x NGRP groups x 16 B + 16 B pad
+    // (an odd multiple of 16 B: the 16-byte fragment reads of 16 consecutive rows are bank-conflict free)
+    constexpr int PPR = 3 * 2 * NGRP, WROW = (PPR + 1) * 16, WSZB = BM * WROW;
+    constexpr int NWP = (BM * PPR + 255) / 256;                      // 16-byte pieces per thread and chunk
+    constexpr int NWQ_ = NWP;
+#else
+    constexpr int NWQ_ = NWQ;
+#endif
+    constexpr int XPG = (NXE + (NGRP - GFIRST) - 1) / (NGRP - GFIRST), WPG = (NWQ_ + (NGRP - GFIRST) - 1) / (NGRP - GFIRST);
     static_assert(WM * WN == 4 && KC % 4 == 0 && CK % 2 == 0 && PX == 128, "tile");
     __shared__ __attribute__((aligned(16))) float Xs[NBUF * XSZ];
+#if MOGAN_X6
+    __shared__ __attribute__((aligned(16))) unsigned char Wb[NBUF * WSZB];
+#else
     __shared__ __attribute__((aligned(16))) float Wl[NBUF * WSZ];
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -97,11 +143,18 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
         y0 = py; x0 = px;
         wptr += (size_t)par * p.Cin * p.Cout * KHW;
     }
+    const int wrow0 = par * p.Cout + blockIdx.y * BM;                 // first filter row of this block in the prepped layout
     const int nchunk_all = p.Cin / CK;
     const int c_beg = sp * p.cps, c_end = min(nchunk_all, c_beg + p.cps);
 
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, (short)0, (int)p.x_bytes, 0x00020000);
+#if MOGAN_X6
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, (short)0, (int)p.wp_bytes, 0x00020000);
+    (void)wptr;
+#else
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wptr, (short)0, (int)p.w_bytes, 0x00020000);
+    (void)wrow0;
+#endif
 
     // ---- per-thread staging plan (chunk independent) ----------------------------------------------------
     // halo: element e -> (c, hy, hx); global offset relative to the chunk's first channel, or OOB (zero padding)
@@ -139,6 +192,21 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
         }
     }
     const unsigned x_img = (unsigned)img * p.Cin * HsWs;
+#if MOGAN_X6
+    // filters: 16-byte piece q = (row, pc) of the chunk's BM x PPR image; global index in dwords
+    const int rows_all = p.npar * p.Cout;
+    unsigned wg[NWP]; int wl[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int q = tid + 256 * i;
+        const int row = q / PPR, pc = q - row * PPR;
+        const bool ok = q < BM * PPR && m0 + row < p.Cout;
+        wg[i] = ok ? (unsigned)(((wrow0 + row) * PPR + pc) * 4) : IDX_OOB;
+        wl[i] = q < BM * PPR ? row * WROW + pc * 16 : -1;
+    }
+    const unsigned wchunk = (unsigned)rows_all * PPR * 4u;          // dwords per chunk of the prepped filters
+    float rx[NXE]; f32x4 rw[NWP]; f32x4 rxq[NXQ];
+#else
     // weights: quad q -> (row, kq): 4 consecutive k of one output channel
     unsigned wg[NWQ]; int wl[NWQ];
 #pragma unroll
@@ -151,6 +219,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
     }
 
     float rx[NXE]; f32x4 rw[NWQ]; f32x4 rxq[NXQ];
+#endif
     auto load_chunk = [&](int c) {
         const unsigned xb = x_img + (unsigned)c * CK * HsWs, wb = (unsigned)c * KC;
         if constexpr (WIDE) {
@@ -159,23 +228,38 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
         } else
 #pragma unroll
         for (int i = 0; i < NXE; ++i) rx[i] = ldg(rX, xg[i] == IDX_OOB ? IDX_OOB : xg[i] + xb);
+#if MOGAN_X6
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) rw[i] = ldg4(rW, wg[i] == IDX_OOB ? IDX_OOB : wg[i] + (unsigned)c * wchunk);
+        (void)wb;
+#else
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) rw[i] = ldg4(rW, wg[i] == IDX_OOB ? IDX_OOB : wg[i] + wb);
+#endif
     };
     auto store_x = [&](int i, float* Xd) {
         if constexpr (WIDE) { if (i < NXQ && ql[i] >= 0) *(f32x4*)&Xd[ql[i]] = rxq[i]; }
         else { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; }
     };
+#if MOGAN_X6
+    auto store_w = [&](int i, unsigned char* Wd) { if (wl[i] >= 0) *(f32x4*)(Wd + wl[i]) = rw[i]; };
+    typedef unsigned char wlds_t;
+    wlds_t* const Wl = Wb;
+    constexpr int WSZ_ = WSZB;
+#else
     auto store_w = [&](int i, float* Wd) {
         if (wl[i] >= 0) {
             Wd[wl[i]] = rw[i][0]; Wd[wl[i] + 1] = rw[i][1]; Wd[wl[i] + 2] = rw[i][2]; Wd[wl[i] + 3] = rw[i][3];
         }
     };
-    auto store_chunk = [&](float* Xd, float* Wd) {
+    typedef float wlds_t;
+    constexpr int WSZ_ = WSZ;
+#endif
+    auto store_chunk = [&](float* Xd, wlds_t* Wd) {
 #pragma unroll
         for (int i = 0; i < NXE; ++i) store_x(i, Xd);
 #pragma unroll
-        for (int i = 0; i < NWQ; ++i) store_w(i, Wd);
+        for (int i = 0; i < NWQ_; ++i) store_w(i, Wd);
     };
 
     f32x16 acc[TM][TN];
@@ -188,7 +272,11 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
 
     // lane bases of the MFMA operand reads
     const int h = lane >> 5;
+#if MOGAN_X6
+    const int abase = (wm * TM * 32 + (lane & 31)) * WROW + h * NGRP * 16;       // bytes
+#else
     const int abase = (wm * TM * 32 + (lane & 31)) * LDW + h * KHW;
+#endif
     int bbase[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
@@ -207,13 +295,40 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
             if constexpr (!DB) load_chunk(c + 1);   // branch-free body (one basic block): a chunk past the end reads harmless data
             else if (more) load_chunk(c + 1);
             const float* Xc = Xs + cur * XSZ;
-            const float* Wc = Wl + cur * WSZ;
+            const wlds_t* Wc = Wl + cur * WSZ_;
             float* Xn = Xs + (cur ^ (NBUF - 1)) * XSZ;
-            float* Wn = Wl + (cur ^ (NBUF - 1)) * WSZ;
+            wlds_t* Wn = Wl + (cur ^ (NBUF - 1)) * WSZ_;
             // k-steps (channel pair c2, tap kh, kw) in groups of eight = one mma_k16 (mogan_mma.h); a short last group is
             // padded with zeros
 #pragma unroll
             for (int g = 0; g < NGRP; ++g) {
+#if MOGAN_X6
+                // A: the pre-split filter fragments, one 16-byte read per piece; B: eight halo values, split in registers
+                X6Frag fa[TM], fb[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fa[t].p[pl] = __builtin_bit_cast(mma_bf16x8, *(const uint4*)(Wc + abase + t * 32 * WROW + (pl * 2 * NGRP + g) * 16));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    float b8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int step = 8 * g + i;                         // compile-time after unrolling
+                        const int c2 = step / KHW, tap = step % KHW, kh = tap / KW, kw = tap % KW;
+                        b8[i] = step < NSTEP
+                            ? Xc[bbase[t] + 2 * c2 * CPL + kh * WWP + (S == 2 ? (kw & 1) * (WWP / 2) + (kw >> 1) : kw)] : 0.f;
+                    }
+                    fb[t] = x6_split8(b8);
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < TN; ++tb) acc[ta][tb] = x6_mfma(fa[ta], fb[tb], term, acc[ta][tb]);
+#else
                 float a[TM][8], b[TN][8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -227,6 +342,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
                             ? Xc[bbase[t] + 2 * c2 * CPL + kh * WWP + (S == 2 ? (kw & 1) * (WWP / 2) + (kw >> 1) : kw)] : 0.f;
                 }
                 mma_k16<TM, TN>(a, b, acc);
+#endif
                 if constexpr (DB) {
                     if (g >= GFIRST && more) {
                         const int s0 = g - GFIRST;
@@ -235,7 +351,7 @@ __global__ __launch_bounds__(256) void dconv_fwd_kernel(const DConvP p) {
                             if (s0 * XPG + j < NXE) store_x(s0 * XPG + j, Xn);
 #pragma unroll
                         for (int j = 0; j < WPG; ++j)
-                            if (s0 * WPG + j < NWQ) store_w(s0 * WPG + j, Wn);
+                            if (s0 * WPG + j < NWQ_) store_w(s0 * WPG + j, Wn);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -595,6 +711,20 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     static const int fwd_target = getenv("MOGAN_DSPLIT_FWD") ? atoi(getenv("MOGAN_DSPLIT_FWD")) : 512;
     if (tiles < 384 && nchunk >= 8) nsplit = (int)std::min<long long>(cdiv(fwd_target, tiles), nchunk / 4);
     const long long y_numel = (long long)p.B * p.Cout * p.yH * p.yW;
+#if MOGAN_X6
+    {   // the filters as bf16 pieces in fragment order, at the head of the workspace (dconv_wprep_kernel)
+        constexpr int NGRP = ((CK / 2) * KH * KW + 7) / 8, PPR = 6 * NGRP;
+        const long long rows = (long long)p.npar * p.Cout;
+        const size_t wpb = (size_t)nchunk * rows * PPR * 16;
+        if (!ws || ws_bytes < wpb + 256 || wpb >= (1ull << 31)) return MOGAN_ERR_WS;
+        const long long total = (long long)nchunk * rows * 2 * NGRP;
+        hipLaunchKernelGGL(dconv_wprep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.Wt, (uint4*)ws, (int)rows,
+                           p.Cin, KH * KW, CK, NGRP, total);
+        p.Wp = ws; p.wp_bytes = (unsigned)wpb;
+        const size_t adv = (wpb + 255) & ~(size_t)255;
+        ws = (char*)ws + adv; ws_bytes -= adv;
+    }
+#endif
     if (nsplit > 1) {
         const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)y_numel)) : 0;
         nsplit = fit < 2 ? 1 : (int)std::min<long long>(nsplit, fit);
@@ -690,12 +820,15 @@ int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin
     p.X = x; p.Wt = w; p.Y = y; p.B = B; p.Cin = Cin; p.Cout = Cout; p.Hs = Hs; p.Ws = Ws; p.H = H; p.W = W; p.up = up;
     p.OH = OH; p.OW = OW; p.pt = ph; p.pl = pw; p.yH = OH; p.yW = OW; p.ys = 1; p.y0 = 0; p.x0 = 0; p.accumulate = 0; p.npar = 1;
     p.x_bytes = 4u * B * Cin * Hs * Ws; p.w_bytes = 4u * Cout * Cin * KH * KW;
-    // 4x4 s2 only at >= 64-pixel rows: measured 124 vs 98 TF (implicit GEMM) at 64x64 output, 98 vs 98 at 32x32 and
-    // 90 vs 98 at 16x16 (more M-blocks re-reading the same halo tile)
-    if (k44 && OW < 64) return 0;
+    // 4x4 s2: round 1 (native fp32 MFMA) took it only at >= 64-pixel rows (124 vs 98 TF against the implicit GEMM at 64x64 output,
+    // 98 vs 98 at 32x32, 90 vs 98 at 16x16: more M-blocks re-reading the same halo tile); with the pre-split filters of the
+    // split-bf16 build it wins down to 16-pixel rows in the step (339.2 / 337.1 vs 337.8 / 335.6 img/s; MOGAN_DCONV_K44_MINOW)
+    static const int k44_min_ow = getenv("MOGAN_DCONV_K44_MINOW") ? atoi(getenv("MOGAN_DCONV_K44_MINOW")) : 16;
+    if (k44 && OW < k44_min_ow) return 0;
     // 4x4 s2: chunks of 4 channels (32 k-steps, like the 36 of a 3x3 chunk of 8) keep the staging registers and the
     // double-buffered LDS images (2 x 36 KB) within two blocks per CU
     const int rc = k44 ? launch_fwd<4, 4, 2, 4>(p, ws, ws_bytes, st) : launch_fwd<3, 3, 1, 8>(p, ws, ws_bytes, st);
+    if (rc == MOGAN_ERR_WS) return 0;       // no room for the prepared filters: the implicit-GEMM path takes it
     return rc ? rc : 1;
 }
 
@@ -729,13 +862,15 @@ int mogan_dconv_dgrad_try(const float* dy, const float* w, float* dx, int B, int
         p.Wt = wt; p.w_bytes = (unsigned)wbytes;
         p.OH = H; p.OW = W; p.pt = KH - 1 - ph; p.pl = KW - 1 - pw; p.ys = 1; p.y0 = 0; p.x0 = 0;
         const int rc = launch_fwd<3, 3, 1, 8>(p, ws2, ws2_bytes, st);
-        return rc ? rc : 1;
+        if (rc == MOGAN_ERR_WS) return 0;       // no room for the prepared filters: the implicit-GEMM path takes it
+    return rc ? rc : 1;
     }
     hipLaunchKernelGGL(wparity_kernel, dim3(nb), dim3(256), 0, st, w, wt, Cout, Cin);
     // the four parity classes run in ONE launch (blockIdx.z): oyb0 = (py+1-kh0)/2 with kh0 = (py+1)&1 -> pt = 1-oyb0
     p.Wt = wt; p.w_bytes = 4u * Cin * Cout * 4; p.npar = 4;
     p.OH = gH; p.OW = gW; p.ys = 2; p.y0 = 0; p.x0 = 0; p.pt = 0; p.pl = 0;
     const int rc = launch_fwd<2, 2, 1, 8>(p, ws2, ws2_bytes, st);
+    if (rc == MOGAN_ERR_WS) return 0;       // no room for the prepared filters: the implicit-GEMM path takes it
     return rc ? rc : 1;
 }
 
@@ -755,5 +890,6 @@ int mogan_dconv_wgrad_try(const float* dy, const float* x, float* dw, int B, int
     p.OH = OH; p.OW = OW; p.pt = ph; p.pl = pw; p.N = Cin * KH * KW; p.accumulate = accumulate;
     p.x_bytes = 4u * B * Cin * Hs * Ws; p.y_bytes = 4u * B * Cout * OH * OW;
     const int rc = k33 ? launch_wgrad<3, 3, 1>(p, ws, ws_bytes, st) : launch_wgrad<4, 4, 2>(p, ws, ws_bytes, st);
+    if (rc == MOGAN_ERR_WS) return 0;       // no room for the prepared filters: the implicit-GEMM path takes it
     return rc ? rc : 1;
 }

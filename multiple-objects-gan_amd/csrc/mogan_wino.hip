@@ -643,6 +643,10 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
                    int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift, int ep_relu,
                    void* ws, size_t ws_bytes, hipStream_t st) {
     if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
+    // MOGAN_WINO_FWD / MOGAN_WINO_DGRAD = 0: forward / data gradient on the direct kernels, the weight gradient stays here
+    static const int fwd_on = getenv("MOGAN_WINO_FWD") ? atoi(getenv("MOGAN_WINO_FWD")) : 1;
+    static const int dg_on = getenv("MOGAN_WINO_DGRAD") ? atoi(getenv("MOGAN_WINO_DGRAD")) : 1;
+    if (!(dgrad ? dg_on : fwd_on)) return 0;
     if (!g_wino || !(KH == 3 && KW == 3 && stride == 1 && ph == pw && (ph == 0 || ph == 1) && up == 0)) return 0;
     const int Kin = dgrad ? Cout : Cin, Kout = dgrad ? Cin : Cout;       // channels the kernel reduces over / produces
     // conv: (H, W) -> (H + 2p - 2); its data gradient runs over dY (the smaller grid) with pad 2 - p and produces (H, W)

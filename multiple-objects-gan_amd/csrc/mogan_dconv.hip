@@ -440,7 +440,20 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
     constexpr int NGRP = NSTEP / 8, GFIRST = NGRP / 2;                     // groups of 8 k-steps (one mma_k16 each)
     constexpr int XPG = (NXE + (NGRP - GFIRST) - 1) / (NGRP - GFIRST), YPG = (NYQ + (NGRP - GFIRST) - 1) / (NGRP - GFIRST);
     static_assert(WM * WN == 4 && BN == 128 && NSTEP % 8 == 0, "tile");
+#if MOGAN_X6
+    // dY tile as bf16 pieces in fragment order: the split happens once per staged value (instead of once per fragment value,
+    // TM x more), an A fragment of a 16-pixel group is one 16-byte read per piece.  Row = [piece][lane half h][group g][8 x bf16]
+    // + 16 B pad = 400 B; pixel p of the tile sits at g = p / 16, h = p & 1, slot (p % 16) / 2.
+    constexpr int YROW = 3 * 2 * (PXK / 16) * 16 + 16, YSZB = BM * YROW;
+    static_assert(PXK == 64, "fragment-order layout of the dY tile");
+    __shared__ __attribute__((aligned(16))) unsigned char Ys[NBUF * YSZB];
+    typedef unsigned char ylds_t;
+    constexpr int YSZ_ = YSZB;
+#else
     __shared__ __attribute__((aligned(16))) float Ys[NBUF * YSZ];
+    typedef float ylds_t;
+    constexpr int YSZ_ = YSZ;
+#endif
     __shared__ __attribute__((aligned(16))) float Xs[NBUF * XSZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -489,7 +502,11 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
         const int row = q / (PXK / 4), p0 = 4 * (q - row * (PXK / 4));
         const int ry = p0 / CW, rxx = p0 - ry * CW;
         yg[i] = m0 + row < p.Cout ? (unsigned)((m0 + row) * p.OH * p.OW + ry * p.OW + rxx) : IDX_OOB;
+#if MOGAN_X6
+        yl[i] = row * YROW + (p0 >> 4) * 16 + ((p0 & 15) >> 1) * 2;      // bytes: group p0/16, slot (p0 % 16) / 2 (even), piece 0, h = 0
+#else
         yl[i] = row * LDY + p0;
+#endif
     }
     float rx[NXE]; f32x4 ry4[NYQ]; f32x4 rxq[NXQ];
     auto load_tile = [&](int t) {
@@ -536,8 +553,20 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
 #endif
     };
     auto store_x = [&](int i, float* Xd) { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; };
-    auto store_y = [&](int i, float* Yd) { *(f32x4*)&Yd[yl[i]] = ry4[i]; };
-    auto store_tile = [&](float* Xd, float* Yd) {
+#if MOGAN_X6
+    auto store_y = [&](int i, ylds_t* Yd) {           // pixels p0, p0+2 -> lane half 0, p0+1, p0+3 -> lane half 1
+        uint32_t w[2][3];
+        x6_split2(ry4[i][0], ry4[i][2], w[0][0], w[0][1], w[0][2]);
+        x6_split2(ry4[i][1], ry4[i][3], w[1][0], w[1][1], w[1][2]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) *(uint32_t*)(Yd + yl[i] + (pl * 2 + hh) * 64) = w[hh][pl];
+    };
+#else
+    auto store_y = [&](int i, ylds_t* Yd) { *(f32x4*)&Yd[yl[i]] = ry4[i]; };
+#endif
+    auto store_tile = [&](float* Xd, ylds_t* Yd) {
         if constexpr (WIDE) {
 #pragma unroll
             for (int i = 0; i < NXQ; ++i) if (ql[i] >= 0) *(f32x4*)&Xd[ql[i]] = rxq[i];
@@ -556,7 +585,11 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+#if MOGAN_X6
+    const int abase = (wm * TM * 32 + (lane & 31)) * YROW + h * 64;          // bytes
+#else
     const int abase = (wm * TM * 32 + (lane & 31)) * LDY + h;
+#endif
     int bbase[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
@@ -576,11 +609,36 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
             if constexpr (PIPE) load_tile(t + 1 < p.ntiles ? t + 1 : t);      // branch-free body (one basic block)
             else if (more) load_tile(t + 1);
             const float* Xc = Xs + cur * XSZ;
-            const float* Yc = Ys + cur * YSZ;
+            const ylds_t* Yc = Ys + cur * YSZ_;
             float* Xn = Xs + (cur ^ (NBUF - 1)) * XSZ;
-            float* Yn = Ys + (cur ^ (NBUF - 1)) * YSZ;
+            ylds_t* Yn = Ys + (cur ^ (NBUF - 1)) * YSZ_;
 #pragma unroll
             for (int g = 0; g < NSTEP / 8; ++g) {
+#if MOGAN_X6
+                X6Frag fa[TM], fb[TN];
+#pragma unroll
+                for (int q = 0; q < TM; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fa[q].p[pl] = __builtin_bit_cast(mma_bf16x8, *(const uint4*)(Yc + abase + q * 32 * YROW + pl * 128 + g * 16));
+#pragma unroll
+                for (int q = 0; q < TN; ++q) {
+                    float b8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int pp = 8 * g + i;                           // pixel pair: compile-time after unrolling
+                        const int ry = (2 * pp) / CW, rxx = (2 * pp) % CW;
+                        b8[i] = Xc[bbase[q] + ry * S * WWP + rxx * S];
+                    }
+                    fb[q] = x6_split8(b8);
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < TN; ++tb) acc[ta][tb] = x6_mfma(fa[ta], fb[tb], term, acc[ta][tb]);
+#else
                 float a[TM][8], b[TN][8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -592,6 +650,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
                     for (int q = 0; q < TN; ++q) b[q][i] = Xc[bbase[q] + ry * S * WWP + rxx * S];
                 }
                 mma_k16<TM, TN>(a, b, acc);
+#endif
                 if constexpr (DBW) {
                     if (g >= GFIRST && more) {
                         const int s0 = g - GFIRST;

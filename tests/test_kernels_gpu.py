@@ -2,7 +2,7 @@
 primitives (oracle/attngan_oracle.py, i.e. the torch-CPU ops the reference composes), evaluated in
 fp64 so that a kernel more accurate than torch-fp32 is not penalised.
 
-Stated tolerances (fp32 kernels, k-ordered fmaf accumulation):
+Stated tolerances (fp32 tensors and accumulators; products on the bf16 MFMA pipe from exact 3-piece splits, csrc/mogan_mma.h):
   conv / bmm outputs      rel-L2 <= 2e-6,  max-abs <= 1e-5 * max|ref|*sqrt(K)/16 (see _check)
   BN / activations / STN / attention / softmax / pooling   max-abs <= 2e-5 (values are O(1))
   Adam                    max-abs <= 1e-6 on O(1) parameters after three steps

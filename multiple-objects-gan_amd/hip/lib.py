@@ -175,21 +175,37 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 # (3,0) 291, (3,>=3) 300.5.  After torch.distributed's RCCL communicator is created (3 streams of its own) the default
 # (4 queues) falls from 299 to 278.  (3 queues, >= 3 idle streams ahead of everything else) is the one plateau that does not
 # move when more streams appear -- 300-301 img/s with and without the process group -- and is what the entry points use.
+#
+# Round 2, split-bf16 kernels (the MFMA kernels 25 % shorter, the arrangement matters more): one process, no process group:
+# (4,0) 357-364 img/s in seven runs on three boxes, (4,2) 361, (3,3) 341-349, (4,1) 329, (4,3) 326-332, (4,4) 350, (5..8, 0)
+# 257-264.  With the RCCL process group of a 1-GPU world: (3,3) 338-342, (4,3) 344-346, (4,0) 324-332.  A single process
+# therefore runs on (4 queues, no idle streams) -- its stream creation order is fixed by this code alone --, a member of a
+# process group keeps the (3 queues, 3 idle streams) plateau, because how many streams RCCL creates on a real multi-GPU
+# node has not been measured by the builder.
 HW_QUEUES_DEFAULT = "3"
 _reserved = []
+
+
+def _single_process():
+    return int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MOGAN_FORCE_DIST")
+
+
+def hw_queue_defaults():
+    """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above)"""
+    return ("4", 0) if _single_process() else (HW_QUEUES_DEFAULT, 3)
 
 
 def configure_hw_queues():
     """Call BEFORE the first HIP call of the process (torch.cuda.set_device, library load): a GPU_MAX_HW_QUEUES set by the
     user wins."""
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", HW_QUEUES_DEFAULT)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", hw_queue_defaults()[0])
 
 
 def reserve_hw_queues(n=None):
     """Call right after torch.cuda.set_device and before any other stream exists: n idle non-blocking HIP streams that
     take the first round of queue slots (MOGAN_RESERVED_STREAMS overrides n; 0 disables)."""
     if n is None:
-        n = int(os.environ.get("MOGAN_RESERVED_STREAMS", "3"))
+        n = int(os.environ.get("MOGAN_RESERVED_STREAMS", str(hw_queue_defaults()[1])))
     if _reserved or n <= 0:
         return
     # through libmogan_hip.so, i.e. in the HIP runtime instance torch itself uses (a second copy of libamdhip64 loaded by

@@ -256,8 +256,6 @@ class TrainEngine:
         # then the weight-gradient streams in the order the branches run (D256, D128, D64, generator), communication
         # streams last -- measured: with the communication streams created in between, the generator's wgrad stream landed
         # on the main stream's queue and the RCCL path ran 12 % slower before a single byte was exchanged
-        self._pad_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("MOGAN_WGRAD_STREAM_PAD", "0")))]   # experiment:
-        # skips pool streams, i.e. shifts the hardware queues of the weight-gradient streams against the branch streams'
         for i in range(len(netsD))[::-1]:
             ops.precreate_wgrad_stream(self.side[i])
         ops.precreate_wgrad_stream(torch.cuda.current_stream())

@@ -2,6 +2,7 @@
 """bench.py -- images/sec of one coco-attngan G+D train step (256x256) on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (re-executes itself under torch.distributed.run, N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -26,6 +27,36 @@ import json
 import os
 import sys
 import time
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become the launcher.  The process is replaced by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
+    <same arguments>` (one rank per GPU, what train.sh:25-29 / trainer.py:296 hand to nn.parallel.data_parallel in the
+    reference), so the scaling run is ONE command either way; rank 0 still prints the one JSON line."""
+    if "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+if __name__ == "__main__":
+    _self_launch()
 
 # The eager multi-stream AttnGAN step runs on a fixed hardware-queue arrangement (mogan_amd/hip/lib.py, "hardware queues":
 # one process 4 queues / no reserved streams, a member of a process group 3 queues / 3 reserved streams); must be in the
@@ -381,7 +412,8 @@ def main():
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         backend = os.environ.get("MOGAN_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d (plain `python bench.py --gpus N` launches its own ranks)" % (
+        world, args.gpus)
 
     set_coco_train_defaults()
     B = args.batch

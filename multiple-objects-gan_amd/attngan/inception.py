@@ -20,6 +20,13 @@ from ..hip import ops
 from .model_base import HipConv2d, HipBatchNorm2d
 
 
+def _versions(*tensors):
+    """(device, storage address, in-place version counter) of every tensor: the key of the frozen encoder's derived-weight
+    caches.  load_state_dict / copy_ / a broadcast into the parameters (TrainEngine.sync_replicas) bump the version
+    counter, .to(device) replaces the storage -- either way the cache is rebuilt instead of serving stale weights."""
+    return tuple((str(t.device), t.data_ptr(), t._version) for t in tensors)
+
+
 class BasicConv2d(nn.Module):
     def __init__(self, cin, cout, **kw):
         super().__init__()
@@ -29,12 +36,13 @@ class BasicConv2d(nn.Module):
 
     def folded(self):
         """eval-mode BN as (scale, shift); cached -- the encoder is frozen."""
-        if self._folded is None or self._folded[0].device != self.bn.weight.device:
+        key = _versions(self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)
+        if self._folded is None or self._folded[2] != key:
             with torch.no_grad():
                 scale = (self.bn.weight / torch.sqrt(self.bn.running_var + self.bn.eps)).contiguous()
                 shift = (self.bn.bias - self.bn.running_mean * scale).contiguous()
-            self._folded = (scale, shift)
-        return self._folded
+            self._folded = (scale, shift, key)
+        return self._folded[:2]
 
     def forward(self, x):
         if self.training:
@@ -619,6 +627,8 @@ class _FrozenTrunkFn(torch.autograd.Function):
 def frozen_trunk(enc, x299):
     """(features 768x17x17, Mixed_7c output 2048x8x8) of the frozen eval-mode trunk of `enc` (a CNN_ENCODER)."""
     ft = getattr(enc, "_frozen_trunk", None)
-    if ft is None or ft.stem["Conv2d_1a_3x3"].w.device != x299.device:
+    key = _versions(*[t for t in list(enc.parameters()) + list(enc.buffers()) if t.is_floating_point()])
+    if ft is None or getattr(enc, "_frozen_trunk_key", None) != key or ft.stem["Conv2d_1a_3x3"].w.device != x299.device:
         ft = enc._frozen_trunk = FrozenTrunk(enc)
+        enc._frozen_trunk_key = key
     return _FrozenTrunkFn.apply(x299, ft)

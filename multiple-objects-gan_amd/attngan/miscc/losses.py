@@ -52,11 +52,29 @@ def _labels_and_mask(labels, class_ids, batch_size, device):
     return labels.to(device=device, dtype=torch.int64).contiguous(), masks
 
 
+def _image_side_only(t, what):
+    """The fused DAMSM kernels differentiate with respect to the IMAGE side only -- in the generator step the text encoder
+    is frozen (trainer.py:281-289).  A caller that wants text-encoder gradients (DAMSM pre-training, pretrain_DAMSM.py: out
+    of scope) must not get silent zeros."""
+    if torch.is_grad_enabled() and t.requires_grad:
+        raise NotImplementedError("%s requires grad: the fused DAMSM losses give gradients to the image features only (the "
+                                  "text encoder is frozen in the GAN train step); detach() the text embeddings" % what)
+
+
+def _damsm_shape_check(C, S, T):
+    """Limits of mogan_damsm_words_* (csrc/mogan_damsm.hip): T <= 32 words, S <= 640 regions, 64 KB of LDS."""
+    lds = 4 * (C * T + T * (S + 1) + 3 * 10 * 32 + 4 * 32)
+    if T > 32 or S > 640 or lds > 64 * 1024:
+        raise ValueError("words_loss: caption length T=%d (<= 32), region count S=%d (<= 640) or the kernel's LDS need of "
+                         "%d bytes (<= 65536; nef=%d) exceed the fused DAMSM kernels' limits" % (T, S, lds, C))
+
+
 def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8):
     """losses.py:20-59: cosine matrix of the image / sentence codes * gamma3 and cross-entropy both ways, fused
     (mogan_damsm_sent_* + mogan_damsm_ce_*: 2 launches forward, 2 backward).  Gradient: cnn_code."""
     if labels is None:
         return None, None
+    _image_side_only(rnn_code, "sent_loss: rnn_code")
     lab, masks = _labels_and_mask(labels, class_ids, batch_size, cnn_code.device)
     return ops.damsm_sent(cnn_code, rnn_code.detach(), lab, masks, cfg.TRAIN.SMOOTH.GAMMA3, eps)
 
@@ -70,6 +88,8 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
     B = batch_size
     ih, iw = img_features.shape[2], img_features.shape[3]
     dev = img_features.device
+    _image_side_only(words_emb, "words_loss: words_emb")
+    _damsm_shape_check(img_features.shape[1], ih * iw, words_emb.shape[2])
     lens = cap_lens.to(dev).to(torch.int32).reshape(B).contiguous()
     lab, masks = _labels_and_mask(labels, class_ids, B, dev)
     l0, l1, a2 = ops.damsm_words(img_features, words_emb.detach(), lens, lab, masks, cfg.TRAIN.SMOOTH.GAMMA1,

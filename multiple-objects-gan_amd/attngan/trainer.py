@@ -93,14 +93,30 @@ class FlatAdam:
         """Accepts torch.optim.Adam's {'state', 'param_groups'} (reference checkpoints, and what state_dict() emits) and
         the flat {'step', 'exp_avg', 'exp_avg_sq'} layout of round-1 checkpoints."""
         if "state" in sd:
+            # torch.optim.Adam fills `state` lazily (a parameter that never received a gradient has no entry) and keys it by
+            # the ids of param_groups[*]["params"], in the order of the parameter list the optimizer was built over -- the
+            # reference builds it over ALL netG.parameters() (trainer.py:137-148), this bucket over the trainable ones.
             st = sd["state"]
-            if len(st) not in (0, len(self.params)):
-                raise ValueError("optimizer state has %d entries, the network %d parameters" % (len(st), len(self.params)))
+            ids = [i for g in sd.get("param_groups") or [] for i in g.get("params", [])]
+            if not ids:
+                ids = list(range(len(self.params)))
+            if len(ids) == len(self.params):
+                targets = list(zip(self.params, self.offsets))
+            else:
+                allp = list(self.module.parameters())
+                if len(ids) != len(allp):
+                    raise ValueError("optimizer state covers %d parameters, the network has %d (%d trainable)"
+                                     % (len(ids), len(allp), len(self.params)))
+                off = {id(p): o for p, o in zip(self.params, self.offsets)}
+                targets = [(p, off.get(id(p))) for p in allp]
             step = 0.0
-            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-                e = st.get(i, st.get(str(i)))
-                if e is None:
-                    continue
+            for key, (p, o) in zip(ids, targets):
+                e = st.get(key, st.get(str(key)))
+                if e is None or o is None:
+                    continue                                  # no moments saved / not trainable here: zeros stay
+                if e["exp_avg"].numel() != p.numel() or e["exp_avg_sq"].numel() != p.numel():
+                    raise ValueError("optimizer state entry %s has %d elements, the parameter %d"
+                                     % (key, e["exp_avg"].numel(), p.numel()))
                 self.m[o:o + p.numel()].copy_(e["exp_avg"].reshape(-1))
                 self.v[o:o + p.numel()].copy_(e["exp_avg_sq"].reshape(-1))
                 step = max(step, float(e["step"]))
@@ -171,12 +187,37 @@ class ChunkedReducer:
                     self.chunk_of[base + 4 * o] = ci
                     self.members[ci].append(base + 4 * o)
         self.expected, self.counts, self.done, self.launched, self.early = None, {}, [], set(), 0
-        self.active = False
-        ops.GRAD_HOOKS.append((base, base + 4 * flat.numel, self.hit))
+        self.active, self.late = False, []
+        # registered through a weak reference: the process-global hook list must not keep a dropped engine (and its flat
+        # buckets, 2.5 GB for D_NET256) alive; close() / garbage collection of the reducer removes the entry
+        import weakref
+        ref = weakref.ref(self)
+
+        def _hit(ptr, stream, _ref=ref):
+            me = _ref()
+            if me is not None:
+                me.hit(ptr, stream)
+        self._hook = (base, base + 4 * flat.numel, _hit)
+        ops.GRAD_HOOKS.append(self._hook)
+        weakref.finalize(self, ChunkedReducer._unhook, self._hook)
         flat.on_zero = self.begin
+
+    @staticmethod
+    def _unhook(hook):
+        try:
+            ops.GRAD_HOOKS.remove(hook)
+        except ValueError:
+            pass
+
+    def close(self):
+        """Detach from hip/ops.GRAD_HOOKS and from the bucket (idempotent)."""
+        ChunkedReducer._unhook(self._hook)
+        if getattr(self.flat, "on_zero", None) == self.begin:
+            self.flat.on_zero = None
 
     def begin(self):
         self.counts, self.done, self.launched, self.active, self.early = {}, [], set(), True, 0
+        self.late = []
 
     def hit(self, ptr, stream):
         if not self.active:
@@ -185,7 +226,10 @@ class ChunkedReducer:
         if self.expected is None:
             return
         ci = self.chunk_of.get(ptr)
-        if ci is None or ci in self.launched:
+        if ci is None:
+            return
+        if ci in self.launched:
+            self.late.append(ptr)            # a contribution queued AFTER the chunk's all-reduce: see finish()
             return
         if all(self.counts.get(q, 0) >= self.expected.get(q, 1 << 30) for q in self.members[ci]):
             self._launch(ci)
@@ -211,10 +255,22 @@ class ChunkedReducer:
         """after the backward (and the weight-gradient join): reduce the chunks not yet on their way, then make the current
         stream wait for all of them"""
         self.active = False
+        if self.late:
+            # the call pattern of this backward had MORE contributions for a parameter than the learned schedule: its chunk
+            # was summed over the ranks before the last weight gradient was queued, the bucket now holds a mix of reduced
+            # and local terms and the replicas would drift apart silently.  There is no cheap repair (the peers' late terms
+            # are gone into their own mixes), so this is an error; construct the engine with MOGAN_DP_CHUNK_MB=0 (whole-
+            # bucket all-reduce after the backward) for models whose backward is not the same every step.
+            n = len(self.late)
+            self.expected, self.late = None, []
+            raise RuntimeError("ChunkedReducer: %d gradient contribution(s) arrived after their chunk's all-reduce had been "
+                               "issued (the backward's call pattern changed between steps); gradients of this step are "
+                               "inconsistent across ranks.  Set MOGAN_DP_CHUNK_MB=0 for this model." % n)
         if self.expected is None:
             self.expected = dict(self.counts)                  # calibration step
         elif any(self.counts.get(q, 0) != n for q, n in self.expected.items()):
-            self.expected = dict(self.counts)                  # the call pattern changed: re-learn, reduce the rest now
+            self.expected = dict(self.counts)                  # FEWER contributions than learned (no chunk left early on
+            #                                                    stale counts): re-learn, the rest is reduced below
         for ci in range(len(self.chunks)):
             if ci not in self.launched:
                 self._launch(ci)
@@ -285,8 +341,9 @@ class TrainEngine:
                 if b.dim() > 0:
                     dist.broadcast(b, src)
             for p in net.parameters():
-                if not p.requires_grad:                       # frozen encoders: not in any bucket
-                    dist.broadcast(p.data, src)
+                if not p.requires_grad:                       # frozen encoders: not in any bucket.  On the parameter itself
+                    with torch.no_grad():                     # (not .data): the in-place version counter must move, the
+                        dist.broadcast(p, src)                # encoder's derived-weight caches are keyed on it
         dist.broadcast(self.bn_counter.flat, src)
 
     # -- data parallel: sum all-reduce of a flat gradient bucket over RCCL on a side stream ----------

@@ -31,6 +31,14 @@ def build(force=False, verbose=True):
     hdr = os.path.join(os.path.dirname(HERE), "include", "mogan_hip.h")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    # the flag set is part of the build's identity (MOGAN_CFLAGS=-DMOGAN_X6=0 switches the arithmetic form of every
+    # kernel): objects compiled with other flags are stale whatever their mtimes say
+    stamp = os.path.join(objdir, "flags.stamp")
+    flagline = " ".join(FLAGS + EXTRA)
+    if not os.path.exists(stamp) or open(stamp).read() != flagline:
+        force = True
+        with open(stamp, "w") as f:
+            f.write(flagline)
     srcs = sources()
     hdrs = [hdr] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]

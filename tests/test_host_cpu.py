@@ -236,3 +236,31 @@ def test_flat_adam_state_dict_is_torch_adam_layout_and_roundtrips():
     flat2 = FlatAdam(net, lr=2e-4)
     flat2.load_state_dict({"step": 3.0, "exp_avg": flat.m.clone(), "exp_avg_sq": flat.v.clone(), "lr": 2e-4})   # round-1 layout
     assert torch.equal(flat2.m, flat.m) and float(flat2.state[0]) == 3.0
+
+
+def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` (N > 1) without a launcher environment replaces itself by torch.distributed.run with N
+    ranks on 127.0.0.1 and the same arguments; with RANK/WORLD_SIZE set (the driver's own launch) or N = 1 it does nothing."""
+    import sys
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index('if __name__ == "__main__":\n    _self_launch()')]
+    ns = {"__file__": os.path.join(ROOT, "bench.py")}
+    exec(compile(head, "bench_head", "exec"), ns)
+    got = []
+    monkeypatch.setattr(ns["os"], "execv", lambda exe, argv: got.append((exe, argv)))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    ns["_self_launch"]()
+    assert len(got) == 1
+    argv = got[0][1]
+    assert argv[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in argv
+    assert argv[argv.index("--nproc-per-node") + 1] == "8" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and argv[-7].endswith("bench.py")
+    del got[:]
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus=1"])
+    ns["_self_launch"]()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.setenv("RANK", "0")
+    ns["_self_launch"]()
+    assert got == []

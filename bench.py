@@ -170,11 +170,9 @@ def roofline_leg(engine, run_step, steps=2):
         if m < 4:
             name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)])
         elif int(m) == 6:
-            name = {1: "wino_wgrad_kernel", 2: "wino22_wgrad_kernel"}.get(int(c), "dconv_wgrad_kernel")
+            name = "wino_wgrad_kernel" if int(c) == 1 else "dconv_wgrad_kernel"
         elif int(c) == 1:       # fused Winograd F(2x2,3x3): flops = the 16/36 of the direct multiplies it executes
             name = "wino_fwd_kernel<%s>" % MODES[int(m)][6:]
-        elif int(c) == 2:       # fused Winograd F(2x2,2x2) of the 4x4 s2 convolutions: 9/16 of the direct multiplies
-            name = "wino22_kernel<%s>" % MODES[int(m)][6:]
         else:
             name = "dconv_fwd_kernel<%s>" % MODES[int(m)][6:]
         rows.append(dict(kernel=name,

@@ -23,7 +23,7 @@
  *     mogan_gemm_set_split_target / mogan_stream_set_split_target) and the tuned (tile, split-K) table
  *     (mogan_gemm_tune_set), both read under a mutex -- results do not depend on them beyond the
  *     summation order across K-splits; plus the test / measurement hooks marked as such below
- *     (mogan_gemm_debug_force, mogan_wino22_debug_min_tiles, mogan_prof_*), which are process-wide and
+ *     (mogan_gemm_debug_force, mogan_prof_*), which are process-wide and
  *     not meant for concurrent use.
  */
 #ifndef MOGAN_HIP_H
@@ -75,10 +75,6 @@ int mogan_gemm_tune_clear(void);
  * the device and before any other stream exists, so that its own streams (and RCCL's) land on the queues in the measured
  * arrangement ("hardware queues").  Returns the number of streams held, or a negative error. */
 int mogan_reserve_streams(int n);
-
-/* test hook: the 4x4-s2 Winograd kernel is only taken from `n` 2x2-output tiles on (default 1024, -1 restores it); the
- * kernel tests lower it to cover small shapes */
-int mogan_wino22_debug_min_tiles(int n);
 
 /* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
 int mogan_gemm_debug_force(int cfg, int split);

@@ -27,14 +27,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+OUT_F32 = os.path.join(HERE, "libmogan_hip_f32.so")
+
+
+def _build_variant(out, objdir, extra, force=False, verbose=True):
     hdr = os.path.join(os.path.dirname(HERE), "include", "mogan_hip.h")
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    # the flag set is part of the build's identity (MOGAN_CFLAGS=-DMOGAN_X6=0 switches the arithmetic form of every
-    # kernel): objects compiled with other flags are stale whatever their mtimes say
+    # the flag set is part of the build's identity (-DMOGAN_X6=0 switches the arithmetic form of every kernel): objects
+    # compiled with other flags are stale whatever their mtimes say
     stamp = os.path.join(objdir, "flags.stamp")
-    flagline = " ".join(FLAGS + EXTRA)
+    flagline = " ".join(FLAGS + extra)
     if not os.path.exists(stamp) or open(stamp).read() != flagline:
         force = True
         with open(stamp, "w") as f:
@@ -46,22 +48,37 @@ def build(force=False, verbose=True):
     def cc(pair):
         src, obj = pair
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("MOGAN_BUILD_JOBS", "6"))) as ex:
         list(ex.map(cc, zip(srcs, objs)))
-    if force or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if force or _stale(out, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
+
+
+def build(force=False, verbose=True):
+    """libmogan_hip.so: the product library (split-bf16 form of the MFMA kernels unless MOGAN_CFLAGS says otherwise)."""
+    return _build_variant(OUT, os.path.join(HERE, "build"), EXTRA, force, verbose)
+
+
+def build_f32(force=False, verbose=True):
+    """libmogan_hip_f32.so: the same sources with -DMOGAN_X6=0, i.e. every MFMA kernel on the native v_mfma_f32_32x32x2_f32.
+    Not loaded by the product; it is the reference point of the precision claims (tools/diag_x6_precision.py) and is kept
+    under test by tests/test_kernels_gpu.py::test_native_fp32_mfma_build (MOGAN_LIB selects it)."""
+    return _build_variant(OUT_F32, os.path.join(HERE, "build_f32"), ["-DMOGAN_X6=0"], force, verbose)
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(OUT)
+    if "--f32" in sys.argv:
+        build_f32(force="--force" in sys.argv)
+        print(OUT_F32)

@@ -529,10 +529,6 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
                 rxq[i] = ldg4(rX, ok ? qpre[i] + qbase : PRE_BAD);
             }
         } else
-#if defined(LAB) && (LAB == 1 || LAB == 3)
-#pragma unroll
-        for (int i = 0; i < NXE; ++i) rx[i] = (float)i;
-#else
         if (!PIPE && interior) {
 #pragma unroll
             for (int i = 0; i < NXE; ++i) rx[i] = ldg(rX, pre[i] + sbase);
@@ -543,14 +539,8 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
                 rx[i] = ldg(rX, ok ? pre[i] + sbase : PRE_BAD);
             }
         }
-#endif
 #pragma unroll
-        for (int i = 0; i < NYQ; ++i)
-#if defined(LAB) && (LAB == 2 || LAB == 3)
-            ry4[i] = f32x4{1.f, 2.f, 3.f, (float)i};
-#else
-            ry4[i] = ldg4(rY, yg[i] == IDX_OOB ? IDX_OOB : yb + yg[i]);
-#endif
+        for (int i = 0; i < NYQ; ++i) ry4[i] = ldg4(rY, yg[i] == IDX_OOB ? IDX_OOB : yb + yg[i]);
     };
     auto store_x = [&](int i, float* Xd) { if (xl[i] >= 0) Xd[xl[i]] = rx[i]; };
 #if MOGAN_X6
@@ -678,16 +668,12 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
                 }
 #endif
             }
-#if defined(LAB) && LAB == 4
-            // lab: no store phase, no barriers (stale LDS)
-#else
             __syncthreads();
             if constexpr (DBW) {
                 cur ^= 1;
             } else {
                 if (more) { store_tile(Xs, Ys); __syncthreads(); }
             }
-#endif
         }
     }
 

@@ -159,12 +159,8 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
         if (n0 >= Ncls) return;     // block-uniform
         kh0 = (py + p.ph) % p.s; kw0 = (px + p.pw) % p.s;
     }
-#ifdef MOGAN_NO_DG44      // lab: A/B of the vector weight loads below
-    const bool dg44 = false;
-#else
     const bool dg44 = MODE == CONV_DGRAD && p.s == 2 && p.KH == 4 && p.KW == 4 && (p.K & 3) == 0 &&
                       (((uintptr_t)p.A) & 15) == 0;
-#endif
     // FWD / DGRAD: the QB rows (pixels) this thread stages are fixed: decode them once
     bool nvalid[QB]; unsigned nbase[QB]; int ny0[QB], nx0[QB];
     if constexpr (MODE == CONV_FWD) {
@@ -228,10 +224,7 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
 
     float ra[QA][4], rb[QB][4];
     constexpr int NEA = QA * 4, NEB = QB * 4, NE = NEA + NEB;     // elements staged per thread per K-tile
-#ifndef MOGAN_NSL
-#define MOGAN_NSL (MOGAN_X6 ? 12 : 16)
-#endif
-    constexpr int NSL = MOGAN_NSL;                                // slices: the first NSL of the 16 k-steps carry
+    constexpr int NSL = MOGAN_X6 ? 12 : 16;                              // slices: the first NSL of the 16 k-steps carry
     constexpr int EPS = (NE + NSL - 1) / NSL;                     // the gather, the rest cover the load latency
 
     // per-quad / per-tile decode kept in registers between the element slices
@@ -624,7 +617,6 @@ __device__ __forceinline__ unsigned xcd_order(unsigned L, unsigned total) {
 template <int MODE, int WM, int WN, int TM, int TN, bool AVEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-#if !defined(LAB) || LAB != 9
     {
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         const unsigned V = xcd_order(bx + gx * (by + gy * bz), total);
@@ -641,7 +633,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             by = t2 % gy; bz = t2 / gy;
         }
     }
-#endif
     gemm_block<MODE, WM, WN, TM, TN, AVEC>(p, bx, by, bz);
 }
 
@@ -1073,12 +1064,6 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
-    if (g_force_cfg < 0) {          // 4x4 s2 p1: fused Winograd F(2x2,2x2) on the four input phases (9 instead of 16 multiplies)
-        mogan_prof_begin(4, 2, (9.0 / 16.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
-        rc = mogan_wino22_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
-        mogan_prof_end(rc == 1, stream);
-        if (rc != 0) return rc < 0 ? rc : 0;
-    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(4, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
         rc = mogan_dconv_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
@@ -1236,12 +1221,6 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
-    if (g_force_cfg < 0) {
-        mogan_prof_begin(5, 2, (9.0 / 16.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
-        rc = mogan_wino22_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
-        mogan_prof_end(rc == 1, stream);
-        if (rc != 0) return rc < 0 ? rc : 0;
-    }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(5, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
         rc = mogan_dconv_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
@@ -1293,12 +1272,6 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
     if (g_force_cfg < 0) {
         mogan_prof_begin(6, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, Cin * KH * KW, B * p.OH * p.OW, stream);
         rc = mogan_wino_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);
-        mogan_prof_end(rc == 1, stream);
-        if (rc != 0) return rc < 0 ? rc : 0;
-    }
-    if (g_force_cfg < 0) {
-        mogan_prof_begin(6, 2, (9.0 / 16.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, Cin * KH * KW, B * p.OH * p.OW, stream);
-        rc = mogan_wino22_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }

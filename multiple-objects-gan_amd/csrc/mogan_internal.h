@@ -31,15 +31,6 @@ MOGAN_HIDDEN int mogan_wino_try(const float* in, const float* w, float* out, int
 MOGAN_HIDDEN int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
                                       int KH, int KW, int stride, int ph, int pw, int up, int accumulate, void* ws,
                                       size_t ws_bytes, hipStream_t st);
-// fused Winograd F(2x2,2x2) for the 4x4 s2 p1 convolutions (mogan_wino22.hip)
-MOGAN_HIDDEN int mogan_wino22_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Cout, int KH,
-                                      int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st);
-MOGAN_HIDDEN int mogan_wino22_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, int Cout,
-                                        int KH, int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes,
-                                        hipStream_t st);
-MOGAN_HIDDEN int mogan_wino22_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
-                                        int KH, int KW, int stride, int ph, int pw, int up, int accumulate, void* ws,
-                                        size_t ws_bytes, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_end(int taken, hipStream_t st);
 MOGAN_HIDDEN extern int mogan_use_dconv;

@@ -34,9 +34,6 @@ typedef __bf16 mma_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x6_split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
     const mma_f32x2 x = {x0, x1};
     p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, mma_bf16x2));
-#ifdef MOGAN_X6_FAKE      // lab: timing of the kernels without the split arithmetic (wrong results)
-    p2 = p1 ^ 1u; p3 = p1 ^ 2u; return;
-#endif
     const mma_f32x2 r = {x0 - __uint_as_float(p1 << 16), x1 - __uint_as_float(p1 & 0xFFFF0000u)};
     p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, mma_bf16x2));
     const mma_f32x2 s = {r[0] - __uint_as_float(p2 << 16), r[1] - __uint_as_float(p2 & 0xFFFF0000u)};

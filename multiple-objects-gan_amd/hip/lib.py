@@ -24,7 +24,6 @@ SIGNATURES = {
     "mogan_gemm_debug_force": [I, I],
     "mogan_gemm_group_min_tiles": [I],
     "mogan_mfma_form": [],
-    "mogan_wino22_debug_min_tiles": [I],
     "mogan_gemm_tune_set": [I, I, I, I, I, I, I],
     "mogan_gemm_tune_clear": [],
     "mogan_reserve_streams": [ctypes.c_int],

@@ -1,5 +1,5 @@
 """Diagnostic: coco_s2 generator gradients vs the reference fixture (tests/test_stackgan_gpu.py::test_networks), per parameter:
-checksum error relative to the abs-sum.  Run with the default library and with MOGAN_LIB=tools/lab/libmogan_f32.so."""
+checksum error relative to the abs-sum.  Run with the default library and with MOGAN_LIB=multiple-objects-gan_amd/libmogan_hip_f32.so."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,8 +1,8 @@
 """Accuracy of the loaded library's MFMA kernels against fp64 on the bench geometries and on adversarial data.
 
-Run it twice -- default library (split-bf16 form, csrc/mogan_mma.h) and MOGAN_LIB=tools/lab/libmogan_f32.so (native
+Run it twice -- default library (split-bf16 form, csrc/mogan_mma.h) and MOGAN_LIB=multiple-objects-gan_amd/libmogan_hip_f32.so (native
 fp32-MFMA form) -- and compare the columns: both carry fp32 rounding only if the numbers agree to within a small factor.
-    python tools/diag_x6_precision.py            # implicit-GEMM + direct kernels (MOGAN_WINO=0 MOGAN_WINO22=0 set here)
+    python tools/diag_x6_precision.py            # implicit-GEMM + direct kernels (MOGAN_WINO=0 set here)
     python tools/diag_x6_precision.py wino       # default dispatch (Winograd kernels where eligible)
 Data sets: "normal" = N(0,1) activations, He-scaled weights; "wide" = every value multiplied by 2^U(-20,20) (products of
 very different magnitude in one sum); "cancel" = x and -x interleaved along the reduction with 1e-4 relative noise (the
@@ -12,7 +12,6 @@ import sys
 
 if "wino" not in sys.argv[1:]:
     os.environ["MOGAN_WINO"] = "0"
-    os.environ["MOGAN_WINO22"] = "0"
 import torch
 import torch.nn.functional as F
 

@@ -18,7 +18,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("gemm_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel", "wino_fwd_kernel", "wino_wgrad_kernel", "wino22_wgrad_kernel", "wino22_kernel")
+KEEP = ("gemm_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel", "wino_fwd_kernel", "wino_wgrad_kernel")
 
 
 def short(name):
@@ -26,7 +26,7 @@ def short(name):
     m = re.search(r"(gemm_kernel|dconv_fwd_kernel|dconv_wgrad_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
-    for k in ("wino_fwd_kernel", "wino_wgrad_kernel", "wino22_wgrad_kernel", "wino22_kernel"):
+    for k in ("wino_fwd_kernel", "wino_wgrad_kernel"):
         if k in name:
             return k + "<>"
     return None

@@ -1,6 +1,6 @@
 """Which kernel should take which convolution?  Records every convolution launch geometry of one B=16 coco-attngan step
 (entry point + integer arguments, with its count), then times each one in isolation through the library's dispatch as
-configured by the environment of THIS process (MOGAN_WINO, MOGAN_WINO22, MOGAN_DCONV, ... are read once per process):
+configured by the environment of THIS process (MOGAN_WINO, MOGAN_DCONV, ... are read once per process):
 
     python tools/time_conv_layers.py out.csv          # one row per geometry: count, microseconds, GFLOP
 

@@ -25,6 +25,18 @@
  *     summation order across K-splits; plus the test / measurement hooks marked as such below
  *     (mogan_gemm_debug_force, mogan_prof_*), which are process-wide and
  *     not meant for concurrent use.
+ *
+ * Arithmetic.  fp32 in, fp32 out, fp32 accumulators everywhere.  In the default build the MFMA kernels (convolutions, bmm)
+ * form every product a*b on the bf16 matrix pipe from the exact three-piece bf16 split of both operands (csrc/mogan_mma.h:
+ * six partial products, the dropped ones <= 2^-23 |a b|), mogan_mfma_form() == 6.  Measured against fp64 this is within
+ * +-25 % of the native fp32 MFMA (libmogan_hip_f32.so, mogan_mfma_form() == 1) on ordinary and on wide-dynamic-range data;
+ * the forward error bound  |err| <= 2^-24 * sum |a||b|  holds in every measured case, but under engineered cancellation
+ * (result ~1e-4 of the terms) the error relative to the tiny RESULT is up to 17x the native form's, whose fma chain profits
+ * from the exact cancellation of adjacent terms (profiles/r02_precision_*.txt).  Input domain of the split form:
+ * |x| <= 3.3895e38 (the largest bf16; larger finite values and +-inf give inf / NaN where the native form may stay finite);
+ * |x| >= 2^-110 or 0 for full accuracy (below, the third / second piece drops under the smallest normal bf16 and the product
+ * keeps 16 / 8 significant bits -- on values whose products are below fp32's normal range anyway).
+ * tests/test_kernels_gpu.py::test_fp32_products_on_the_bf16_pipe_* keep these statements under test.
  */
 #ifndef MOGAN_HIP_H
 #define MOGAN_HIP_H

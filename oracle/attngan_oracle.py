@@ -98,6 +98,7 @@ def res_block(net, pre, x):
 
 
 LRELU_MASKS = None      # test hook, see lrelu
+LRELU_FLIPS = None      # test hook: list of (decisions that differ from the oracle's own sign, decisions, max |x| among them)
 
 
 def lrelu(x):
@@ -108,6 +109,10 @@ def lrelu(x):
     if LRELU_MASKS is not None:
         m = LRELU_MASKS.pop(0)
         assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+        if LRELU_FLIPS is not None:      # an imposed mask must only differ where x is within rounding of the kink
+            diff = m != (x.detach() > 0)
+            n = int(diff.sum())
+            LRELU_FLIPS.append((n, x.numel(), float(x.detach()[diff].abs().max()) if n else 0.0))
         return torch.where(m, x, 0.2 * x)
     return F.leaky_relu(x, 0.2)
 

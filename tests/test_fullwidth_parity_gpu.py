@@ -159,12 +159,20 @@ def test_full_width_gnet_forward_and_dnet256_loss_backward():
         rep[k] = max_abs(a, b)
         assert rep[k] <= 1e-4, "%s differs from the fp64 oracle by %.3e" % (k, rep[k])
     O.LRELU_MASKS = [(t > 0).cpu() for a, t in trace if a == ops.ACT_LRELU]
+    O.LRELU_FLIPS = []
     try:
         # the same fake image as the HIP pass (so that the decisions belong to the same function)
         oerr = O.discriminator_loss(2, od, c64["imgs"][2], imgs[2].detach().cpu().to(dt), c64["sent_emb"], c64, ocfg)
         assert len(O.LRELU_MASKS) == 0, "%d LeakyReLU launches were not consumed by the oracle" % len(O.LRELU_MASKS)
+        flips = O.LRELU_FLIPS
     finally:
-        O.LRELU_MASKS = None
+        O.LRELU_MASKS = O.LRELU_FLIPS = None
+    # the imposed decisions may differ from the oracle's own only at pre-activations within fp32 rounding of zero: a handful
+    # of the ~2e7 decisions of the two passes, each at |x| <= 1e-5 (a wrong mask would otherwise be inherited silently)
+    nflip, ndec = sum(f[0] for f in flips), sum(f[1] for f in flips)
+    assert nflip <= 16 and max(f[2] for f in flips) <= 1e-5, \
+        "%d of %d imposed LeakyReLU decisions differ from the fp64 oracle's (largest |x| %.3e)" % (
+            nflip, ndec, max(f[2] for f in flips))
     oerr.backward()
     assert abs(float(errD.detach()) - float(oerr.detach())) <= 1e-5 * abs(float(oerr.detach()))
     worst = (0.0, "")

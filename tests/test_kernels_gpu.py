@@ -482,6 +482,37 @@ def test_fp32_products_on_the_bf16_pipe_hold_the_fp32_error_bound(layer, kind):
             assert bound <= 2.0 ** -24, "cancel fwd: max err / sum|a||b| = %.2e" % bound
 
 
+def test_fp32_products_on_the_bf16_pipe_input_domain():
+    """The edges of the split form's input domain (include/mogan_hip.h, "Arithmetic"): (huge) |x| up to the largest bf16
+    value 3.3895e38 is exact like everything else -- here 3.0e38 against weights of 1e-3, finite fp32 results; beyond it (up
+    to FLT_MAX = 3.4028e38, and +-inf) the first piece rounds to infinity and the result is inf / NaN, never a silently wrong
+    finite number; (tiny) inputs down to 2^-100 keep all three pieces normal bf16 numbers: rel-L2 <= 1e-6; below ~2^-110 the
+    third (then the second) piece falls under the smallest normal bf16 and the result degrades gracefully towards the 8 / 16
+    bits of the remaining pieces -- at 2^-118: rel-L2 <= 2^-12 -- on numbers whose squares are far below fp32's range."""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, Cout = 2, 64, 8, 64
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.125
+    run = lambda a, b: ops.conv2d_forward(a.to(DEV), b.to(DEV), 1, 0, 0, 0).cpu().double()
+    ref = lambda a, b: F.conv2d(a.double(), b.double())
+    # huge but representable first pieces
+    xs = torch.sign(x) * 3.0e38
+    ws = w * 1e-3 / 64
+    y = run(xs, ws)
+    assert torch.isfinite(y).all() and rel_l2(y, ref(xs, ws)) <= 1e-6
+    # beyond the largest bf16: non-finite, not wrong-but-finite
+    xs2 = xs.clone()
+    xs2[0, 0, 0, 0] = 3.4e38
+    y2 = run(xs2, ws)
+    assert not torch.isfinite(y2[0, :, 0, 0]).any(), "a value above the bf16 range must poison its outputs"
+    assert torch.isfinite(y2[1]).all()
+    # tiny values
+    y3 = run(x * 2.0 ** -100, w)
+    assert rel_l2(y3, ref(x * 2.0 ** -100, w)) <= 1e-6
+    y4 = run(x * 2.0 ** -118, w)
+    assert rel_l2(y4, ref(x * 2.0 ** -118, w)) <= 2.0 ** -12
+
+
 def test_native_fp32_mfma_build():
     """The second build variant of the same sources (-DMOGAN_X6=0: every MFMA kernel on the native v_mfma_f32_32x32x2_f32,
     libmogan_hip_f32.so, built by __graft_entry__.build()) is the reference point of the precision claims in DESIGN.md

@@ -168,6 +168,33 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
                        int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,
                        hipStream_t stream);
 
+/* ---- Weight-heavy convolutions on pre-split "panels" (csrc/mogan_pgemm.hip): the deep discriminator layers
+ * (code/coco/attngan/model.py:594-613, 616-642, 738-760) are GEMMs with 768..3072 x 6144..27648 weights against a few hundred
+ * pixels.  Their weights change once per optimizer step but are used by the real, the fake and the generator pass, so the
+ * caller keeps -- next to the fp32 master -- a PACKED copy per direction: the three bf16 pieces of every weight (see
+ * "Arithmetic" above) in the order the matrix instruction consumes them.  The convolution entry points below read the packed
+ * copy with plain 16-byte loads and pack the activations per call into the workspace (channels-last bf16 pieces); results are
+ * the same fp32 products as mogan_conv2d_fwd / mogan_conv2d_dgrad up to the summation order.
+ *   mogan_pk_conv_eligible   1 if the geometry meets the panel formats' constraints (forward: Cin % 32 == 0; data gradient:
+ *                            Cout % 32 == 0, KH, KW, Hs, Ws multiples of the stride) AND the layer is weight-heavy enough for
+ *                            the path to pay (<= 64 output pixels per image and parity class, K >= 1024, >= 128 rows); else 0
+ *   mogan_pk_weight_bytes    size of the packed copy for one direction (dgrad = 0 forward, 1 data gradient); 0 = not packable
+ *   mogan_pk_weight_pack     w (Cout,Cin,KH,KW) fp32 -> packed copy; the caller re-packs after every change of w (it owns the
+ *                            buffer and the bookkeeping: the library keeps no weight state)
+ *   mogan_conv2d_fwd_pk      y = conv2d(x, w) from the forward-packed weights;  workspace: B*Hs*Ws*Cin*6 bytes + split-K slabs
+ *   mogan_conv2d_dgrad_pk    dx = conv2d data gradient from the dgrad-packed weights; workspace: B*OH*OW*Cout*6 bytes + slabs
+ *   mogan_pk_debug_force     test hook (process-wide): take_all != 0 drops the size heuristic of mogan_pk_conv_eligible (hard
+ *                            constraints stay); cfg in 0..2 forces a tile shape (-1 = heuristic), split > 0 a K-split count */
+int mogan_pk_conv_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int dgrad);
+size_t mogan_pk_weight_bytes(int Cout, int Cin, int KH, int KW, int stride, int dgrad);
+int mogan_pk_weight_pack(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int stride, int ph, int pw, int dgrad,
+                         hipStream_t stream);
+int mogan_conv2d_fwd_pk(const float* x, const void* wpk, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                        int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream);
+int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                          int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream);
+int mogan_pk_debug_force(int take_all, int cfg, int split);
+
 /* nn.Upsample(scale_factor=2, mode='nearest') + conv3x3(padding 1, no bias) -- every upBlock of the reference
  * (code/coco/attngan/model.py:48-55, code/coco/stackgan/model.py:16-22) -- evaluated as the TRANSPOSED 4x4
  * stride-2 pad-1 convolution with kernel K = T w T^t, T = [[0,0,1],[0,1,1],[1,1,0],[1,0,0]]: each phase of the

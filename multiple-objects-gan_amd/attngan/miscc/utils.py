@@ -44,6 +44,8 @@ def weights_init(m):
 def load_params(model, new_param):
     for p, new_p in zip(model.parameters(), new_param):
         p.data.copy_(new_p)
+    from ...hip import ops
+    ops.invalidate_all_packs()           # packed weight copies (hip/ops.WeightPacks) follow the new values at their next use
 
 
 def copy_G_params(model):

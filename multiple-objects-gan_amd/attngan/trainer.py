@@ -63,6 +63,24 @@ class FlatAdam:
             p.grad = self.g[o:o + p.numel()].view_as(p)
         self.ema = self.p.clone() if with_ema else None
         self.state = torch.zeros(3, dtype=torch.float32, device=dev)     # device-resident step counter
+        # packed copies of the convolution weights (hip/ops.WeightPacks, csrc/mogan_pgemm.hip): created lazily by the layers
+        # that qualify, re-packed here after every change of the bucket
+        self._pk_cell = [0]
+        self.packs = [ops.attach_packs(p, self._pk_cell) for p in self.params if p.dim() == 4] if dev.type == "cuda" else []
+        if isinstance(module, torch.nn.Module):
+            module.register_load_state_dict_post_hook(lambda m, keys: self.touch())
+
+    def touch(self):
+        """the bucket's parameters were written (load_state_dict, a broadcast, a restore): packed copies are rebuilt at
+        their next use"""
+        self._pk_cell[0] += 1
+
+    def repack(self):
+        """the same, but the copies in use are rebuilt NOW on the current stream -- after the optimizer step (one pack per
+        weight version) and wherever a replayed hipGraph will use the copies without a pack node of its own"""
+        self._pk_cell[0] += 1
+        for pk in self.packs:
+            pk.repack()
 
     on_zero = None          # set by ChunkedReducer: a new accumulation round of this bucket begins
 
@@ -74,6 +92,7 @@ class FlatAdam:
     def step(self, grad_scale=1.0):
         ops.adam_step(self.p, self.g, self.m, self.v, self.ema, self.lr, 0.5, 0.999, 1e-8,
                       dev_state=self.state, eps_mode=self.eps_mode, grad_scale=grad_scale)
+        self.repack()
 
     def ema_params(self):
         return [self.ema[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
@@ -132,6 +151,7 @@ class FlatAdam:
         """Replica synchronisation: rank `src`'s parameters, EMA shadow, moments and step counter to every rank."""
         for t in (self.p, self.m, self.v, self.state) + ((self.ema,) if self.ema is not None else ()):
             dist.broadcast(t, src)
+        self.touch()
 
 
 def allreduce_flat(flat_g, comm_stream=None):
@@ -614,6 +634,8 @@ class TrainEngine:
     def _restore(self, snap):
         for t, s in zip(self._state_tensors(), snap):
             t.copy_(s)
+        for o in [self.optG] + self.optDs:
+            o.repack()
 
     # -- hipGraph capture of device_step ---------------------------------------------------------------
     _GRAPH_KEYS = ("z", "eps", "words_embs", "sent_emb", "mask", "cap_lens", "tm", "tmi", "label_one_hot",

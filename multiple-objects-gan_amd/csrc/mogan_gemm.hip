@@ -737,6 +737,12 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 
 }  // namespace
+void mogan_splitk_reduce_dense(const float* ws, float* out, long long n, int nsplit, int accumulate, hipStream_t st) {
+    ReduceP q{};
+    q.n = n; q.slab = n; q.nsplit = nsplit; q.acc = accumulate;
+    q.Mcms = n; q.cms = n; q.ybs = n; q.msplit = 0x7fffffff;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ws, out, q);
+}
 int mogan_use_dconv = 1;
 static ProfRec g_prof_open; static bool g_prof_open_valid = false;
 void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st) {
@@ -782,6 +788,10 @@ struct TuneHash { size_t operator()(const TuneKey& k) const {
     return h * 7 + (size_t)k.nz; } };
 static std::unordered_map<TuneKey, std::pair<int, int>, TuneHash> g_tuned;
 static std::mutex g_tuned_mu;
+
+}  // namespace
+int mogan_split_target(hipStream_t st) { return split_target_of(st); }
+namespace {
 
 static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, size_t ws_bytes, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return 0;
@@ -1024,7 +1034,7 @@ int mogan_prof_dump(const char* path) {
 // out: rows of 5 doubles {mode, cfg, launches, algorithmic flops, milliseconds}, one per (mode,cfg) seen
 int mogan_prof_collect(double* out, int max_rows) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    double acc[7][NCFG][3] = {};
+    double acc[9][NCFG][3] = {};
     for (auto& r : g_prof) {
         hipEventSynchronize(r.e1);
         float ms = 0.f;
@@ -1034,7 +1044,7 @@ int mogan_prof_collect(double* out, int max_rows) {
     }
     g_prof.clear();
     int n = 0;
-    for (int m = 0; m < 7; ++m)
+    for (int m = 0; m < 9; ++m)
         for (int c = 0; c < NCFG; ++c)
             if (acc[m][c][0] > 0 && n < max_rows) {
                 double* o = out + 5 * n++;

@@ -31,6 +31,10 @@ MOGAN_HIDDEN int mogan_wino_try(const float* in, const float* w, float* out, int
 MOGAN_HIDDEN int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
                                       int KH, int KW, int stride, int ph, int pw, int up, int accumulate, void* ws,
                                       size_t ws_bytes, hipStream_t st);
+// out[i] = (accumulate ? out[i] : 0) + sum_s ws[s * n + i], i < n, fixed order (the split-K slabs of a dense output)
+MOGAN_HIDDEN void mogan_splitk_reduce_dense(const float* ws, float* out, long long n, int nsplit, int accumulate, hipStream_t st);
+// split-K block target of a launch on `st` (mogan_gemm_set_split_target / mogan_stream_set_split_target)
+MOGAN_HIDDEN int mogan_split_target(hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_end(int taken, hipStream_t st);
 MOGAN_HIDDEN extern int mogan_use_dconv;

@@ -1,0 +1,522 @@
+// mogan_pgemm.hip -- "panel" implicit GEMM for the weight-heavy convolutions (the deep layers of the discriminators).
+//
+// The deep D layers are GEMMs with a huge weight operand and few columns (768..3072 x 6144..27648 weights against N = B*OH*OW
+// = 240..1024 pixels).  In gemm_kernel both operands are gathered as fp32 and split into their three bf16 pieces (mogan_mma.h)
+// every time a K-tile is staged: 144 split + 176 gather VALU instructions per 48 MFMAs, and the weights -- which change once
+// per optimizer step but are used by the real, fake and generator passes -- are split again in every launch.  Here both
+// operands arrive PRE-SPLIT, in the order the matrix instruction consumes them:
+//
+//   weights      "A panels", written once per weight version by wpack_kernel (mogan_pk_weight_pack):
+//                [class][m-tile of 32 rows][k-step of 16][piece 3][lane 64][8 bf16].  One (m-tile, k-step, piece) is the
+//                1 KB A operand of one v_mfma_f32_32x32x16_bf16 in lane order, so a wave streams the weights of its rows
+//                with coalesced 16-byte loads STRAIGHT INTO REGISTERS (no LDS, no VALU); every weight byte is read by
+//                exactly one wave of a block.  K runs tap-major: k = (kh*KW + kw)*C + c.
+//   activations  "pixel panels", written per call by apack_kernel into the workspace: channels-last bf16 pieces
+//                [pixel][channel group of 32][piece 3][32 bf16] (192 contiguous bytes per pixel and K-tile).  Because K is
+//                tap-major a K-tile of 32 is ONE tap and 32 consecutive channels, so the im2col gather of a row is a copy of
+//                192 contiguous bytes from the pixel (oy*s - p + kh, ox*s - p + kw): twelve lanes per row, 16-byte loads,
+//                16-byte LDS stores, ~8 VALU instructions of address arithmetic per chunk and NO materialised im2col matrix.
+//
+// pgemm_kernel<TM, TN>: 4 waves, wave w owns rows [w*TM*32, (w+1)*TM*32) x all TN*32 columns of the block tile; the pixel
+// panel tile goes through LDS (208-byte rows, double buffered, one barrier per K-tile of 32), weights by direct loads one
+// K-tile ahead; per 16 k a wave issues TM*3 global loads, TN*3 ds_read_b128 and TM*TN*6 MFMAs.  Forward: rows = Cout.
+// Data gradient: one GEMM per stride-parity class (rows = Cin, K = Cout * taps of the class), all classes in one launch.
+// Split-K slabs + mogan_splitk_reduce as in gemm_kernel (deterministic).
+//
+// Replaces (reference = stock torch ops): nn.Conv2d forward / backward-data of the deep discriminator layers,
+// code/coco/attngan/model.py:594-613 (downBlock, Block3x3_leakRelu), 616-642 (D_GET_LOGITS jointConv), 738-760 (D_NET256).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include "../../include/mogan_hip.h"
+#include "mogan_internal.h"
+#include "mogan_mma.h"
+#include <type_traits>
+#ifndef PK_NSET
+#define PK_NSET 3
+#endif
+#define PK_TRIP (PK_NSET == 2 ? 2 : 6)      // K-tiles per trip of the main loop
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PkP {
+    const unsigned char* A;      // weight panels (class 0)
+    const unsigned char* P;      // pixel panels
+    float* C; float* ws;
+    int M, N, K;                 // per class
+    int Mt, KS;                  // ceil(M / 32), K / 16
+    unsigned long long a_cls_stride;
+    unsigned a_bytes, p_bytes;
+    int ntile, kt_per, nsplit;   // K-tiles of 32 in all, per split
+    long long slab;
+    int accumulate;
+    int dgrad, ncls;
+    int Cc, CG;                  // channels of the pixel panel, Cc / 32
+    int PH, PW;                  // image dims of the pixel panel
+    int RH, RW;                  // rows n -> (img, r, c) with r < RH, c < RW
+    int s, ph, pw, nkw;          // nkw: taps per class along x (tap = ta * nkw + tb)
+    int outH, outW;              // dims of the output image
+    int gx, gy;
+};
+
+__device__ __forceinline__ unsigned xcd_order(unsigned L, unsigned total) {
+    const unsigned k = L & 7u, j = L >> 3, q = total >> 3, r = total & 7u;
+    return k * q + (k < r ? k : r) + j;
+}
+
+__device__ __forceinline__ uint4 ldg16(__amdgpu_buffer_rsrc_t r, unsigned off, bool ok) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : 0xFFFFFFF0u, 0, 0));
+}
+
+template <int TM, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) {
+    constexpr int BM = 4 * TM * 32, BN = TN * 32, RS = 208;
+    constexpr int NCH = BN * 12 / 256;                 // 16-byte chunks of the pixel panel tile per thread and K-tile
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * RS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // block -> (n-tile, class, m-tile, K-split); n fastest, then the class: the blocks that stream the same weight rows
+    // (the n-tiles; for a strided data gradient the classes read interleaved taps of the same filters) sit on one XCD
+    unsigned V = xcd_order(blockIdx.x, gridDim.x);
+    const unsigned bx = V % p.gx; V /= p.gx;
+    const unsigned cls = V % p.ncls; V /= p.ncls;
+    const unsigned by = V % p.gy;
+    const int sp = V / p.gy;
+    const int n0 = bx * BN, m0 = by * BM;
+    const int t_beg = sp * p.kt_per, t_end = min(p.ntile, t_beg + p.kt_per);
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + cls * p.a_cls_stride), (short)0,
+                                                                         (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)p.P, (short)0, (int)p.p_bytes, 0x00020000);
+
+    // rows of the pixel panel tile this thread stages (fixed over the K loop)
+    int py = 0, px = 0, kh0 = 0, kw0 = 0;
+    if (p.dgrad) { py = cls / p.s; px = cls % p.s; kh0 = (py + p.ph) % p.s; kw0 = (px + p.pw) % p.s; }
+    const int RHW = p.RH * p.RW;
+    int ry[NCH], rx[NCH]; unsigned pb[NCH]; unsigned ldso[NCH], cho[NCH]; bool rok[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + 256 * i, row = c / 12, ch = c - row * 12;
+        const int n = n0 + row;
+        rok[i] = n < p.N;
+        const int nn = rok[i] ? n : 0;
+        const int img = nn / RHW, rem = nn - img * RHW;
+        const int r = rem / p.RW, cc = rem - r * p.RW;
+        if (p.dgrad) { ry[i] = (r * p.s + py + p.ph - kh0) / p.s; rx[i] = (cc * p.s + px + p.pw - kw0) / p.s; }
+        else { ry[i] = r * p.s - p.ph; rx[i] = cc * p.s - p.pw; }
+        pb[i] = (unsigned)img * (unsigned)(p.PH * p.PW);
+        ldso[i] = row * RS + ch * 16;
+        cho[i] = ch * 16;                                  // the same offset inside the pixel's 192-byte group
+    }
+    const unsigned pixb = (unsigned)p.Cc * 6u;          // bytes per pixel in the panel
+    const int sgn = p.dgrad ? -1 : 1;
+
+    // weight stream of this wave: m-tile mt -> byte offset of its k-step 0, plus this lane's 16 bytes
+    unsigned abase[TM]; bool aok[TM];
+#pragma unroll
+    for (int ta = 0; ta < TM; ++ta) {
+        const int mt = (m0 >> 5) + wave * TM + ta;
+        aok[ta] = mt < p.Mt;
+        abase[ta] = (unsigned)mt * (unsigned)p.KS * 3072u + (unsigned)lane * 16u;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // A operands of one K-tile (2 k-steps x TM tiles x 3 pieces): NSET register sets, the loads run NSET - 1 K-tiles ahead of
+    // the MFMAs that consume them (a K-tile lasts ~0.4 us at three waves per SIMD; an HBM round trip under load is longer)
+    constexpr int NSET = PK_NSET;
+    uint4 ra[NSET][2][TM][3];
+    uint4 rb[NCH];
+
+    // Loads past the end of this block's K range are issued all the same, at out-of-range offsets (the buffer unit returns
+    // zeros): the loop body has no branch, and a trailing odd K-tile multiplies zeros.  (Uniform `if (more) load` branches
+    // made the register sets phi nodes: 64 accumulator-file copies per trip.)
+    auto load_a = [&](int t, uint4 (&ra)[2][TM][3]) {
+        const bool live = t < t_end;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    ra[s2][ta][pl] = ldg16(rA, abase[ta] + (unsigned)((t * 2 + s2) * 3 + pl) * 1024u, aok[ta] & live);
+    };
+    auto load_b = [&](int t) {
+        const bool live = t < t_end;
+        const int tap = t / p.CG, cg = t - tap * p.CG;           // uniform
+        const int ta = tap / p.nkw, tb = tap - ta * p.nkw;
+        const int dy = sgn * ta, dx = sgn * tb;
+        const unsigned goff = (unsigned)cg * 192u;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int iy = ry[i] + dy, ix = rx[i] + dx;
+            const bool ok = (int)rok[i] & (int)live & (int)((unsigned)iy < (unsigned)p.PH) & (int)((unsigned)ix < (unsigned)p.PW);   // no short circuit
+            unsigned off = (pb[i] + (unsigned)(iy * p.PW + ix)) * pixb + goff + cho[i];
+            asm volatile("" : "+v"(off));      // keep the address arithmetic unconditional: otherwise it is sunk behind an
+            rb[i] = ldg16(rP, off, ok);        // exec-mask branch per chunk instead of one v_cndmask
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *(uint4*)(&Bs[buf][ldso[i]]) = rb[i];
+    };
+    const int brow = (lane & 31) * RS + (lane >> 5) * 16;
+    // column tile by column tile: the three pieces of B tile tb + 1 are read from LDS while the TM * 6 MFMAs of tile tb run, so
+    // only two B fragments are live; every accumulator still receives its six partial products smallest first
+    auto read_b = [&](int buf, int s2, int tb) {
+        X6Frag f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            f.p[pl] = __builtin_bit_cast(mma_bf16x8, *(const uint4*)(&Bs[buf][brow + tb * 32 * RS + pl * 64 + s2 * 32]));
+        return f;
+    };
+    auto compute = [&](int buf, const uint4 (&ra)[2][TM][3]) {
+        X6Frag fb = read_b(buf, 0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            X6Frag fa[TM];
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fa[ta].p[pl] = __builtin_bit_cast(mma_bf16x8, ra[s2][ta][pl]);
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb) {
+                const X6Frag cur = fb;
+                if (tb + 1 < TN) fb = read_b(buf, s2, tb + 1);
+                else if (s2 == 0) fb = read_b(buf, 1, 0);
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int ta = 0; ta < TM; ++ta) acc[ta][tb] = x6_mfma(fa[ta], cur, term, acc[ta][tb]);
+            }
+        }
+    };
+
+    // (No early exit inside a trip: a `break` between the stages gives the loop several exits with different live register
+    // sets and the allocator answers with hundreds of spills.  Tiles past t_end load zeros -- see load_a -- and the host rounds
+    // the K range of a split to a multiple of the trip length.)
+    // one K-tile: B tile t + 1 to registers, A tile t + NSET - 1 to its register set, the MFMAs of tile t, B tile t + 1 to the
+    // other LDS buffer.  SET / BUF are compile-time so that every register set is named statically.
+    auto stage = [&](auto SET, auto BUF, int t) {
+        constexpr int S = decltype(SET)::value, Bf = decltype(BUF)::value;
+        load_b(t + 1);
+        load_a(t + NSET - 1, ra[(S + NSET - 1) % NSET]);
+        compute(Bf, ra[S]);
+        store_b(Bf ^ 1);
+        __syncthreads();
+    };
+    if (t_beg < t_end) {
+        load_b(t_beg);
+#pragma unroll
+        for (int j = 0; j < NSET - 1; ++j) load_a(t_beg + j, ra[j]);
+        store_b(0);
+        __syncthreads();
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        if constexpr (NSET == 2) {
+            for (int t = t_beg; t < t_end; t += 2) {
+                stage(I0{}, I0{}, t);
+                stage(I1{}, I1{}, t + 1);
+            }
+        } else {
+            using I2 = std::integral_constant<int, 2>;
+            for (int t = t_beg; t < t_end; t += 6) {
+                stage(I0{}, I0{}, t);
+                stage(I1{}, I1{}, t + 1);
+                stage(I2{}, I0{}, t + 2);
+                stage(I0{}, I1{}, t + 3);
+                stage(I1{}, I0{}, t + 4);
+                stage(I2{}, I1{}, t + 5);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const bool split = p.nsplit > 1;
+    float* __restrict__ slab = p.ws + (size_t)sp * p.slab;
+    const bool addc = !split && p.accumulate;
+    const size_t cms = (size_t)p.outH * p.outW;
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int n = n0 + tb * 32 + (lane & 31);
+        const bool nok = n < p.N;
+        const int nn = nok ? n : 0;
+        const int img = nn / RHW, rem = nn - img * RHW;
+        const int r = rem / p.RW, cc = rem - r * p.RW;
+        const size_t pos = p.dgrad ? (size_t)(r * p.s + py) * p.outW + (cc * p.s + px) : (size_t)rem;
+        const size_t cbase = (size_t)img * p.M * cms + pos;
+#pragma unroll
+        for (int ta = 0; ta < TM; ++ta) {
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int m = m0 + (wave * TM + ta) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+                if (nok && m < p.M) {
+                    float v = acc[ta][tb][r16];
+                    float* dst = (split ? slab : p.C) + cbase + (size_t)m * cms;
+                    if (addc) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pack kernels
+// NCHW fp32 -> channels-last bf16 pieces: P[q = (img, y, x)][cg][piece][32].  Block = 32 channels x 64 pixels.
+__global__ __launch_bounds__(256) void apack_kernel(const float* __restrict__ x, unsigned char* __restrict__ P, int Bn, int C,
+                                                    int HW) {
+    __shared__ float L[32][65];
+    const int tid = threadIdx.x;
+    const long long Q = (long long)Bn * HW;
+    const long long q0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = tid + 256 * j, cl = e >> 6, ql = e & 63;
+        const long long q = q0 + ql;
+        float v = 0.f;
+        if (q < Q) {
+            const long long img = q / HW, pix = q - img * HW;
+            v = x[(img * C + c0 + cl) * HW + pix];
+        }
+        L[cl][ql] = v;
+    }
+    __syncthreads();
+    const int ql = tid >> 2, g8 = tid & 3;
+    const long long q = q0 + ql;
+    if (q >= Q) return;
+    uint32_t w[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x6_split2(L[g8 * 8 + 2 * j][ql], L[g8 * 8 + 2 * j + 1][ql], w[0][j], w[1][j], w[2][j]);
+    unsigned char* d = P + ((size_t)q * (C >> 5) + blockIdx.y) * 192 + g8 * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *(uint4*)(d + pl * 64) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
+// W (Cout, Cin, KH, KW) fp32 -> weight panels.  Block = 32 rows (m) x 16 channels (c) x all taps through LDS: coalesced
+// reads of the fp32 master, 16-byte stores of whole lane slots.  dgrad = 0: m = co, c = ci, k = tap * Cin + ci.
+// dgrad = 1: m = ci, c = co; tap (kh, kw) belongs to the stride-parity class (py, px) with (py + ph) % s == kh % s and is its
+// tap (a, b) = (kh / s, kw / s): k = (a * nkw + b) * Cout + co.
+struct WpackP { const float* w; unsigned char* A; int Cout, Cin, KH, KW, s, ph, pw, dgrad, M, Cc, Mt, KS; unsigned long long cls_stride; };
+
+__global__ __launch_bounds__(256) void wpack_kernel(const WpackP p) {
+    extern __shared__ float L[];                       // [tap][32 m][17]
+    const int tid = threadIdx.x;
+    const int KHW = p.KH * p.KW;
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 16;
+    const int total = 32 * 16 * KHW;
+    for (int e = tid; e < total; e += 256) {
+        int mi, cl, tap; size_t src;
+        if (!p.dgrad) {
+            mi = e / (16 * KHW); const int rem = e - mi * 16 * KHW;
+            cl = rem / KHW; tap = rem - cl * KHW;
+            src = ((size_t)(m0 + mi) * p.Cin + c0) * KHW + rem;
+        } else {
+            cl = e / (32 * KHW); const int rem = e - cl * 32 * KHW;
+            mi = rem / KHW; tap = rem - mi * KHW;
+            src = ((size_t)(c0 + cl) * p.Cin + m0) * KHW + rem;
+        }
+        L[(tap * 32 + mi) * 17 + cl] = (m0 + mi < p.M) ? p.w[src] : 0.f;
+    }
+    __syncthreads();
+    const int nkw = p.KW / p.s;
+    for (int it = tid; it < KHW * 64; it += 256) {
+        const int tap = it >> 6, lane = it & 63, mi = lane & 31, h = lane >> 5;
+        const float* v = &L[(tap * 32 + mi) * 17 + 8 * h];
+        uint32_t w[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x6_split2(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+        int cls = 0, ktap = tap;
+        if (p.dgrad) {
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int py = ((kh - p.ph) % p.s + p.s) % p.s, px = ((kw - p.pw) % p.s + p.s) % p.s;
+            cls = py * p.s + px;
+            ktap = (kh / p.s) * nkw + (kw / p.s);
+        }
+        const int ks = (ktap * p.Cc + c0) >> 4;
+        unsigned char* d = p.A + (size_t)cls * p.cls_stride + ((size_t)blockIdx.x * p.KS + ks) * 3072 + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *(uint4*)(d + pl * 1024) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int g_pk_force = 0;       // test hook: 1 = take every shape that meets the hard constraints
+
+struct PkGeom { int ncls, nkh, nkw, M, Cc, K, Mt, KS; unsigned long long cls_bytes; };
+
+// hard constraints of the panel formats (independent of any size heuristic)
+static bool pk_geom(int Cout, int Cin, int KH, int KW, int s, int dgrad, PkGeom& g) {
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || s <= 0) return false;
+    if (!dgrad) {
+        if (Cin % 32) return false;
+        g.ncls = 1; g.nkh = KH; g.nkw = KW; g.M = Cout; g.Cc = Cin;
+    } else {
+        if (Cout % 32 || KH % s || KW % s) return false;
+        g.ncls = s * s; g.nkh = KH / s; g.nkw = KW / s; g.M = Cin; g.Cc = Cout;
+    }
+    if (KH * KW > 25) return false;                     // LDS tile of wpack_kernel
+    g.K = g.nkh * g.nkw * g.Cc;
+    g.Mt = (int)cdiv(g.M, 32); g.KS = g.K / 16;
+    g.cls_bytes = (unsigned long long)g.Mt * g.KS * 3072ull;
+    return g.cls_bytes < (1ull << 32);
+}
+
+// tile shapes (block = 128 * tm rows x 32 * tn columns).  Measured on the deep D layers at B = 16 (tools/time_pk.py): 128 x 64 at
+// three waves per SIMD wins on every layer (the kernel is latency bound: 256 x 128 at one wave per SIMD ran at half its rate),
+// so the heuristic takes it unless a larger tile has clearly less padding; the others stay reachable for tuning / tests
+struct PkCfg { int tm, tn; };
+static const PkCfg kPk[] = {{1, 2}, {1, 4}, {2, 2}};
+enum { NPK = 3 };
+static int g_pk_cfg = -1, g_pk_split = 0;
+
+// OCC = waves per SIMD the register allocation is held to (512 / OCC registers per lane)
+template <int TM, int TN, int OCC>
+static void launch_pk(unsigned blocks, hipStream_t st, const PkP& p) {
+    hipLaunchKernelGGL((pgemm_kernel<TM, TN, OCC>), dim3(blocks), dim3(256), 0, st, p);
+}
+
+static int run_pk(PkP& p, void* ws, size_t ws_bytes, int prof_mode, hipStream_t st) {
+    // tile: least padded work; 128-row tiles (two blocks per CU) need ~30 % more LDS traffic per MFMA than 256-row tiles
+    int best = 0; double bestw = 1e300;
+    for (int c = 0; c < NPK; ++c) {
+        const int bm = 128 * kPk[c].tm, bn = 32 * kPk[c].tn;
+        double w = (double)cdiv(p.M, bm) * bm * (double)cdiv(p.N, bn) * bn;
+        w *= c == 0 ? 1.0 : 1.15;
+        if (w < bestw * 0.999) { bestw = w; best = c; }
+    }
+    if (g_pk_cfg >= 0) best = g_pk_cfg;
+    const int bm = 128 * kPk[best].tm, bn = 32 * kPk[best].tn;
+    p.gx = (int)cdiv(p.N, bn); p.gy = (int)cdiv(p.M, bm);
+    const long long tiles = (long long)p.gx * p.gy * p.ncls;
+    const long long c_numel = (long long)p.slab;
+    int nsplit = 1;
+    // blocks per launch as gemm_kernel's split-K aims at (768 alone on the GPU, 384 in the multi-stream step)
+    const int target = mogan_split_target(st);
+    if (tiles < target && p.ntile >= 8) {
+        nsplit = (int)cdiv(target, tiles);
+        nsplit = std::min(nsplit, p.ntile / 4);
+        if (nsplit < 1) nsplit = 1;
+    }
+    if (g_pk_split > 0) nsplit = std::min(g_pk_split, p.ntile);
+    if (nsplit > 1) {
+        const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)c_numel)) : 0;
+        if (fit < 2) nsplit = 1; else nsplit = (int)std::min<long long>(nsplit, fit);
+    }
+    p.kt_per = (int)cdiv(cdiv(p.ntile, nsplit), PK_TRIP) * PK_TRIP;      // whole trips of the K loop (pgemm_kernel)
+    p.nsplit = (int)cdiv(p.ntile, p.kt_per);
+    p.ws = (float*)ws;
+    const long long blocks = tiles * p.nsplit;
+    if (blocks <= 0 || blocks > 0x7fffffff) return MOGAN_ERR_SHAPE;
+    const double flops = 2.0 * (double)p.M * (double)p.N * p.ncls * (double)p.K;
+    mogan_prof_begin(prof_mode, best, flops, p.M, p.N * p.ncls, p.K, st);
+    switch (best) {
+        case 1: launch_pk<1, 4, 2>((unsigned)blocks, st, p); break;
+        case 2: launch_pk<2, 2, 2>((unsigned)blocks, st, p); break;
+        default: launch_pk<1, 2, 3>((unsigned)blocks, st, p); break;
+    }
+    mogan_prof_end(1, st);
+    if (p.nsplit > 1) mogan_splitk_reduce_dense((const float*)ws, p.C, c_numel, p.nsplit, p.accumulate, st);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+static int apack(const float* x, unsigned char* P, int B, int C, int HW, hipStream_t st) {
+    const long long Q = (long long)B * HW;
+    hipLaunchKernelGGL(apack_kernel, dim3((unsigned)cdiv(Q, 64), (unsigned)(C / 32)), dim3(256), 0, st, x, P, B, C, HW);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mogan_pk_debug_force(int take_all, int cfg, int split) {
+    g_pk_force = take_all; g_pk_cfg = (cfg >= 0 && cfg < NPK) ? cfg : -1; g_pk_split = split > 0 ? split : 0;
+    return 0;
+}
+
+int mogan_pk_conv_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int dgrad) {
+    PkGeom g;
+    if (B <= 0 || Hs <= 0 || Ws <= 0 || !pk_geom(Cout, Cin, KH, KW, stride, dgrad, g)) return 0;
+    const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return 0;
+    if (dgrad && (Hs % stride || Ws % stride)) return 0;          // every parity class has the same Hs/s x Ws/s grid
+    // 32-bit byte offsets into the pixel panel
+    const long long pix = dgrad ? (long long)B * OH * OW : (long long)B * Hs * Ws;
+    if (pix * g.Cc * 6 >= (1ll << 32)) return 0;
+    if (g_pk_force) return 1;
+    // weight-heavy GEMMs only: few columns per class, long K, enough rows for the 128/256-row tiles.  Wider layers keep the
+    // direct / Winograd / gather kernels, where packing the activations would cost more than it saves.
+    const int rows_hw = dgrad ? (Hs / stride) * (Ws / stride) : OH * OW;
+    return rows_hw <= 64 && g.K >= 1024 && g.M >= 128;
+}
+
+size_t mogan_pk_weight_bytes(int Cout, int Cin, int KH, int KW, int stride, int dgrad) {
+    PkGeom g;
+    if (!pk_geom(Cout, Cin, KH, KW, stride, dgrad, g)) return 0;
+    return (size_t)g.cls_bytes * g.ncls;
+}
+
+int mogan_pk_weight_pack(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int stride, int ph, int pw, int dgrad,
+                         hipStream_t stream) {
+    PkGeom g;
+    if (!w || !wpk || !pk_geom(Cout, Cin, KH, KW, stride, dgrad, g)) return MOGAN_ERR_SHAPE;
+    WpackP p{};
+    p.w = w; p.A = (unsigned char*)wpk; p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.s = dgrad ? stride : 1;
+    p.ph = ph; p.pw = pw; p.dgrad = dgrad; p.M = g.M; p.Cc = g.Cc; p.Mt = g.Mt; p.KS = g.KS; p.cls_stride = g.cls_bytes;
+    if (g.Cc % 16) return MOGAN_ERR_SHAPE;
+    const size_t lds = (size_t)KH * KW * 32 * 17 * sizeof(float);
+    hipLaunchKernelGGL(wpack_kernel, dim3((unsigned)g.Mt, (unsigned)(g.Cc / 16)), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+int mogan_conv2d_fwd_pk(const float* x, const void* wpk, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                        int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
+    PkGeom g;
+    if (!pk_geom(Cout, Cin, KH, KW, stride, 0, g) || B <= 0) return MOGAN_ERR_SHAPE;
+    const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const size_t pbytes = (size_t)B * Hs * Ws * Cin * 6;
+    if (pbytes >= (1ull << 32) || (long long)B * Cout * OH * OW >= (1ll << 31)) return MOGAN_ERR_SHAPE;
+    if (!ws || ws_bytes < up256(pbytes)) return MOGAN_ERR_WS;
+    apack(x, (unsigned char*)ws, B, Cin, Hs * Ws, stream);
+    PkP p{};
+    p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)ws; p.C = y;
+    p.M = Cout; p.N = B * OH * OW; p.K = g.K; p.Mt = g.Mt; p.KS = g.KS; p.a_cls_stride = g.cls_bytes;
+    p.a_bytes = (unsigned)g.cls_bytes; p.p_bytes = (unsigned)pbytes; p.ntile = g.K / 32; p.slab = (long long)B * Cout * OH * OW;
+    p.accumulate = 0; p.dgrad = 0; p.ncls = 1; p.Cc = Cin; p.CG = Cin / 32; p.PH = Hs; p.PW = Ws; p.RH = OH; p.RW = OW;
+    p.s = stride; p.ph = ph; p.pw = pw; p.nkw = KW; p.outH = OH; p.outW = OW;
+    return run_pk(p, (char*)ws + up256(pbytes), ws_bytes - up256(pbytes), 7, stream);
+}
+
+int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                          int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
+    PkGeom g;
+    if (!pk_geom(Cout, Cin, KH, KW, stride, 1, g) || B <= 0 || Hs % stride || Ws % stride) return MOGAN_ERR_SHAPE;
+    const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const size_t pbytes = (size_t)B * OH * OW * Cout * 6;
+    if (pbytes >= (1ull << 32) || (long long)B * Cin * Hs * Ws >= (1ll << 31)) return MOGAN_ERR_SHAPE;
+    if (!ws || ws_bytes < up256(pbytes)) return MOGAN_ERR_WS;
+    apack(dy, (unsigned char*)ws, B, Cout, OH * OW, stream);
+    PkP p{};
+    p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)ws; p.C = dx;
+    p.M = Cin; p.N = B * (Hs / stride) * (Ws / stride); p.K = g.K; p.Mt = g.Mt; p.KS = g.KS; p.a_cls_stride = g.cls_bytes;
+    p.a_bytes = (unsigned)g.cls_bytes; p.p_bytes = (unsigned)pbytes; p.ntile = g.K / 32; p.slab = (long long)B * Cin * Hs * Ws;
+    p.accumulate = 0; p.dgrad = 1; p.ncls = stride * stride; p.Cc = Cout; p.CG = Cout / 32; p.PH = OH; p.PW = OW;
+    p.RH = Hs / stride; p.RW = Ws / stride; p.s = stride; p.ph = ph; p.pw = pw; p.nkw = g.nkw; p.outH = Hs; p.outW = Ws;
+    return run_pk(p, (char*)ws + up256(pbytes), ws_bytes - up256(pbytes), 8, stream);
+}
+
+}  // extern "C"

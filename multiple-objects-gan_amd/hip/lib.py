@@ -36,6 +36,12 @@ SIGNATURES = {
     "mogan_affine_relu_bwd_out": [P, P, P, P, I, I, I, P],
     "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_wgrad": [P, P, P] + [I] * 12 + [P, Z, P],
+    "mogan_pk_conv_eligible": [I] * 11,
+    "mogan_pk_weight_bytes": [I] * 6,
+    "mogan_pk_weight_pack": [P, P] + [I] * 8 + [P],
+    "mogan_conv2d_fwd_pk": [P, P, P] + [I] * 10 + [P, Z, P],
+    "mogan_conv2d_dgrad_pk": [P, P, P] + [I] * 10 + [P, Z, P],
+    "mogan_pk_debug_force": [I, I, I],
     "mogan_upconv3x3_ws_bytes": [I, I],
     "mogan_upconv3x3_fwd": [P, P, P, I, I, I, I, I, P, Z, P],
     "mogan_upconv3x3_dgrad": [P, P, P, I, I, I, I, I, P, Z, P],
@@ -110,7 +116,7 @@ class ConvDgradArgs(ctypes.Structure):          # MoganConvDgradArgs
                 ("accumulate", I)] + [(k, I) for k in ("B", "Cin", "Hs", "Ws", "Cout", "KH", "KW", "stride", "ph", "pw")]
 
 
-_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z}
+_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
 _lib = None

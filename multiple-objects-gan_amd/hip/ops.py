@@ -183,9 +183,101 @@ def _is_upconv(w_shape, stride, ph, pw, up):
     return UPCONV4 and bool(up) and stride == 1 and ph == 1 and pw == 1 and w_shape[2] == 3 and w_shape[3] == 3
 
 
+# ------------------------------------------------------------------------------- packed weights (csrc/mogan_pgemm.hip)
+# The weight-heavy convolutions (deep discriminator layers) read their filters from a PACKED copy: the three bf16 pieces of
+# every weight in matrix-instruction order, one copy per direction (forward / data gradient).  The copy belongs to the
+# parameter's owner: trainer.FlatAdam attaches a WeightPacks object to every 4-D parameter of its bucket and re-packs the
+# copies in use right after each optimizer step (one pack per weight version, used by the real, the fake and the generator
+# pass); anything else that writes weights calls FlatAdam.touch() / invalidate_all_packs().  A parameter without the
+# attribute (plain modules, the kernel tests' default) takes the unpacked kernels.
+PK_ENABLED = os.environ.get("MOGAN_PK", "1") != "0"
+PK_STATS = {"fwd": 0, "dgrad": 0, "packs": 0}      # launches through the packed path (tests, diagnostics)
+_PK_GLOBAL = [0]
+
+
+def invalidate_all_packs():
+    """Every packed weight copy of the process is stale (weights were written behind the owners' backs: load_state_dict,
+    load_params, a test poking .data); they are rebuilt at their next use."""
+    _PK_GLOBAL[0] += 1
+
+
+class WeightPacks:
+    """Packed copies of ONE convolution weight: slot[dgrad] = [buffer, version, global epoch, geometry, event, stream,
+    packed inside a hipGraph capture]."""
+
+    def __init__(self, w, version_cell=None):
+        self.w = w
+        self.cell = version_cell if version_cell is not None else [0]
+        self.slots = {}
+        self.elig = {}
+
+    def _pack(self, dgrad, slot):
+        Cout, Cin, KH, KW = self.w.shape
+        stride, ph, pw = slot[3]
+        st = stream_ptr()
+        call("mogan_pk_weight_pack", ptr(self.w), slot[0].data_ptr(), Cout, Cin, KH, KW, stride, ph, pw, dgrad, st)
+        slot[1], slot[2] = self.cell[0], _PK_GLOBAL[0]
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[4], slot[5], slot[6] = ev, st, bool(lib._capturing())
+        PK_STATS["packs"] += 1
+
+    def repack(self):
+        """re-pack every copy in use now, on the current stream (the owner just changed the weight)"""
+        for dgrad, slot in self.slots.items():
+            self._pack(dgrad, slot)
+
+    def pointer(self, dgrad, B, Hs, Ws, stride, ph, pw):
+        """device pointer of the packed copy for this call's geometry, or None: take the unpacked kernels"""
+        key = (dgrad, B, Hs, Ws, stride, ph, pw)
+        e = self.elig.get(key)
+        Cout, Cin, KH, KW = self.w.shape
+        if e is None:
+            e = self.elig[key] = bool(lib.load().mogan_pk_conv_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, dgrad))
+        if not e:
+            return None
+        slot = self.slots.get(dgrad)
+        if slot is None:
+            nbytes = int(lib.load().mogan_pk_weight_bytes(Cout, Cin, KH, KW, stride, dgrad))
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.w.device)
+            slot = self.slots[dgrad] = [buf, -1, -1, (stride, ph, pw), None, None, False]
+        elif slot[3] != (stride, ph, pw):
+            return None                                   # one weight, two convolution geometries: not a case of the step
+        if slot[1] != self.cell[0] or slot[2] != _PK_GLOBAL[0]:
+            self._pack(dgrad, slot)
+        elif slot[5] != stream_ptr() and (slot[6] or not lib._capturing()):
+            # packed on another stream: order behind that pack (a capturing stream must not wait for an event recorded
+            # outside its capture -- and need not: the device is synchronised before a capture begins)
+            torch.cuda.current_stream().wait_event(slot[4])
+        return slot[0].data_ptr()
+
+
+def attach_packs(w, version_cell=None):
+    if getattr(w, "_mogan_pk", None) is None:
+        w._mogan_pk = WeightPacks(w, version_cell)
+    return w._mogan_pk
+
+
+def _packed(w, dgrad, B, Hs, Ws, stride, ph, pw, up):
+    if up or not PK_ENABLED:
+        return None
+    pk = getattr(w, "_mogan_pk", None)
+    if pk is None:
+        return None
+    return pk.pointer(dgrad, B, Hs, Ws, stride, ph, pw)
+
+
 def conv2d_forward(x, w, stride, ph, pw, up):
     B, Cin, Hs, Ws = x.shape
     Cout, _, KH, KW = w.shape
+    wp = _packed(w, 0, B, Hs, Ws, stride, ph, pw, up)
+    if wp is not None:
+        OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, 0)
+        y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        wsp, wsn = workspace(x.device)
+        call("mogan_conv2d_fwd_pk", ptr(x), wp, ptr(y), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, wsp, wsn, stream_ptr())
+        PK_STATS["fwd"] += 1
+        return y
     if _is_upconv(w.shape, stride, ph, pw, up):
         y = torch.empty((B, Cout, 2 * Hs, 2 * Ws), dtype=torch.float32, device=x.device)
         wsp, wsn = workspace(x.device)
@@ -203,6 +295,12 @@ def conv2d_dgrad(dy, w, x_shape, stride, ph, pw, up):
     B, Cin, Hs, Ws = x_shape
     Cout, _, KH, KW = w.shape
     wsp, wsn = workspace(dy.device)
+    wp = _packed(w, 1, B, Hs, Ws, stride, ph, pw, up)
+    if wp is not None:
+        dx = torch.empty((B, Cin, Hs, Ws), dtype=torch.float32, device=dy.device)
+        call("mogan_conv2d_dgrad_pk", ptr(dy), wp, ptr(dx), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, wsp, wsn, stream_ptr())
+        PK_STATS["dgrad"] += 1
+        return dx
     if _is_upconv(w.shape, stride, ph, pw, up):          # the gradient comes out at the source resolution
         dx = torch.empty((B, Cin, Hs, Ws), dtype=torch.float32, device=dy.device)
         call("mogan_upconv3x3_dgrad", ptr(dy), ptr(w), ptr(dx), B, Cin, Hs, Ws, Cout, wsp, wsn, stream_ptr())

@@ -144,6 +144,8 @@ class StackGANEngine:
                 self._graph_out = self.device_step(st)
             for t, s in zip(self._state_tensors(), snap):
                 t.copy_(s)
+            for o in (self.optG, self.optD):
+                o.repack()               # the replayed graph uses the packed weight copies without a pack node of its own
         for k, dst in self._static.items():
             dst.copy_(b[k])
         self._graph.replay()

@@ -531,3 +531,63 @@ def test_native_fp32_mfma_build():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
     assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-2000:]
+
+
+PK_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad      (forward needs Cin % 32 == 0, the data gradient Cout % 32 == 0)
+    (4, 64, 8, 8, 96, 4, 2, 1),        # down-convolution 8x8 -> 4x4, four parity classes in the data gradient
+    (3, 96, 16, 16, 160, 4, 2, 1),     # ragged: N = 3*64 = 192 columns, 160 rows (the last m-tile half empty)
+    (16, 128, 4, 4, 64, 3, 1, 1),      # 3x3 s1 on a 4x4 map (jointConv / the last D_NET256 layers), one class
+    (5, 32, 6, 10, 32, 4, 2, 1),       # non-square map, one K-tile per tap, N = 5*15 = 75
+    (2, 64, 8, 8, 64, 1, 1, 0),        # 1x1
+    (15, 64, 4, 4, 32, 3, 1, 1),       # the "wrong pair" batch (B - 1 images): N = 240
+]
+
+
+@pytest.mark.parametrize("case", PK_CASES)
+@pytest.mark.parametrize("force", [(-1, 0), (0, 1), (1, 3), (2, 2), (0, 5)])
+def test_packed_weight_convolution(case, force):
+    """csrc/mogan_pgemm.hip: forward and data gradient from the packed weight copies (mogan_pk_weight_pack,
+    mogan_conv2d_fwd_pk, mogan_conv2d_dgrad_pk) against fp64, every tile shape, with and without K-splits; the weight
+    gradient of the same autograd node takes the unpacked kernels.  The size heuristic of mogan_pk_conv_eligible is switched
+    off (the hard constraints of the panel formats stay) so that small shapes reach the kernels."""
+    B, Cin, H, W, Cout, k, s, pad = case
+    lib.load().mogan_pk_debug_force(1, force[0], force[1])
+    before = dict(ops.PK_STATS)
+    try:
+        x = T("pkx%s" % (case,), (B, Cin, H, W)).requires_grad_(True)
+        w = T("pkw%s" % (case,), (Cout, Cin, k, k), 0.2).requires_grad_(True)
+        ref = F.conv2d(x.double(), w.double(), None, s, pad)
+        g = T("pkg%s" % (case,), ref.shape)
+        ref.backward(g.double())
+        xd = x.detach().to(DEV).requires_grad_(True)
+        wd = w.detach().to(DEV).requires_grad_(True)
+        ops.attach_packs(wd)
+        y = ops.conv2d(xd, wd, None, s, pad, False)
+        y.backward(g.to(DEV))
+        torch.cuda.synchronize()
+        assert ops.PK_STATS["fwd"] == before["fwd"] + 1 and ops.PK_STATS["dgrad"] == before["dgrad"] + 1, \
+            "the packed path was not taken: %s -> %s" % (before, ops.PK_STATS)
+        _check(y, ref, what="fwd")
+        _check(xd.grad, x.grad, what="dgrad")
+        _check(wd.grad, w.grad, what="wgrad")
+        # a changed weight must be re-packed by its owner: same objects, new values
+        with torch.no_grad():
+            wd.mul_(-0.5)
+        wd._mogan_pk.cell[0] += 1                       # what FlatAdam.touch() does
+        y2 = ops.conv2d_forward(xd.detach(), wd, s, pad, pad, 0)
+        torch.cuda.synchronize()
+        _check(y2, -0.5 * ref.detach(), what="fwd after re-pack")
+    finally:
+        lib.load().mogan_pk_debug_force(0, -1, 0)
+
+
+def test_packed_weight_eligibility():
+    """mogan_pk_conv_eligible: the deep discriminator layers of the benchmark qualify, wide / thin / misaligned ones do not."""
+    e = lib.load().mogan_pk_conv_eligible
+    assert e(16, 1536, 8, 8, 3072, 4, 4, 2, 1, 1, 0) == 1 and e(16, 1536, 8, 8, 3072, 4, 4, 2, 1, 1, 1) == 1
+    assert e(16, 3072, 4, 4, 1536, 3, 3, 1, 1, 1, 0) == 1 and e(15, 1024, 4, 4, 768, 3, 3, 1, 1, 1, 1) == 1
+    assert e(16, 96, 128, 128, 192, 4, 4, 2, 1, 1, 0) == 0          # wide: 64x64 outputs
+    assert e(16, 84, 16, 16, 192, 4, 4, 1, 1, 1, 0) == 0            # Cin % 32 != 0
+    assert e(16, 768, 8, 8, 100, 4, 4, 2, 1, 1, 1) == 0             # data gradient: Cout % 32 != 0
+    assert e(16, 64, 8, 8, 64, 4, 4, 2, 1, 1, 0) == 0               # K = 1024 but only 64 rows

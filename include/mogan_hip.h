@@ -195,6 +195,30 @@ int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, in
                           int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream);
 int mogan_pk_debug_force(int take_all, int cfg, int split);
 
+/* Deep block = conv -> BatchNorm2d (training statistics) -> LeakyReLU / ReLU / nothing on a map with B*OH*OW <= 2048 values per
+ * channel (downBlock / Block3x3_leakRelu of the deep discriminator layers, model.py:575-613, 616-642): the packed-weight GEMM
+ * followed by ONE tail kernel that sums the K-split slabs, computes the batch statistics (8 channels per block, a channel's
+ * values stay in registers), updates the running statistics, applies BN + activation and writes the NEXT layer's pixel panel --
+ * 2 launches where conv + split-K reduce + bn_stats (2) + bn_act_fwd + the activation pack took 6; the backward is one tail
+ * kernel (activation + BN backward, d gamma / d beta, the gradient's pixel panel) + the packed data-gradient GEMM.
+ *   forward   x (B,Cin,Hs,Ws) fp32 and/or its pixel panel xpanel (nullable: packed here into the workspace), wpk = forward
+ *             packed weights; outputs y = conv(x) (B,Cout,OH,OW: the BN input, kept for the backward), stats = mean[Cout] |
+ *             invstd[Cout], z = act(BN(y)), zpanel (nullable) = pixel panel of z, mogan_pk_panel_bytes(B, Cout, OH*OW) bytes;
+ *             rmean / rvar updated like nn.BatchNorm (momentum, unbiased variance), nullable
+ *   backward  dz -> dy (B,Cout,OH,OW: gradient at the conv output, what the weight gradient needs), dgamma / dbeta (nullable;
+ *             accumulate != 0 adds), dx (nullable: no data gradient) from wpk_dgrad = data-gradient packed weights
+ * Same arithmetic as mogan_bn_stats / mogan_bn_act_fwd / mogan_bn_act_bwd (fp64 sums). */
+size_t mogan_pk_panel_bytes(int B, int C, int HW);
+int mogan_deep_block_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act);
+int mogan_deep_conv_bn_act_fwd(const float* x, const void* xpanel, const void* wpk, const float* gamma, const float* beta,
+                               float* rmean, float* rvar, float* y, float* stats, float* z, void* zpanel, int B, int Cin, int Hs,
+                               int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, float eps, float momentum, int act,
+                               float slope, void* ws, size_t ws_bytes, hipStream_t stream);
+int mogan_deep_conv_bn_act_bwd(const float* dz, const float* y, const float* stats, const float* gamma, const float* beta,
+                               const void* wpk_dgrad, float* dy, float* dgamma, float* dbeta, int accumulate, float* dx, int B,
+                               int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act, float slope,
+                               void* ws, size_t ws_bytes, hipStream_t stream);
+
 /* nn.Upsample(scale_factor=2, mode='nearest') + conv3x3(padding 1, no bias) -- every upBlock of the reference
  * (code/coco/attngan/model.py:48-55, code/coco/stackgan/model.py:16-22) -- evaluated as the TRANSPOSED 4x4
  * stride-2 pad-1 convolution with kernel K = T w T^t, T = [[0,0,1],[0,1,1],[1,1,0],[1,0,0]]: each phase of the

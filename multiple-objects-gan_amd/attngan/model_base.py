@@ -48,13 +48,24 @@ class BNCallCounter:
 class _HipBNMixin:
     _call_counter = None
 
+    def _count_call(self):
+        if self.num_batches_tracked is not None:
+            if self._call_counter is not None:
+                self._call_counter.hit(self)
+            else:
+                self.num_batches_tracked += 1
+
+    def fused_with_conv(self, x, conv, act=ops.ACT_NONE, slope=0.2):
+        """conv -> this BatchNorm (training statistics) -> act as ONE deep block (hip/ops.DeepConvBNActFn); the caller has
+        checked ops.deep_block_eligible."""
+        self._count_call()
+        ph, pw = conv.padding if isinstance(conv.padding, tuple) else (conv.padding, conv.padding)
+        return ops.deep_conv_bn_act(x, conv.weight, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
+                                    self.eps, self.momentum, conv.stride[0], ph, pw)
+
     def fused(self, x, act=ops.ACT_NONE, slope=0.2, residual=None):
         if self.training:
-            if self.num_batches_tracked is not None:
-                if self._call_counter is not None:
-                    self._call_counter.hit(self)
-                else:
-                    self.num_batches_tracked += 1
+            self._count_call()
             return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
                               residual, self.eps, self.momentum)
         # eval mode: running statistics folded into a per-channel affine
@@ -99,6 +110,31 @@ class FusedSeq(nn.Sequential):
     """nn.Sequential whose forward pattern-matches its children into fused launches:
     [Upsample] conv|linear [BN [GLU|LeakyReLU|ReLU]] , a trailing BN may take a residual."""
 
+    @staticmethod
+    def _deep_block(mods, i, x, up, residual):
+        """conv (no bias) -> BatchNorm2d (training) [-> LeakyReLU / ReLU] on a small map with packed weights: one fused deep
+        block (model.py:575-613, 616-642); returns (output, index behind the matched children) or None"""
+        m, n = mods[i], len(mods)
+        if up or not isinstance(m, HipConv2d) or m.bias is not None or i + 1 >= n or m.stride[0] != m.stride[1]:
+            return None
+        bn = mods[i + 1]
+        if not isinstance(bn, HipBatchNorm2d) or not bn.training or not torch.is_grad_enabled():
+            return None
+        j = i + 2
+        code, slope = _act_of(mods[j]) if j < n else (None, 0.0)
+        if code in (ops.ACT_LRELU, ops.ACT_RELU):
+            j += 1
+        elif code is None or code in (ops.ACT_TANH, ops.ACT_SIGMOID):
+            code, slope = ops.ACT_NONE, 0.0
+        else:
+            return None                                   # GLU: the generator's blocks, not a deep block
+        if j == n and residual is not None:
+            return None
+        ph, pw = m.padding if isinstance(m.padding, tuple) else (m.padding, m.padding)
+        if not ops.deep_block_eligible(x, m.weight, m.stride[0], ph, pw, code):
+            return None
+        return bn.fused_with_conv(x, m, code, slope), j
+
     def forward(self, x, residual=None):
         mods = list(self)
         i, n, up = 0, len(mods), False
@@ -109,6 +145,10 @@ class FusedSeq(nn.Sequential):
                 continue
             if isinstance(m, (HipConv2d, HipLinear)):
                 assert not (up and isinstance(m, HipLinear)), "nn.Upsample in front of a Linear"
+                deep = self._deep_block(mods, i, x, up, residual)
+                if deep is not None:
+                    x, i = deep
+                    continue
                 x = m(x, up=up)
                 up, i = False, i + 1
                 if i < n and isinstance(mods[i], _HipBNMixin):

@@ -348,6 +348,178 @@ __global__ __launch_bounds__(256) void wpack_kernel(const WpackP p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ fused tails
+// conv -> BatchNorm(train) -> LeakyReLU/ReLU of a deep layer has B*OH*OW <= 2048 values per channel: ONE block computes the
+// batch statistics of 8 channels, applies them and hands the next layer its pixel panel -- instead of split-K reduce,
+// bn_partial, bn_finalize, bn_act_fwd and apack (5 launches).  32 lanes (half a wave) own a channel, its values stay in
+// registers between the statistics and the apply step; arithmetic as mogan_norm.hip (fp64 sums, biased variance for the
+// normalisation, unbiased for running_var).
+template <int ACT>
+__device__ __forceinline__ float act_apply(float t, float slope) {
+    if (ACT == MOGAN_ACT_RELU) return t > 0.f ? t : 0.f;
+    if (ACT == MOGAN_ACT_LRELU) return t > 0.f ? t : t * slope;
+    return t;
+}
+__device__ __forceinline__ double half_wave_sum(double v) {          // all 32 lanes of the half get the sum
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// 8 channels x NE pixels of fp32 in LDS (L[ch][e]) -> pieces of the pixel panel: one 16-byte unit per pixel and piece
+__device__ __forceinline__ void panel_from_lds(const float* L, int NE, unsigned char* P, int C, int c0) {
+    const int cg = c0 >> 5, g8 = (c0 & 31) >> 3;
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        uint32_t w[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x6_split2(L[(2 * j) * NE + e], L[(2 * j + 1) * NE + e], w[0][j], w[1][j], w[2][j]);
+        unsigned char* d = P + ((size_t)e * (C >> 5) + cg) * 192 + g8 * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *(uint4*)(d + pl * 64) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+    }
+}
+
+struct TailP {
+    const float* src; int nsplit; long long slab;       // conv output = sum of nsplit slabs (nsplit == 1: src is y itself)
+    const float* gamma; const float* beta; float* rmean; float* rvar;
+    float* y; float* mean; float* invstd; float* z; unsigned char* zpanel;
+    int B, C, HW; float eps, momentum, slope;
+};
+
+template <int ACT, int EPT>
+__global__ __launch_bounds__(256) void deep_tail_fwd_kernel(const TailP p) {
+    extern __shared__ float L[];
+    const int tid = threadIdx.x, chl = tid >> 5, j = tid & 31;
+    const int c0 = blockIdx.x * 8, c = c0 + chl;
+    const int NE = p.B * p.HW;
+    float v[EPT];
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = j + 32 * i;
+        v[i] = 0.f;
+        if (e < NE) {
+            const int b = e / p.HW, pos = e - b * p.HW;
+            const size_t idx = ((size_t)b * p.C + c) * p.HW + pos;
+            float a = p.src[idx];
+            for (int sp = 1; sp < p.nsplit; ++sp) a += p.src[(size_t)sp * p.slab + idx];
+            if (p.nsplit > 1 || p.src != p.y) p.y[idx] = a;
+            v[i] = a;
+            s1 += (double)a; s2 += (double)a * a;
+        }
+    }
+    s1 = half_wave_sum(s1); s2 = half_wave_sum(s2);
+    const double n = (double)NE;
+    const double m = s1 / n;
+    double var = s2 / n - m * m; if (var < 0) var = 0;
+    const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)p.eps));
+    if (j == 0) {
+        p.mean[c] = mu; p.invstd[c] = is;
+        if (p.rmean) p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * mu;
+        if (p.rvar) {
+            const double unb = n > 1 ? var * n / (n - 1.0) : var;
+            p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
+        }
+    }
+    const float sc = p.gamma[c] * is, sh = p.beta[c] - mu * sc;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = j + 32 * i;
+        if (e < NE) {
+            const int b = e / p.HW, pos = e - b * p.HW;
+            const float t = act_apply<ACT>(v[i] * sc + sh, p.slope);
+            p.z[((size_t)b * p.C + c) * p.HW + pos] = t;
+            if (p.zpanel) L[chl * NE + e] = t;
+        }
+    }
+    if (p.zpanel) {
+        __syncthreads();
+        panel_from_lds(L, NE, p.zpanel, p.C, c0);
+    }
+}
+
+struct TailBwdP {
+    const float* dz; const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta;
+    float* dy; unsigned char* dypanel; float* dgamma; float* dbeta; int accumulate;
+    int B, C, HW; float slope;
+};
+
+template <int ACT, int EPT>
+__global__ __launch_bounds__(256) void deep_tail_bwd_kernel(const TailBwdP p) {
+    extern __shared__ float L[];
+    const int tid = threadIdx.x, chl = tid >> 5, j = tid & 31;
+    const int c0 = blockIdx.x * 8, c = c0 + chl;
+    const int NE = p.B * p.HW;
+    const float mu = p.mean[c], is = p.invstd[c];
+    const float sc = p.gamma[c] * is, sh = p.beta[c] - mu * sc;
+    float g[EPT], xh[EPT];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = j + 32 * i;
+        g[i] = 0.f; xh[i] = 0.f;
+        if (e < NE) {
+            const int b = e / p.HW, pos = e - b * p.HW;
+            const size_t idx = ((size_t)b * p.C + c) * p.HW + pos;
+            const float xa = p.y[idx], d = p.dz[idx];
+            const float t = xa * sc + sh;
+            float da = d;
+            if (ACT == MOGAN_ACT_RELU) da = t > 0.f ? d : 0.f;
+            if (ACT == MOGAN_ACT_LRELU) da = t > 0.f ? d : d * p.slope;
+            g[i] = da; xh[i] = (xa - mu) * is;
+            a0 += da; a1 += (double)da * xh[i];
+        }
+    }
+    a0 = half_wave_sum(a0); a1 = half_wave_sum(a1);
+    const float f0 = (float)a0, f1 = (float)a1;
+    if (j == 0) {
+        if (p.dbeta) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + f0;
+        if (p.dgamma) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + f1;
+    }
+    const float inv_n = 1.f / ((float)p.B * (float)p.HW);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = j + 32 * i;
+        if (e < NE) {
+            const int b = e / p.HW, pos = e - b * p.HW;
+            const float d = sc * (g[i] - f0 * inv_n - xh[i] * f1 * inv_n);
+            p.dy[((size_t)b * p.C + c) * p.HW + pos] = d;
+            if (p.dypanel) L[chl * NE + e] = d;
+        }
+    }
+    if (p.dypanel) {
+        __syncthreads();
+        panel_from_lds(L, NE, p.dypanel, p.C, c0);
+    }
+}
+
+template <int ACT>
+static int launch_tail_fwd(const TailP& p, hipStream_t st) {
+    const int NE = p.B * p.HW;
+    const size_t lds = p.zpanel ? (size_t)8 * NE * sizeof(float) : 0;
+    const dim3 grid(p.C / 8);
+    if (NE <= 256) hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 8>), grid, dim3(256), lds, st, p);
+    else if (NE <= 512) hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 16>), grid, dim3(256), lds, st, p);
+    else if (NE <= 1024) hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 32>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 64>), grid, dim3(256), lds, st, p);
+    return 0;
+}
+template <int ACT>
+static int launch_tail_bwd(const TailBwdP& p, hipStream_t st) {
+    const int NE = p.B * p.HW;
+    const size_t lds = p.dypanel ? (size_t)8 * NE * sizeof(float) : 0;
+    const dim3 grid(p.C / 8);
+    if (NE <= 256) hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 8>), grid, dim3(256), lds, st, p);
+    else if (NE <= 512) hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 16>), grid, dim3(256), lds, st, p);
+    else if (NE <= 1024) hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 32>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 64>), grid, dim3(256), lds, st, p);
+    return 0;
+}
+static bool tail_ok(int B, int C, int HW, int act) {
+    return B > 0 && HW > 0 && C > 0 && C % 32 == 0 && (long long)B * HW <= 2048 &&
+           (act == MOGAN_ACT_NONE || act == MOGAN_ACT_RELU || act == MOGAN_ACT_LRELU);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -387,7 +559,8 @@ static void launch_pk(unsigned blocks, hipStream_t st, const PkP& p) {
     hipLaunchKernelGGL((pgemm_kernel<TM, TN, OCC>), dim3(blocks), dim3(256), 0, st, p);
 }
 
-static int run_pk(PkP& p, void* ws, size_t ws_bytes, int prof_mode, hipStream_t st) {
+// keep_slabs: with nsplit > 1 the K-split slabs stay in `ws` for a consumer that sums them itself (deep_tail_fwd_kernel)
+static int run_pk(PkP& p, void* ws, size_t ws_bytes, int prof_mode, hipStream_t st, bool keep_slabs = false) {
     // tile: least padded work; 128-row tiles (two blocks per CU) need ~30 % more LDS traffic per MFMA than 256-row tiles
     int best = 0; double bestw = 1e300;
     for (int c = 0; c < NPK; ++c) {
@@ -427,7 +600,7 @@ static int run_pk(PkP& p, void* ws, size_t ws_bytes, int prof_mode, hipStream_t 
         default: launch_pk<1, 2, 3>((unsigned)blocks, st, p); break;
     }
     mogan_prof_end(1, st);
-    if (p.nsplit > 1) mogan_splitk_reduce_dense((const float*)ws, p.C, c_numel, p.nsplit, p.accumulate, st);
+    if (p.nsplit > 1 && !keep_slabs) mogan_splitk_reduce_dense((const float*)ws, p.C, c_numel, p.nsplit, p.accumulate, st);
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 
@@ -481,42 +654,128 @@ int mogan_pk_weight_pack(const float* w, void* wpk, int Cout, int Cin, int KH, i
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 
-int mogan_conv2d_fwd_pk(const float* x, const void* wpk, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
-                        int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
+}  // extern "C" (helpers below)
+
+namespace {
+// forward GEMM from a ready pixel panel; slabs stay in ws when keep_slabs (see run_pk)
+static int pk_fwd_from_panel(const void* panel, const void* wpk, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                             int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream, bool keep_slabs,
+                             int* nsplit_out) {
     PkGeom g;
     if (!pk_geom(Cout, Cin, KH, KW, stride, 0, g) || B <= 0) return MOGAN_ERR_SHAPE;
     const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
     const size_t pbytes = (size_t)B * Hs * Ws * Cin * 6;
     if (pbytes >= (1ull << 32) || (long long)B * Cout * OH * OW >= (1ll << 31)) return MOGAN_ERR_SHAPE;
-    if (!ws || ws_bytes < up256(pbytes)) return MOGAN_ERR_WS;
-    apack(x, (unsigned char*)ws, B, Cin, Hs * Ws, stream);
     PkP p{};
-    p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)ws; p.C = y;
+    p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)panel; p.C = y;
     p.M = Cout; p.N = B * OH * OW; p.K = g.K; p.Mt = g.Mt; p.KS = g.KS; p.a_cls_stride = g.cls_bytes;
     p.a_bytes = (unsigned)g.cls_bytes; p.p_bytes = (unsigned)pbytes; p.ntile = g.K / 32; p.slab = (long long)B * Cout * OH * OW;
     p.accumulate = 0; p.dgrad = 0; p.ncls = 1; p.Cc = Cin; p.CG = Cin / 32; p.PH = Hs; p.PW = Ws; p.RH = OH; p.RW = OW;
     p.s = stride; p.ph = ph; p.pw = pw; p.nkw = KW; p.outH = OH; p.outW = OW;
-    return run_pk(p, (char*)ws + up256(pbytes), ws_bytes - up256(pbytes), 7, stream);
+    const int rc = run_pk(p, ws, ws_bytes, 7, stream, keep_slabs);
+    if (nsplit_out) *nsplit_out = p.nsplit;
+    return rc;
 }
-
-int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
-                          int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
+static int pk_dgrad_from_panel(const void* panel, const void* wpk, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                               int KW, int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
     PkGeom g;
     if (!pk_geom(Cout, Cin, KH, KW, stride, 1, g) || B <= 0 || Hs % stride || Ws % stride) return MOGAN_ERR_SHAPE;
     const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
     const size_t pbytes = (size_t)B * OH * OW * Cout * 6;
     if (pbytes >= (1ull << 32) || (long long)B * Cin * Hs * Ws >= (1ll << 31)) return MOGAN_ERR_SHAPE;
-    if (!ws || ws_bytes < up256(pbytes)) return MOGAN_ERR_WS;
-    apack(dy, (unsigned char*)ws, B, Cout, OH * OW, stream);
     PkP p{};
-    p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)ws; p.C = dx;
+    p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)panel; p.C = dx;
     p.M = Cin; p.N = B * (Hs / stride) * (Ws / stride); p.K = g.K; p.Mt = g.Mt; p.KS = g.KS; p.a_cls_stride = g.cls_bytes;
     p.a_bytes = (unsigned)g.cls_bytes; p.p_bytes = (unsigned)pbytes; p.ntile = g.K / 32; p.slab = (long long)B * Cin * Hs * Ws;
     p.accumulate = 0; p.dgrad = 1; p.ncls = stride * stride; p.Cc = Cout; p.CG = Cout / 32; p.PH = OH; p.PW = OW;
     p.RH = Hs / stride; p.RW = Ws / stride; p.s = stride; p.ph = ph; p.pw = pw; p.nkw = g.nkw; p.outH = Hs; p.outW = Ws;
-    return run_pk(p, (char*)ws + up256(pbytes), ws_bytes - up256(pbytes), 8, stream);
+    return run_pk(p, ws, ws_bytes, 8, stream);
+}
+}  // namespace
+
+extern "C" {
+
+int mogan_conv2d_fwd_pk(const float* x, const void* wpk, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                        int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || Cin <= 0 || Cin % 32 || Hs <= 0 || Ws <= 0) return MOGAN_ERR_SHAPE;
+    const size_t pbytes = (size_t)B * Hs * Ws * Cin * 6;
+    if (!ws || ws_bytes < up256(pbytes)) return MOGAN_ERR_WS;
+    apack(x, (unsigned char*)ws, B, Cin, Hs * Ws, stream);
+    return pk_fwd_from_panel(ws, wpk, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, (char*)ws + up256(pbytes),
+                             ws_bytes - up256(pbytes), stream, false, nullptr);
+}
+
+int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                          int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || Cout <= 0 || Cout % 32 || stride <= 0) return MOGAN_ERR_SHAPE;
+    const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
+    const size_t pbytes = (size_t)B * OH * OW * Cout * 6;
+    if (!ws || ws_bytes < up256(pbytes)) return MOGAN_ERR_WS;
+    apack(dy, (unsigned char*)ws, B, Cout, OH * OW, stream);
+    return pk_dgrad_from_panel(ws, wpk, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, (char*)ws + up256(pbytes),
+                               ws_bytes - up256(pbytes), stream);
+}
+
+size_t mogan_pk_panel_bytes(int B, int C, int HW) { return (B > 0 && C > 0 && HW > 0) ? (size_t)B * HW * C * 6 : 0; }
+
+int mogan_deep_block_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act) {
+    if (!mogan_pk_conv_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0)) return 0;
+    if (!mogan_pk_conv_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 1)) return 0;
+    const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
+    return tail_ok(B, Cout, OH * OW, act) ? 1 : 0;
+}
+
+int mogan_deep_conv_bn_act_fwd(const float* x, const void* xpanel, const void* wpk, const float* gamma, const float* beta,
+                               float* rmean, float* rvar, float* y, float* stats, float* z, void* zpanel, int B, int Cin, int Hs,
+                               int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, float eps, float momentum, int act,
+                               float slope, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || Cin <= 0 || Cin % 32 || Hs <= 0 || Ws <= 0 || stride <= 0) return MOGAN_ERR_SHAPE;
+    const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0 || !tail_ok(B, Cout, OH * OW, act) || !gamma || !beta || !y || !stats || !z) return MOGAN_ERR_SHAPE;
+    char* w0 = (char*)ws; size_t wn = ws_bytes;
+    if (!xpanel) {                       // the producer of x handed over no panel: pack it here
+        const size_t pbytes = up256((size_t)B * Hs * Ws * Cin * 6);
+        if (!ws || ws_bytes < pbytes) return MOGAN_ERR_WS;
+        apack(x, (unsigned char*)ws, B, Cin, Hs * Ws, stream);
+        xpanel = ws; w0 += pbytes; wn -= pbytes;
+    }
+    int nsplit = 1;
+    int rc = pk_fwd_from_panel(xpanel, wpk, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, w0, wn, stream, true, &nsplit);
+    if (rc) return rc;
+    TailP t{};
+    t.src = nsplit > 1 ? (const float*)w0 : y; t.nsplit = nsplit; t.slab = (long long)B * Cout * OH * OW;
+    t.gamma = gamma; t.beta = beta; t.rmean = rmean; t.rvar = rvar; t.y = y; t.mean = stats; t.invstd = stats + Cout; t.z = z;
+    t.zpanel = (unsigned char*)zpanel; t.B = B; t.C = Cout; t.HW = OH * OW; t.eps = eps; t.momentum = momentum; t.slope = slope;
+    if (act == MOGAN_ACT_LRELU) launch_tail_fwd<MOGAN_ACT_LRELU>(t, stream);
+    else if (act == MOGAN_ACT_RELU) launch_tail_fwd<MOGAN_ACT_RELU>(t, stream);
+    else launch_tail_fwd<MOGAN_ACT_NONE>(t, stream);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+int mogan_deep_conv_bn_act_bwd(const float* dz, const float* y, const float* stats, const float* gamma, const float* beta,
+                               const void* wpk_dgrad, float* dy, float* dgamma, float* dbeta, int accumulate, float* dx, int B,
+                               int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act, float slope,
+                               void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || stride <= 0) return MOGAN_ERR_SHAPE;
+    const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0 || !tail_ok(B, Cout, OH * OW, act) || !dz || !y || !stats || !gamma || !beta || !dy)
+        return MOGAN_ERR_SHAPE;
+    const size_t pbytes = up256((size_t)B * OH * OW * Cout * 6);
+    const bool want_dx = dx != nullptr;
+    if (want_dx && (!ws || ws_bytes < pbytes || !wpk_dgrad)) return MOGAN_ERR_WS;
+    TailBwdP t{};
+    t.dz = dz; t.y = y; t.mean = stats; t.invstd = stats + Cout; t.gamma = gamma; t.beta = beta; t.dy = dy;
+    t.dypanel = want_dx ? (unsigned char*)ws : nullptr; t.dgamma = dgamma; t.dbeta = dbeta; t.accumulate = accumulate;
+    t.B = B; t.C = Cout; t.HW = OH * OW; t.slope = slope;
+    if (act == MOGAN_ACT_LRELU) launch_tail_bwd<MOGAN_ACT_LRELU>(t, stream);
+    else if (act == MOGAN_ACT_RELU) launch_tail_bwd<MOGAN_ACT_RELU>(t, stream);
+    else launch_tail_bwd<MOGAN_ACT_NONE>(t, stream);
+    if (!want_dx) return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+    return pk_dgrad_from_panel(ws, wpk_dgrad, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, (char*)ws + pbytes,
+                               ws_bytes - pbytes, stream);
 }
 
 }  // extern "C"

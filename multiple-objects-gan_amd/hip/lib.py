@@ -42,6 +42,10 @@ SIGNATURES = {
     "mogan_conv2d_fwd_pk": [P, P, P] + [I] * 10 + [P, Z, P],
     "mogan_conv2d_dgrad_pk": [P, P, P] + [I] * 10 + [P, Z, P],
     "mogan_pk_debug_force": [I, I, I],
+    "mogan_pk_panel_bytes": [I, I, I],
+    "mogan_deep_block_eligible": [I] * 11,
+    "mogan_deep_conv_bn_act_fwd": [P] * 11 + [I] * 10 + [F, F, I, F, P, Z, P],
+    "mogan_deep_conv_bn_act_bwd": [P] * 9 + [I, P] + [I] * 10 + [I, F, P, Z, P],
     "mogan_upconv3x3_ws_bytes": [I, I],
     "mogan_upconv3x3_fwd": [P, P, P, I, I, I, I, I, P, Z, P],
     "mogan_upconv3x3_dgrad": [P, P, P, I, I, I, I, I, P, Z, P],
@@ -116,7 +120,7 @@ class ConvDgradArgs(ctypes.Structure):          # MoganConvDgradArgs
                 ("accumulate", I)] + [(k, I) for k in ("B", "Cin", "Hs", "Ws", "Cout", "KH", "KW", "stride", "ph", "pw")]
 
 
-_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z}
+_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
 _lib = None

@@ -411,6 +411,110 @@ def conv2d(x, w, bias=None, stride=1, padding=0, up=False):
     return Conv2dFn.apply(x, w, bias, int(stride), int(ph), int(pw), 1 if up else 0)
 
 
+# ------------------------------------------------------------------------------- deep block: conv + BN + activation
+DEEP_STATS = {"fwd": 0, "bwd": 0, "panel_hits": 0}
+DEEP_ENABLED = os.environ.get("MOGAN_DEEP", "1") != "0"       # 0: packed GEMMs, but BatchNorm / activation as separate launches
+_deep_elig = {}
+
+
+def deep_block_eligible(x, w, stride, ph, pw, act):
+    """conv -> BatchNorm(train) -> act as the fused deep block (csrc/mogan_pgemm.hip): the weight has packed copies, both
+    directions of the convolution take the packed path and the output map is small enough for the one-block-per-8-channels
+    tail kernels."""
+    if not (PK_ENABLED and DEEP_ENABLED) or getattr(w, "_mogan_pk", None) is None or x.dim() != 4:
+        return False
+    B, Cin, Hs, Ws = x.shape
+    Cout, _, KH, KW = w.shape
+    key = (B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act)
+    e = _deep_elig.get(key)
+    if e is None:
+        e = _deep_elig[key] = bool(lib.load().mogan_deep_block_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act))
+    return e
+
+
+class DeepConvBNActFn(torch.autograd.Function):
+    """z = act(BatchNorm2d_train(conv2d(x, w))) for the deep discriminator layers (model.py:575-613: downBlock,
+    Block3x3_leakRelu; 616-642: jointConv) in two launches forward (packed-weight GEMM, tail) and two + the weight gradient
+    backward.  The output carries the pixel panel of z for the next deep block (attribute _mogan_panel)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, act, slope, eps, momentum, stride, ph, pw):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        B, Cin, Hs, Ws = x.shape
+        Cout, _, KH, KW = w.shape
+        OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, 0)
+        dev = x.device
+        pk = w._mogan_pk
+        wp = pk.pointer(0, B, Hs, Ws, stride, ph, pw)
+        f32 = dict(dtype=torch.float32, device=dev)
+        y = torch.empty((B, Cout, OH, OW), **f32)
+        z = torch.empty((B, Cout, OH, OW), **f32)
+        stats = torch.empty((2, Cout), **f32)
+        zpanel = torch.empty(int(lib.load().mogan_pk_panel_bytes(B, Cout, OH * OW)), dtype=torch.uint8, device=dev)
+        xp = getattr(x, "_mogan_panel", None)
+        if xp is not None and (xp[1] != x.data_ptr() or xp[2] != x._version):
+            xp = None                                    # not the panel of these values
+        if xp is not None:
+            DEEP_STATS["panel_hits"] += 1
+        wsp, wsn = workspace(dev)
+        call("mogan_deep_conv_bn_act_fwd", ptr(x), ptr(xp[0]) if xp is not None else None, wp, ptr(gamma), ptr(beta),
+             ptr(running_mean), ptr(running_var), ptr(y), ptr(stats), ptr(z), ptr(zpanel), B, Cin, Hs, Ws, Cout, KH, KW,
+             stride, ph, pw, eps, momentum, act, slope, wsp, wsn, stream_ptr())
+        DEEP_STATS["fwd"] += 1
+        if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
+            ACT_TRACE.append((act, z))
+        ctx.save_for_backward(x, w, y, stats, gamma, beta)
+        ctx.cfg = (act, slope, stride, ph, pw)
+        z._mogan_panel = (zpanel, z.data_ptr(), z._version)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, y, stats, gamma, beta = ctx.saved_tensors
+        act, slope, stride, ph, pw = ctx.cfg
+        dz = _c(dz)
+        B, Cin, Hs, Ws = x.shape
+        Cout, _, KH, KW = w.shape
+        dev = x.device
+        dy = torch.empty_like(y)
+        want_dx = ctx.needs_input_grad[0]
+        dx = torch.empty(x.shape, dtype=torch.float32, device=dev) if want_dx else None
+        wpd = w._mogan_pk.pointer(1, B, Hs, Ws, stride, ph, pw) if want_dx else None
+        gg, gb = _grad_buf(gamma), _grad_buf(beta)
+        want_gb = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        direct = gg is not None and gb is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+        dg = db = None
+        if direct:
+            pg, pb = gg, gb
+        elif want_gb:
+            dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+            pg, pb = dgb[0], dgb[1]
+        else:
+            pg = pb = None
+        wsp, wsn = workspace(dev)
+        call("mogan_deep_conv_bn_act_bwd", ptr(dz), ptr(y), ptr(stats), ptr(gamma), ptr(beta), wpd, ptr(dy), ptr(pg), ptr(pb),
+             1 if direct else 0, ptr(dx), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act, slope, wsp, wsn, stream_ptr())
+        DEEP_STATS["bwd"] += 1
+        if direct:
+            _grad_hit(gg)
+            _grad_hit(gb)
+        elif want_gb:
+            dg, db = pg, pb
+        dw = None
+        if ctx.needs_input_grad[1]:
+            g = _grad_buf(w)
+            if g is not None:
+                _wgrad_accumulate(dy, x, w, (stride, ph, pw, 0), g)
+            else:
+                dw = conv2d_wgrad(dy, x, w.shape, stride, ph, pw, 0)
+        return (dx, dw, dg, db) + (None,) * 9
+
+
+def deep_conv_bn_act(x, w, gamma, beta, running_mean, running_var, act, slope, eps, momentum, stride, ph, pw):
+    return DeepConvBNActFn.apply(x, w, gamma, beta, running_mean, running_var, int(act), float(slope), float(eps),
+                                 float(momentum), int(stride), int(ph), int(pw))
+
+
 # ------------------------------------------------------------------------------- strided bmm / linear
 def bmm_raw(a, b, out, accumulate=False):
     """out[z] (+)= a[z] @ b[z] for 3-D strided views (no copies)."""

@@ -591,3 +591,94 @@ def test_packed_weight_eligibility():
     assert e(16, 84, 16, 16, 192, 4, 4, 1, 1, 1, 0) == 0            # Cin % 32 != 0
     assert e(16, 768, 8, 8, 100, 4, 4, 2, 1, 1, 1) == 0             # data gradient: Cout % 32 != 0
     assert e(16, 64, 8, 8, 64, 4, 4, 2, 1, 1, 0) == 0               # K = 1024 but only 64 rows
+
+
+DEEP_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, act
+    (16, 64, 8, 8, 64, 4, 2, 1, ops.ACT_LRELU),      # 256 values per channel
+    (16, 32, 16, 16, 96, 4, 2, 1, ops.ACT_LRELU),    # 1024
+    (3, 64, 4, 4, 96, 3, 1, 1, ops.ACT_RELU),        # 48: ragged half-waves
+    (32, 32, 16, 16, 32, 4, 2, 1, ops.ACT_NONE),     # 2048: the largest map the tail kernels take
+    (15, 64, 4, 4, 32, 3, 1, 1, ops.ACT_LRELU),      # the "wrong pair" batch
+]
+
+
+@pytest.mark.parametrize("case", DEEP_CASES)
+@pytest.mark.parametrize("split", [0, 1, 3])
+def test_deep_block_conv_bn_act(case, split):
+    """csrc/mogan_pgemm.hip deep block (packed-weight GEMM + one tail kernel each way) = conv2d -> BatchNorm2d(train) ->
+    LeakyReLU / ReLU (model.py:575-613) against torch in fp64: output, running statistics, and the gradients of the input,
+    the filter, gamma and beta; K-split slabs summed by the tail kernel (split 3) and the direct store (split 1)."""
+    import torch.nn as nn
+    from mogan_amd.attngan.model_base import FusedSeq, HipBatchNorm2d, HipConv2d
+    B, Cin, H, W, Cout, k, s, pad, act = case
+    lib.load().mogan_pk_debug_force(1, -1, split)
+    before = dict(ops.DEEP_STATS)
+    try:
+        mods = [HipConv2d(Cin, Cout, k, s, pad, bias=False), HipBatchNorm2d(Cout)]
+        if act == ops.ACT_LRELU:
+            mods.append(nn.LeakyReLU(0.2))
+        elif act == ops.ACT_RELU:
+            mods.append(nn.ReLU())
+        seq = FusedSeq(*mods)
+        with torch.no_grad():
+            seq[0].weight.copy_(T("dbw%s" % (case,), (Cout, Cin, k, k), 0.1))
+            seq[1].weight.copy_(T("dbg%s" % (case,), (Cout,), 0.3, 1.0))
+            seq[1].bias.copy_(T("dbb%s" % (case,), (Cout,), 0.2))
+        x = T("dbx%s" % (case,), (B, Cin, H, W))
+        # fp64 reference
+        xd = x.double().requires_grad_(True)
+        wd = seq[0].weight.detach().double().requires_grad_(True)
+        gd = seq[1].weight.detach().double().requires_grad_(True)
+        bd = seq[1].bias.detach().double().requires_grad_(True)
+        rm, rv = torch.zeros(Cout, dtype=torch.float64), torch.ones(Cout, dtype=torch.float64)
+        yd = F.conv2d(xd, wd, None, s, pad)
+        zd = F.batch_norm(yd, rm, rv, gd, bd, True, 0.1, 1e-5)
+        if act == ops.ACT_LRELU:
+            zd = F.leaky_relu(zd, 0.2)
+        elif act == ops.ACT_RELU:
+            zd = F.relu(zd)
+        gz = T("dbgz%s" % (case,), zd.shape)
+        zd.backward(gz.double())
+        # the fused path
+        seq = seq.to(DEV).train()
+        ops.attach_packs(seq[0].weight)
+        xg = x.to(DEV).requires_grad_(True)
+        z = seq(xg)
+        assert ops.DEEP_STATS["fwd"] == before["fwd"] + 1, "the deep block was not taken"
+        z.backward(gz.to(DEV))
+        torch.cuda.synchronize()
+        assert ops.DEEP_STATS["bwd"] == before["bwd"] + 1
+        assert max_abs(z, zd) <= 2e-5
+        assert max_abs(seq[1].running_mean, rm) <= 1e-6 and max_abs(seq[1].running_var, rv) <= 1e-5
+        assert rel_l2(xg.grad, xd.grad) <= 5e-6, rel_l2(xg.grad, xd.grad)
+        assert rel_l2(seq[0].weight.grad, wd.grad) <= 5e-6
+        assert max_abs(seq[1].weight.grad, gd.grad) <= 2e-4 * max(1.0, float(gd.grad.abs().max()))
+        assert max_abs(seq[1].bias.grad, bd.grad) <= 2e-4 * max(1.0, float(bd.grad.abs().max()))
+    finally:
+        lib.load().mogan_pk_debug_force(0, -1, 0)
+
+
+def test_deep_blocks_hand_over_their_pixel_panel():
+    """Two deep blocks in a row: the second takes the first one's pixel panel (no activation pack), and gets the same result
+    as from the plain tensor."""
+    import torch.nn as nn
+    from mogan_amd.attngan.model_base import FusedSeq, HipBatchNorm2d, HipConv2d
+    lib.load().mogan_pk_debug_force(1, -1, 0)
+    try:
+        torch.manual_seed(11)
+        a = FusedSeq(HipConv2d(64, 96, 4, 2, 1, bias=False), HipBatchNorm2d(96), nn.LeakyReLU(0.2)).to(DEV).train()
+        b = FusedSeq(HipConv2d(96, 64, 3, 1, 1, bias=False), HipBatchNorm2d(64), nn.LeakyReLU(0.2)).to(DEV).train()
+        for m in (a, b):
+            ops.attach_packs(m[0].weight)
+        x = torch.randn(8, 64, 8, 8, device=DEV)
+        hits = ops.DEEP_STATS["panel_hits"]
+        h = a(x)
+        z1 = b(h)
+        assert ops.DEEP_STATS["panel_hits"] == hits + 1, "the second block did not take the first one's panel"
+        z2 = b(h.detach().clone())                       # same values, no panel attached
+        assert ops.DEEP_STATS["panel_hits"] == hits + 1
+        torch.cuda.synchronize()
+        assert torch.equal(z1, z2)
+    finally:
+        lib.load().mogan_pk_debug_force(0, -1, 0)

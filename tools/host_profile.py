@@ -20,4 +20,4 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3): step()
 pr.disable(); torch.cuda.synchronize()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45); print(s.getvalue()[:9000])

@@ -521,6 +521,8 @@ def main():
         out["cpu_baseline"], out["parity"] = cpu_baseline_leg(engine, bt_cpu, dev_batch, B, device)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if os.environ.get("MOGAN_CHAIN_EVENTS") and rank == 0:       # diagnostic: where the main stream (generator chain) spends the step
+        out["chain_ms"] = engine.chain_report()
     if rank == 0:                      # the JSON line is the last thing on stdout (RCCL prints its banner there too)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)

@@ -303,7 +303,7 @@ class ChunkedReducer:
 class TrainEngine:
     """Device-side state of one rank: networks, flat optimizers, DP communicator, optional hipGraph."""
 
-    def __init__(self, text_encoder, image_encoder, netG, netsD, distributed=False, use_graph=False):
+    def __init__(self, text_encoder, image_encoder, netG, netsD, distributed=False, use_graph=False, branch_graphs=None):
         self.text_encoder, self.image_encoder, self.netG, self.netsD = text_encoder, image_encoder, netG, netsD
         self.optG = FlatAdam(netG, cfg.TRAIN.GENERATOR_LR, with_ema=True)
         self.optDs = [FlatAdam(d, cfg.TRAIN.DISCRIMINATOR_LR) for d in netsD]
@@ -322,6 +322,16 @@ class TrainEngine:
         self.early_damsm_bwd = os.environ.get("MOGAN_EARLY_DAMSM_BWD", "1") != "0"
         self._enc_graphs = {}
         self.multi_stream = os.environ.get("MOGAN_STREAMS", "1") != "0"
+        # Branch graphs (single process, multi-stream, not the whole-step graph): every discriminator branch -- D_i(real);
+        # D_i(fake), loss, backward incl. the weight gradients on their side stream, Adam, re-pack, the generator-step forward
+        # through the updated D_i and its gradient with respect to the fake image -- is captured ONCE as two hipGraphs per
+        # discriminator and replayed on the branch's stream; the generator itself (forward, backward, Adam) stays eager on the
+        # main stream.  ~900 of the step's ~2000 launches leave the host path (34 -> ~20 ms of python per step), the stream
+        # structure of the eager step is unchanged.  MOGAN_BRANCH_GRAPHS=0 / branch_graphs=False: everything eager.
+        if branch_graphs is None:
+            branch_graphs = os.environ.get("MOGAN_BRANCH_GRAPHS", "1") != "0"
+        self.branch_graphs = bool(branch_graphs) and self.multi_stream and not self.distributed and not use_graph
+        self._bg = None
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
         bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
         if bmap:
@@ -433,7 +443,16 @@ class TrainEngine:
 
     # -- the reference loop body -------------------------------------------------------------------
     def _phase(self, name):
-        """MOGAN_PHASE_TIMES=1: device-synchronised wall time per phase of the step (diagnostic; serialises the phases)."""
+        """MOGAN_PHASE_TIMES=1: device-synchronised wall time per phase of the step (diagnostic; serialises the phases).
+        MOGAN_CHAIN_EVENTS=1: an event on the MAIN stream at every phase boundary instead (no synchronisation, the step runs
+        as usual); chain_report() turns them into the time the main stream -- the generator's dependency chain -- spent in
+        each phase, waits for the side branches included."""
+        if os.environ.get("MOGAN_CHAIN_EVENTS"):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._chain = getattr(self, "_chain", [])
+            self._chain.append((name, ev))
+            return
         if not os.environ.get("MOGAN_PHASE_TIMES"):
             return
         torch.cuda.synchronize()
@@ -442,6 +461,27 @@ class TrainEngine:
             self._ph = getattr(self, "_ph", {})
             self._ph[self._ph_name] = self._ph.get(self._ph_name, 0.0) + (now - self._ph_last) * 1e3
         self._ph_last, self._ph_name = now, name
+
+    def chain_report(self, skip=5):
+        """mean milliseconds between consecutive MOGAN_CHAIN_EVENTS events over the recorded steps (after `skip` steps)"""
+        ch = getattr(self, "_chain", [])
+        torch.cuda.synchronize()
+        names = []
+        for n, _ in ch:
+            if n in names:
+                break
+            names.append(n)
+        k = len(names)
+        steps = len(ch) // k
+        acc = {}
+        for st in range(skip, steps):
+            for i in range(k):
+                a = ch[st * k + i]
+                nxt = ch[st * k + i + 1] if st * k + i + 1 < len(ch) else None
+                if nxt is None:
+                    continue
+                acc.setdefault(a[0], []).append(a[1].elapsed_time(nxt[1]))
+        return {n: round(sum(v) / len(v), 3) for n, v in acc.items()}
 
     def device_step(self, b):
         """trainer.py:291-342 given the text embeddings; `b` holds device tensors:
@@ -466,6 +506,8 @@ class TrainEngine:
         fake_labels = b["z"].new_zeros(B)
         match_labels = b["match_labels"]
         real_feat = {}
+        if self.branch_graphs:
+            return self._branch_graph_step(b, real_labels, fake_labels, match_labels)
         if self.multi_stream:
             # D_i(real) depends neither on the generator nor on the text encoder: it runs beside them.  With an
             # `inputs_ready` event (recorded by the caller once the batch tensors are on the device) the D branches
@@ -590,6 +632,151 @@ class TrainEngine:
         self.bn_counter.flush()                                           # all num_batches_tracked, one launch
         out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach(),
                    fake_last=fake_imgs[-1].detach())
+        out.update({k: v.detach() for k, v in parts.items()})
+        self._phase("end")
+        return out
+
+    # -- branch graphs -----------------------------------------------------------------------------------------------
+    _BG_KEYS = ("sent_emb", "label_one_hot", "tm", "tmi")
+
+    def _bg_capture(self, b, fake_imgs):
+        """Capture the discriminator branches on their streams (see __init__).  Static inputs: the real images, the fake
+        images, the sentence embedding and (D_NET64) labels / boxes; static outputs: errD_i, g_loss_i and d g_loss_i / d fake_i.
+        The forward of D_i(real) and the rest live in two graphs of one memory pool so that D_i(real) can be replayed early,
+        beside the generator's forward."""
+        from ..hip import lib as _lib
+        from .miscc.losses import _call_d
+        netsD, nD = self.netsD, len(self.netsD)
+        st = {k: b[k].clone() for k in self._BG_KEYS}
+        st["imgs"] = [t.clone() for t in b["imgs"]]
+        st["fake"] = [t.detach().clone() for t in fake_imgs]
+        B = b["z"].shape[0]
+        real_labels, fake_labels = b["z"].new_ones(B), b["z"].new_zeros(B)
+        bg = {"static": st, "gR": [], "gU": [], "out": [], "calls": []}
+        torch.cuda.synchronize()
+        counter = self.bn_counter
+        for i in range(nD):
+            s = self.side[i]
+            if os.environ.get("MOGAN_BG_WGRAD", "0") != "0":      # 1: fork the weight gradients inside the branch graphs (measured: a forked graph replays slowly, 47.1 vs 42.1 ms per step)
+                ops.CAPTURE_WGRAD_OK.add(s.cuda_stream)
+            kw = dict(local_labels=st["label_one_hot"], transf_matrices=st["tm"], transf_matrices_inv=st["tmi"]) if i == 0 else {}
+            pool = torch.cuda.graph_pool_handle()
+            calls0 = list(counter.calls)
+            gR, gU = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with _lib.capture_guard():
+                with torch.cuda.graph(gR, pool=pool, stream=s):
+                    self.optDs[i].zero_grad()
+                    feat = _call_d(netsD[i], st["imgs"][i], kw.get("local_labels"), kw.get("transf_matrices"),
+                                   kw.get("transf_matrices_inv"))
+                with torch.cuda.graph(gU, pool=pool, stream=s):
+                    errD = discriminator_loss(netsD[i], st["imgs"][i], st["fake"][i], st["sent_emb"], real_labels, fake_labels,
+                                              None, real_features=feat, **kw)
+                    with ops.wgrad_overlap():
+                        errD.backward()
+                    self._opt_step(self.optDs[i], None)
+                    for p in netsD[i].parameters():
+                        p.requires_grad_(False)
+                    leaf = st["fake"][i].detach().requires_grad_(True)
+                    g_loss = generator_d_branch(netsD[i], leaf, st["sent_emb"], **kw)
+                    g_img, = torch.autograd.grad(g_loss, leaf)
+                    for p in netsD[i].parameters():
+                        p.requires_grad_(True)
+                    out = (errD.detach(), g_loss.detach(), g_img)
+            del feat, errD, g_loss, leaf
+            bg["gR"].append(gR); bg["gU"].append(gU); bg["out"].append(out)
+            bg["calls"].append([a - c for a, c in zip(counter.calls, calls0)])     # BatchNorm calls the replays stand for
+            counter.calls = calls0
+        torch.cuda.synchronize()
+        return bg
+
+    def _branch_graph_step(self, b, real_labels, fake_labels, match_labels):
+        """device_step with the discriminator branches replayed as hipGraphs (same streams, same order, same results)."""
+        netG, netsD, nD = self.netG, self.netsD, len(self.netsD)
+        B = b["z"].shape[0]
+        cur = torch.cuda.current_stream()
+        if self._bg is None:
+            # warm-up (allocator, workspaces, packed weight copies) must not train: two eager steps on this batch, undone
+            snap = self._snapshot()
+            calls = list(self.bn_counter.calls)
+            self.branch_graphs = False
+            try:
+                wb = {k: v for k, v in b.items() if k != "inputs_ready"}
+                for _ in range(2):
+                    self.device_step(dict(wb))
+                with torch.no_grad():
+                    if "words_embs" not in b:
+                        b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
+                    fk, _, _, _ = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
+                self._bg = self._bg_capture(b, fk)
+            finally:
+                self.branch_graphs = True
+            self._restore(snap)
+            self.bn_counter.calls = calls
+            torch.cuda.synchronize()
+        bg, st = self._bg, self._bg["static"]
+        ready = b.get("inputs_ready")
+        # D_i(real): beside the text encoder and the generator's forward (and the tail of the previous step)
+        for i in range(nD)[::-1]:
+            s = self.side[i]
+            if ready is not None:
+                s.wait_event(ready)
+            else:
+                s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                st["imgs"][i].copy_(b["imgs"][i])
+                if i == 0:
+                    for k in ("label_one_hot", "tm", "tmi"):
+                        st[k].copy_(b[k])
+                bg["gR"][i].replay()
+        if ready is not None:
+            cur.wait_event(ready)
+        self._phase("text+Gfwd")
+        if "words_embs" not in b:
+            b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
+        st["sent_emb"].copy_(b["sent_emb"])                # (main stream; the branches wait for it below)
+        fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
+        out, parts = {}, {}
+        self._phase("D heads + Inception")
+
+        def branch(i):
+            s = self.side[i]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                st["fake"][i].copy_(fake_imgs[i].detach())
+                bg["gU"][i].replay()
+            for j, n in enumerate(bg["calls"][i]):
+                self.bn_counter.calls[j] += n
+
+        branch(nD - 1)
+        s = self.side[nD]
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            img = fake_imgs[nD - 1].detach().requires_grad_(True)
+            w_loss, s_loss = generator_damsm_branch(self._encoder(img), img, b["words_embs"], b["sent_emb"], match_labels,
+                                                    b["cap_lens"], b.get("class_ids"), B)
+            damsm_grad, = torch.autograd.grad(ops.scalar_sum([w_loss, s_loss]), img)
+            parts["w_loss"], parts["s_loss"] = w_loss.detach(), s_loss.detach()
+        for i in range(nD - 1)[::-1]:
+            branch(i)
+        self._phase("D tails + G-step D fwd")
+        for s in self.side:
+            cur.wait_stream(s)
+        self._phase("G backward")
+        self.optG.zero_grad()
+        for i in range(nD):
+            errD, g_loss, _ = bg["out"][i]
+            out["errD%d" % i] = errD.clone()
+            parts["g_loss%d" % i] = g_loss.clone()
+        kl_loss = KL_loss(mu, logvar)
+        errG_total = ops.scalar_sum([generator_total(parts, nD), kl_loss.detach()])          # the logged value
+        grads = [bg["out"][i][2] for i in range(nD)]
+        grads[nD - 1] = ops.add(grads[nD - 1], damsm_grad)       # d errG / d img256 = D256 path + DAMSM path
+        with ops.wgrad_overlap():
+            torch.autograd.backward(list(fake_imgs) + [kl_loss], grads + [None])
+        self._phase("G adam")
+        self._opt_step(self.optG, None)
+        self.bn_counter.flush()
+        out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach(), fake_last=fake_imgs[-1].detach())
         out.update({k: v.detach() for k, v in parts.items()})
         self._phase("end")
         return out

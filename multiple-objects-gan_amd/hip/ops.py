@@ -417,6 +417,12 @@ DEEP_ENABLED = os.environ.get("MOGAN_DEEP", "1") != "0"       # 0: packed GEMMs,
 _deep_elig = {}
 
 
+def pk_debug_force(take_all, cfg=-1, split=0):
+    """test hook (mogan_pk_debug_force) + the host-side eligibility caches it invalidates"""
+    lib.load().mogan_pk_debug_force(int(take_all), int(cfg), int(split))
+    _deep_elig.clear()
+
+
 def deep_block_eligible(x, w, stride, ph, pw, act):
     """conv -> BatchNorm(train) -> act as the fused deep block (csrc/mogan_pgemm.hip): the weight has packed copies, both
     directions of the convolution take the packed path and the output map is small enough for the one-block-per-8-channels

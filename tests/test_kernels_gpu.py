@@ -552,7 +552,7 @@ def test_packed_weight_convolution(case, force):
     gradient of the same autograd node takes the unpacked kernels.  The size heuristic of mogan_pk_conv_eligible is switched
     off (the hard constraints of the panel formats stay) so that small shapes reach the kernels."""
     B, Cin, H, W, Cout, k, s, pad = case
-    lib.load().mogan_pk_debug_force(1, force[0], force[1])
+    ops.pk_debug_force(1, force[0], force[1])
     before = dict(ops.PK_STATS)
     try:
         x = T("pkx%s" % (case,), (B, Cin, H, W)).requires_grad_(True)
@@ -579,7 +579,7 @@ def test_packed_weight_convolution(case, force):
         torch.cuda.synchronize()
         _check(y2, -0.5 * ref.detach(), what="fwd after re-pack")
     finally:
-        lib.load().mogan_pk_debug_force(0, -1, 0)
+        ops.pk_debug_force(0, -1, 0)
 
 
 def test_packed_weight_eligibility():
@@ -612,7 +612,7 @@ def test_deep_block_conv_bn_act(case, split):
     import torch.nn as nn
     from mogan_amd.attngan.model_base import FusedSeq, HipBatchNorm2d, HipConv2d
     B, Cin, H, W, Cout, k, s, pad, act = case
-    lib.load().mogan_pk_debug_force(1, -1, split)
+    ops.pk_debug_force(1, -1, split)
     before = dict(ops.DEEP_STATS)
     try:
         mods = [HipConv2d(Cin, Cout, k, s, pad, bias=False), HipBatchNorm2d(Cout)]
@@ -656,7 +656,7 @@ def test_deep_block_conv_bn_act(case, split):
         assert max_abs(seq[1].weight.grad, gd.grad) <= 2e-4 * max(1.0, float(gd.grad.abs().max()))
         assert max_abs(seq[1].bias.grad, bd.grad) <= 2e-4 * max(1.0, float(bd.grad.abs().max()))
     finally:
-        lib.load().mogan_pk_debug_force(0, -1, 0)
+        ops.pk_debug_force(0, -1, 0)
 
 
 def test_deep_blocks_hand_over_their_pixel_panel():
@@ -664,7 +664,7 @@ def test_deep_blocks_hand_over_their_pixel_panel():
     as from the plain tensor."""
     import torch.nn as nn
     from mogan_amd.attngan.model_base import FusedSeq, HipBatchNorm2d, HipConv2d
-    lib.load().mogan_pk_debug_force(1, -1, 0)
+    ops.pk_debug_force(1, -1, 0)
     try:
         torch.manual_seed(11)
         a = FusedSeq(HipConv2d(64, 96, 4, 2, 1, bias=False), HipBatchNorm2d(96), nn.LeakyReLU(0.2)).to(DEV).train()
@@ -681,4 +681,4 @@ def test_deep_blocks_hand_over_their_pixel_panel():
         torch.cuda.synchronize()
         assert torch.equal(z1, z2)
     finally:
-        lib.load().mogan_pk_debug_force(0, -1, 0)
+        ops.pk_debug_force(0, -1, 0)

@@ -234,15 +234,16 @@ def test_g_net_eval_mode():
     assert all(int(v) == 0 for k, v in G.state_dict().items() if k.endswith("num_batches_tracked"))
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_train_steps(use_graph):
+@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs"])
+def test_two_train_steps(mode):
     """the op order of the step (fake images generated once, each D updated
-    before generator_loss forwards through it), Adam, EMA, BN running statistics -- eager and as one
-    replayed hipGraph."""
+    before generator_loss forwards through it), Adam, EMA, BN running statistics -- eager, as one
+    replayed hipGraph, and with the discriminator branches replayed as hipGraphs beside the eager generator (the default)."""
     from mogan_amd.attngan.trainer import TrainEngine
     g = golden("step")
     G, Ds, enc = _build_all()
-    eng = TrainEngine(None, enc, G, Ds, use_graph=use_graph)
+    eng = TrainEngine(None, enc, G, Ds, use_graph=mode == "graph", branch_graphs=mode == "branch_graphs")
+    assert eng.branch_graphs == (mode == "branch_graphs")
     nets = [("G", G)] + [("D%d" % i, D) for i, D in enumerate(Ds)]
     init = {n: {k: probe(v) for k, v in net.state_dict().items()} for n, net in nets}
     for step in range(2):

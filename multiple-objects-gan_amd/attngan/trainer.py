@@ -741,6 +741,8 @@ class TrainEngine:
         def branch(i):
             s = self.side[i]
             s.wait_stream(cur)
+            if os.environ.get("MOGAN_EXP_SKIP") == "d%d" % i:      # experiment only: the step without this D's update
+                return
             with torch.cuda.stream(s):
                 st["fake"][i].copy_(fake_imgs[i].detach())
                 bg["gU"][i].replay()
@@ -752,9 +754,13 @@ class TrainEngine:
         s.wait_stream(cur)
         with torch.cuda.stream(s):
             img = fake_imgs[nD - 1].detach().requires_grad_(True)
-            w_loss, s_loss = generator_damsm_branch(self._encoder(img), img, b["words_embs"], b["sent_emb"], match_labels,
-                                                    b["cap_lens"], b.get("class_ids"), B)
-            damsm_grad, = torch.autograd.grad(ops.scalar_sum([w_loss, s_loss]), img)
+            if os.environ.get("MOGAN_EXP_SKIP") == "damsm":       # experiment only: the step without its Inception/DAMSM branch
+                w_loss = s_loss = kl_zero = torch.zeros((), device=img.device)
+                damsm_grad = torch.zeros_like(img)
+            else:
+                w_loss, s_loss = generator_damsm_branch(self._encoder(img), img, b["words_embs"], b["sent_emb"], match_labels,
+                                                        b["cap_lens"], b.get("class_ids"), B)
+                damsm_grad, = torch.autograd.grad(ops.scalar_sum([w_loss, s_loss]), img)
             parts["w_loss"], parts["s_loss"] = w_loss.detach(), s_loss.detach()
         for i in range(nD - 1)[::-1]:
             branch(i)

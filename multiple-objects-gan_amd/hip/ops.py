@@ -69,6 +69,9 @@ _wgrad_keep = []         # operands of in-flight side-stream launches; released 
 # concatenated batch (dW = dY_1 X_1^t + dY_2 X_2^t -- the same sum), leftovers at the join.
 MERGE_WGRAD = os.environ.get("MOGAN_MERGE_WGRAD", "1") != "0"
 _wgrad_pending = {}
+# under hipGraph capture too (the branch graphs of trainer.TrainEngine replay the merged launches): the parked contribution and
+# the concatenated operands live in the graph's memory pool
+MERGE_WGRAD_CAPTURED = os.environ.get("MOGAN_MERGE_WGRAD_CAPTURED", "1") != "0"
 _wgrad_ctx_depth = 0         # parking needs somebody to flush: only inside `with wgrad_overlap():`
 _MERGE_K = int(os.environ.get("MOGAN_MERGE_WGRAD_K", "2048"))
 _MERGE_W = int(os.environ.get("MOGAN_MERGE_WGRAD_W", str(1 << 21)))
@@ -92,7 +95,7 @@ def _wgrad_accumulate(dy, x, w, geom, g):
     """dW += wgrad(dy, x) into the parameter's .grad buffer g, possibly deferred / merged (see MERGE_WGRAD)."""
     K = dy.shape[0] * dy.shape[2] * dy.shape[3]
     if not (MERGE_WGRAD and _wgrad_ctx_depth > 0 and K <= _MERGE_K and w.numel() >= _MERGE_W) \
-            or torch.cuda.is_current_stream_capturing():
+            or (torch.cuda.is_current_stream_capturing() and not MERGE_WGRAD_CAPTURED):
         _wgrad_launch(dy, x, w.shape, geom, g)
         return
     key = (g.data_ptr(), torch.cuda.current_stream().cuda_stream)

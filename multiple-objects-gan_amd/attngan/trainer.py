@@ -355,8 +355,14 @@ class TrainEngine:
         chunk = int(float(os.environ.get("MOGAN_DP_CHUNK_MB", "96")) * (1 << 20))
         if self.distributed and chunk > 0 and not self._debug_no_ar:
             for o in [self.optG] + self.optDs:
-                if o.numel * 4 >= 2 * chunk:
-                    self.reducers[id(o)] = ChunkedReducer(o, chunk, torch.cuda.Stream())
+                c = chunk
+                if o is self.optG:
+                    # the generator's all-reduce is the one nothing else hides (it sits between errG.backward() and the
+                    # generator's Adam on the main stream): its bucket travels in thirds while the backward is still running
+                    # -- h_net3 / img_net3 at the end of the bucket are differentiated first --, only the last chunk is exposed
+                    c = min(chunk, max(8 << 20, o.numel * 4 // 3))
+                if o.numel * 4 >= 2 * c:
+                    self.reducers[id(o)] = ChunkedReducer(o, c, torch.cuda.Stream())
 
     def sync_replicas(self, src=0):
         """Every rank starts from rank `src`'s weights, EMA shadow, optimizer state and BatchNorm buffers: the step only

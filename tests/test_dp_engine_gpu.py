@@ -111,3 +111,27 @@ def test_two_rank_engine_step_equals_oracle_mean_gradient_step(tmp_path, chunk_m
             failures.append("%s: %d of %d parameter deltas differ from the mean-gradient step by > lr/2" % (name, bad, n))
     print("\n".join(report))
     assert not failures, "; ".join(failures) + " | " + " | ".join(report)
+
+
+def test_two_rank_full_width_shard(tmp_path):
+    """BASELINE config 4's literal shard on two ranks: the benchmark's full-width networks (coco_train.yml, the real Inception
+    encoder, B = 4 per rank, both ranks on cuda:0 over gloo), ranks started from different weights, two steps.  The replicas
+    must be identical afterwards (checksums of every flat parameter bucket and of the EMA shadow), finite, different from each
+    other in what they saw; the generator's bucket and D_NET256's travel in chunks that start during their backward passes."""
+    env = dict(os.environ, MOGAN_DIST_BACKEND="gloo", DP_FULL="1")
+    env.pop("MOGAN_DP_CHUNK_MB", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29990 - os.getpid() % 90), os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r0 = torch.load(str(tmp_path / "rank0.pt"), weights_only=False)
+    r1 = torch.load(str(tmp_path / "rank1.pt"), weights_only=False)
+    for k, v in r0["sums"].items():
+        assert v == r1["sums"][k], "%s differs between the ranks: %s vs %s" % (k, v, r1["sums"][k])
+        if len(v) == 4:
+            assert v[3] and v[2] > 0, "%s: not finite / Adam moments empty" % k
+    assert r0["logs"]["errD2"] != r1["logs"]["errD2"]
+    assert all(abs(x) < 1e6 for x in r0["logs"].values())
+    assert set(r0["reducers"]) == {"G", "D2"}, r0["reducers"]
+    for name, (n, early) in r0["reducers"].items():
+        assert n >= 2 and early >= n - 1, (name, n, early)

@@ -189,6 +189,9 @@ int mogan_pk_conv_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int
 size_t mogan_pk_weight_bytes(int Cout, int Cin, int KH, int KW, int stride, int dgrad);
 int mogan_pk_weight_pack(const float* w, void* wpk, int Cout, int Cin, int KH, int KW, int stride, int ph, int pw, int dgrad,
                          hipStream_t stream);
+/* both copies from one read of w (Cin % 32 == 0 and Cout % 32 == 0): what the owner of the weight calls after its optimizer step */
+int mogan_pk_weight_pack_both(const float* w, void* wpk_fwd, void* wpk_dgrad, int Cout, int Cin, int KH, int KW, int stride, int ph,
+                              int pw, hipStream_t stream);
 int mogan_conv2d_fwd_pk(const float* x, const void* wpk, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
                         int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream);
 int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,

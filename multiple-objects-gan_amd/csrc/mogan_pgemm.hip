@@ -349,6 +349,66 @@ __global__ __launch_bounds__(256) void wpack_kernel(const WpackP p) {
 }
 
 
+// Both directions from ONE read of the fp32 master (what the optimizer's owner calls after every step): block = 32 co x 16 ci
+// x all taps.  Forward panels: rows = co, one (m-tile, k-step) unit per tap.  Data-gradient panels: rows = ci (these 16 are
+// half of an m-tile: 32 of a unit's 64 lane slots), two k-steps of 16 co per tap.  KHW is a template parameter (no run-time
+// divisions), the master is read with 16-byte loads.
+struct Wpack2P { const float* w; unsigned char* Af; unsigned char* Ad; int Cout, Cin, KW, s, ph, pw, KSf, KSd;
+                 unsigned long long cls_stride; };
+
+template <int KHW>
+__global__ __launch_bounds__(256) void wpack2_kernel(const Wpack2P p) {
+    __shared__ float L[KHW * 32 * 17];                 // [tap][32 co][16 ci + 1]
+    const int tid = threadIdx.x;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 16;
+    constexpr int ROW = 16 * KHW;                      // floats per co row of the tile (contiguous in the master)
+    if constexpr (ROW % 4 == 0) {
+        for (int q = tid; q < 32 * ROW / 4; q += 256) {
+            const int mi = q / (ROW / 4), r4 = (q - mi * (ROW / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co0 + mi < p.Cout) v = *(const float4*)(p.w + ((size_t)(co0 + mi) * p.Cin + ci0) * KHW + r4);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int r = r4 + j; L[((r % KHW) * 32 + mi) * 17 + r / KHW] = e[j]; }
+        }
+    } else {
+        for (int q = tid; q < 32 * ROW; q += 256) {
+            const int mi = q / ROW, r = q - mi * ROW;
+            L[((r % KHW) * 32 + mi) * 17 + r / KHW] = (co0 + mi < p.Cout) ? p.w[((size_t)(co0 + mi) * p.Cin + ci0) * KHW + r] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int nkw = p.KW / p.s;
+    for (int it = tid; it < KHW * 128; it += 256) {
+        const int tap = it >> 7, sub = it & 127;
+        uint32_t w[3][4];
+        unsigned char* d;
+        if (sub < 64) {                                  // forward: lane = (co, half of the 16 ci)
+            const int mi = sub & 31, h = sub >> 5;
+            const float* v = &L[(tap * 32 + mi) * 17 + 8 * h];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x6_split2(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+            const int ks = (tap * p.Cin + ci0) >> 4;
+            d = p.Af + ((size_t)blockIdx.x * p.KSf + ks) * 3072 + sub * 16;
+        } else {                                         // data gradient: lane = (ci, half), k-step = co group of 16
+            const int u = sub - 64, cil = u & 15, h = (u >> 4) & 1, kstep = u >> 5;
+            const float* v = &L[(tap * 32 + kstep * 16 + h * 8) * 17 + cil];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x6_split2(v[(2 * j) * 17], v[(2 * j + 1) * 17], w[0][j], w[1][j], w[2][j]);
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int py = ((kh - p.ph) % p.s + p.s) % p.s, px = ((kw - p.pw) % p.s + p.s) % p.s;
+            const int ktap = (kh / p.s) * nkw + (kw / p.s);
+            const int ks = ((ktap * p.Cout + co0) >> 4) + kstep;
+            const int ci = ci0 + cil, lane = (ci & 31) + 32 * h;
+            d = p.Ad + (size_t)(py * p.s + px) * p.cls_stride + ((size_t)(ci >> 5) * p.KSd + ks) * 3072 + lane * 16;
+            if (co0 + kstep * 16 >= p.Cout) continue;    // (Cout % 32 == 0 is required, kept for safety)
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *(uint4*)(d + pl * 1024) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------ fused tails
 // conv -> BatchNorm(train) -> LeakyReLU/ReLU of a deep layer has B*OH*OW <= 2048 values per channel: ONE block computes the
 // batch statistics of 8 channels, applies them and hands the next layer its pixel panel -- instead of split-K reduce,
@@ -717,6 +777,28 @@ int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, in
     apack(dy, (unsigned char*)ws, B, Cout, OH * OW, stream);
     return pk_dgrad_from_panel(ws, wpk, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, (char*)ws + up256(pbytes),
                                ws_bytes - up256(pbytes), stream);
+}
+
+int mogan_pk_weight_pack_both(const float* w, void* wpk_fwd, void* wpk_dgrad, int Cout, int Cin, int KH, int KW, int stride, int ph,
+                              int pw, hipStream_t stream) {
+    PkGeom gf, gd;
+    if (!w || !wpk_fwd || !wpk_dgrad || !pk_geom(Cout, Cin, KH, KW, stride, 0, gf) || !pk_geom(Cout, Cin, KH, KW, stride, 1, gd))
+        return MOGAN_ERR_SHAPE;
+    if (Cin % 32) return MOGAN_ERR_SHAPE;                 // (rows of the data-gradient panels: whole m-tiles)
+    Wpack2P p{};
+    p.w = w; p.Af = (unsigned char*)wpk_fwd; p.Ad = (unsigned char*)wpk_dgrad; p.Cout = Cout; p.Cin = Cin; p.KW = KW; p.s = stride;
+    p.ph = ph; p.pw = pw; p.KSf = gf.KS; p.KSd = gd.KS; p.cls_stride = gd.cls_bytes;
+    const dim3 grid((unsigned)cdiv(Cout, 32), (unsigned)(Cin / 16));
+    switch (KH * KW) {
+        case 16: hipLaunchKernelGGL(wpack2_kernel<16>, grid, dim3(256), 0, stream, p); break;
+        case 9: hipLaunchKernelGGL(wpack2_kernel<9>, grid, dim3(256), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL(wpack2_kernel<1>, grid, dim3(256), 0, stream, p); break;
+        default: {
+            int rc = mogan_pk_weight_pack(w, wpk_fwd, Cout, Cin, KH, KW, stride, ph, pw, 0, stream);
+            return rc ? rc : mogan_pk_weight_pack(w, wpk_dgrad, Cout, Cin, KH, KW, stride, ph, pw, 1, stream);
+        }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 
 size_t mogan_pk_panel_bytes(int B, int C, int HW) { return (B > 0 && C > 0 && HW > 0) ? (size_t)B * HW * C * 6 : 0; }

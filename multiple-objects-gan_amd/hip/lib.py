@@ -39,6 +39,7 @@ SIGNATURES = {
     "mogan_pk_conv_eligible": [I] * 11,
     "mogan_pk_weight_bytes": [I] * 6,
     "mogan_pk_weight_pack": [P, P] + [I] * 8 + [P],
+    "mogan_pk_weight_pack_both": [P, P, P] + [I] * 7 + [P],
     "mogan_conv2d_fwd_pk": [P, P, P] + [I] * 10 + [P, Z, P],
     "mogan_conv2d_dgrad_pk": [P, P, P] + [I] * 10 + [P, Z, P],
     "mogan_pk_debug_force": [I, I, I],

@@ -226,7 +226,21 @@ class WeightPacks:
         PK_STATS["packs"] += 1
 
     def repack(self):
-        """re-pack every copy in use now, on the current stream (the owner just changed the weight)"""
+        """re-pack every copy in use now, on the current stream (the owner just changed the weight): both directions from one
+        read of the master where both are in use (mogan_pk_weight_pack_both)"""
+        s0, s1 = self.slots.get(0), self.slots.get(1)
+        Cout, Cin, KH, KW = self.w.shape
+        if s0 is not None and s1 is not None and s0[3] == s1[3] and Cin % 32 == 0 and Cout % 32 == 0:
+            stride, ph, pw = s0[3]
+            st = stream_ptr()
+            call("mogan_pk_weight_pack_both", ptr(self.w), s0[0].data_ptr(), s1[0].data_ptr(), Cout, Cin, KH, KW, stride, ph, pw, st)
+            ev = torch.cuda.Event()
+            ev.record()
+            cap = bool(lib._capturing())
+            for slot in (s0, s1):
+                slot[1], slot[2], slot[4], slot[5], slot[6] = self.cell[0], _PK_GLOBAL[0], ev, st, cap
+            PK_STATS["packs"] += 1
+            return
         for dgrad, slot in self.slots.items():
             self._pack(dgrad, slot)
 

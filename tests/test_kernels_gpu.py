@@ -574,10 +574,19 @@ def test_packed_weight_convolution(case, force):
         # a changed weight must be re-packed by its owner: same objects, new values
         with torch.no_grad():
             wd.mul_(-0.5)
-        wd._mogan_pk.cell[0] += 1                       # what FlatAdam.touch() does
+        wd._mogan_pk.cell[0] += 1                       # what FlatAdam.touch() does: the copies are rebuilt at their next use
         y2 = ops.conv2d_forward(xd.detach(), wd, s, pad, pad, 0)
         torch.cuda.synchronize()
         _check(y2, -0.5 * ref.detach(), what="fwd after re-pack")
+        with torch.no_grad():
+            wd.mul_(-3.0)
+        wd._mogan_pk.cell[0] += 1
+        wd._mogan_pk.repack()                           # what FlatAdam.step() does: both copies now, from one read of w
+        y3 = ops.conv2d_forward(xd.detach(), wd, s, pad, pad, 0)
+        dx3 = ops.conv2d_dgrad(g.to(DEV), wd, xd.shape, s, pad, pad, 0)
+        torch.cuda.synchronize()
+        _check(y3, 1.5 * ref.detach(), what="fwd after repack()")
+        _check(dx3, 1.5 * x.grad, what="dgrad after repack()")
     finally:
         ops.pk_debug_force(0, -1, 0)
 

@@ -138,6 +138,9 @@ def roofline_leg(engine, run_step, steps=2):
     from mogan_amd.hip import ops
     g, ms_, wg = engine.use_graph, getattr(engine, "multi_stream", False), ops._WGRAD_ENV
     ge = getattr(engine, "graph_encoder", False)
+    bgr = getattr(engine, "branch_graphs", False)
+    if hasattr(engine, "branch_graphs"):
+        engine.branch_graphs = False                  # replayed graphs bypass the per-launch hooks as well
     engine.use_graph = False
     if hasattr(engine, "multi_stream"):
         engine.multi_stream = False
@@ -163,6 +166,8 @@ def roofline_leg(engine, run_step, steps=2):
         engine.multi_stream = ms_
     if hasattr(engine, "graph_encoder"):
         engine.graph_encoder = ge
+    if hasattr(engine, "branch_graphs"):
+        engine.branch_graphs = bgr
     ops._WGRAD_ENV = wg
     rows = []
     for i in range(n):
@@ -472,7 +477,8 @@ def main():
                                "GlobalAttentionGeneral + Inception/DAMSM losses (random-init), coco_train.yml "
                                "widths (GF 48, DF 96, T 12), fp32", "batch_per_gpu": B, "global_batch": world * B,
                    "parallelism": "dp%d" % world,
-                   "launch": "hipGraph" if engine.use_graph else "eager, %d streams + wgrad side streams" % (
+                   "launch": "hipGraph" if engine.use_graph else "%s, %d streams + wgrad side streams" % (
+                       "generator eager + discriminator branches as hipGraphs" if engine.branch_graphs else "eager",
                        1 + (len(engine.side) if engine.multi_stream else 0))},
         "losses": {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.dim() == 0},
     }

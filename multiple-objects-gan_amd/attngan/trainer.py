@@ -512,7 +512,7 @@ class TrainEngine:
         fake_labels = b["z"].new_zeros(B)
         match_labels = b["match_labels"]
         real_feat = {}
-        if self.branch_graphs:
+        if self.branch_graphs and (self._bg is None or self._bg["B"] == B):     # (a ragged last batch runs eagerly)
             return self._branch_graph_step(b, real_labels, fake_labels, match_labels)
         if self.multi_stream:
             # D_i(real) depends neither on the generator nor on the text encoder: it runs beside them.  With an
@@ -658,7 +658,7 @@ class TrainEngine:
         st["fake"] = [t.detach().clone() for t in fake_imgs]
         B = b["z"].shape[0]
         real_labels, fake_labels = b["z"].new_ones(B), b["z"].new_zeros(B)
-        bg = {"static": st, "gR": [], "gU": [], "out": [], "calls": []}
+        bg = {"static": st, "gR": [], "gU": [], "out": [], "calls": [], "B": B}
         torch.cuda.synchronize()
         counter = self.bn_counter
         for i in range(nD):

@@ -453,19 +453,44 @@ __global__ __launch_bounds__(256) void deep_tail_fwd_kernel(const TailP p) {
     const int c0 = blockIdx.x * 8, c = c0 + chl;
     const int NE = p.B * p.HW;
     float v[EPT];
-    double s1 = 0.0, s2 = 0.0;
+    unsigned idx[EPT];                                  // (the tensor has < 2^31 elements: checked by the entry point)
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = j + 32 * i;
-        v[i] = 0.f;
-        if (e < NE) {
-            const int b = e / p.HW, pos = e - b * p.HW;
-            const size_t idx = ((size_t)b * p.C + c) * p.HW + pos;
-            float a = p.src[idx];
-            for (int sp = 1; sp < p.nsplit; ++sp) a += p.src[(size_t)sp * p.slab + idx];
-            if (p.nsplit > 1 || p.src != p.y) p.y[idx] = a;
-            v[i] = a;
-            s1 += (double)a; s2 += (double)a * a;
+        const int b = e / p.HW, pos = e - b * p.HW;
+        idx[i] = ((unsigned)b * p.C + c) * p.HW + pos;
+        v[i] = e < NE ? p.src[idx[i]] : 0.f;
+    }
+    // the K-split slabs in their fixed order, EPT independent loads in flight per slab (a dependent chain of nsplit loads per
+    // element made this kernel 45 us long)
+    constexpr int SB = EPT <= 8 ? 4 : (EPT <= 16 ? 2 : 1);       // slabs per trip: ~32 loads in flight per thread
+    int sp = 1;
+    for (; sp + SB <= p.nsplit; sp += SB) {
+        float a[SB][EPT];
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) a[u][i] = (j + 32 * i) < NE ? p.src[(size_t)(sp + u) * p.slab + idx[i]] : 0.f;
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) v[i] += a[u][i];
+    }
+    for (; sp < p.nsplit; ++sp) {
+        const float* sl = p.src + (size_t)sp * p.slab;
+        float a[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) a[i] = (j + 32 * i) < NE ? sl[idx[i]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) v[i] += a[i];
+    }
+    double s1 = 0.0, s2 = 0.0;
+    const bool wr = p.nsplit > 1 || p.src != p.y;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        if (j + 32 * i < NE) {
+            if (wr) p.y[idx[i]] = v[i];
+            s1 += (double)v[i]; s2 += (double)v[i] * v[i];
         }
     }
     s1 = half_wave_sum(s1); s2 = half_wave_sum(s2);
@@ -486,9 +511,8 @@ __global__ __launch_bounds__(256) void deep_tail_fwd_kernel(const TailP p) {
     for (int i = 0; i < EPT; ++i) {
         const int e = j + 32 * i;
         if (e < NE) {
-            const int b = e / p.HW, pos = e - b * p.HW;
             const float t = act_apply<ACT>(v[i] * sc + sh, p.slope);
-            p.z[((size_t)b * p.C + c) * p.HW + pos] = t;
+            p.z[idx[i]] = t;
             if (p.zpanel) L[chl * NE + e] = t;
         }
     }

@@ -257,6 +257,13 @@ int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
  * BN+residual: 75,80. */
 int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const float* residual, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream);
+/* mogan_bn_stats + mogan_bn_act_fwd in one call (training-mode BatchNorm + activation, model.py:48-81, 575-613): maps with
+ * B*HW <= 4096 values per channel (and HW >= 16) take ONE launch -- a block per output channel reduces, finalises and applies --,
+ * larger ones the three launches of the two calls above; mean / invstd [C] are written for mogan_bn_act_bwd either way (which
+ * takes the matching one-launch kernel for the same shapes).  ws as for mogan_bn_stats. */
+int mogan_bn_act_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* running_mean,
+                           float* running_var, float* mean, float* invstd, float* y, int B, int C, int HW, int act, float slope,
+                           float eps, float momentum, void* ws, size_t ws_bytes, hipStream_t stream);
 /* dy (B,Cy,HW) -> dx (B,C,HW), dgamma[C], dbeta[C] (accumulate != 0 adds into dgamma/dbeta).
  * The residual branch's gradient is dy itself. ws REQUIRED (mogan_bn_ws_bytes). */
 int mogan_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,

@@ -19,6 +19,8 @@ static inline void zero_fill(float* p, size_t n, hipStream_t st) {
     size_t b = (n + 255) / 256; if (b > 65536) b = 65536; if (b < 1) b = 1;
     hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)b), dim3(256), 0, st, p, n);
 }
+#define POOL_LAUNCH(K, total, ...) do { if ((total) < (1ll << 31)) hipLaunchKernelGGL((K<unsigned>), __VA_ARGS__); \
+                                         else hipLaunchKernelGGL((K<long long>), __VA_ARGS__); } while (0)
 static inline unsigned nblk(long long n, int per = 256) {
     long long b = (n + per - 1) / per;
     return (unsigned)(b < 1 ? 1 : (b > 262144 ? 262144 : b));     // grid-stride beyond this
@@ -239,12 +241,15 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ m
 }
 
 // -------------------------------------------------------------------------------- pooling / resize
+// IT = index type: unsigned for tensors below 2^31 elements (every case of the step: 64-bit divisions made these kernels
+// integer-bound, maxpool_bwd 112 us on 88 MB), long long otherwise (POOL_LAUNCH picks)
 // idx (nullable) records the offset a*k+b of the first maximum of each window for the backward
+template <typename IT>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ idx, long long total, int H, int W,
                                                           int OH, int OW, int k, int s, int C, long long ybs) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+    for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < (IT)total; i += (IT)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const IT t = i / OW; const int oy = (int)(t % OH); const IT pl = t / OH;
         const long long yo = (pl / C) * ybs + ((pl % C) * OH + oy) * (long long)OW + ox;     // (strided) output position
         const float* px = x + pl * H * W;
         float m = -INFINITY; int am = 0;
@@ -257,12 +262,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     }
 }
 // gather form: dx[p,iy,ix] = sum over the windows that contain (iy,ix) and whose first maximum is there
+template <typename IT>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy,
                                                           float* __restrict__ dx, long long total, int H, int W, int OH,
                                                           int OW, int k, int s, int C, long long dybs,
                                                           const float* __restrict__ relu_of, int accumulate) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
+    for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < (IT)total; i += (IT)gridDim.x * 256) {
+        const int ix = (int)(i % W); const IT t = i / W; const int iy = (int)(t % H); const IT pl = t / H;
         float g = 0.f;
         const int oy0 = max(0, (iy - k + s) / s), oy1 = min(OH - 1, iy / s);
         const int ox0 = max(0, (ix - k + s) / s), ox1 = min(OW - 1, ix / s);
@@ -276,12 +282,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
         dx[i] = accumulate ? dx[i] + g : g;
     }
 }
+template <typename IT>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           long long total, int H, int W, int OH, int OW, int k, int s,
                                                           int pad) {
     const float inv = 1.f / (float)(k * k);                       // count_include_pad=True
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+    for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < (IT)total; i += (IT)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const IT t = i / OW; const int oy = (int)(t % OH); const IT pl = t / OH;
         const float* px = x + pl * H * W;
         float sum = 0.f;
         for (int a = 0; a < k; ++a) {
@@ -291,12 +298,13 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
         y[i] = sum * inv;
     }
 }
+template <typename IT>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                           long long total, int H, int W, int OH, int OW, int k, int s,
                                                           int pad, const float* __restrict__ relu_of, int accumulate) {
     const float inv = 1.f / (float)(k * k);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ix = (int)(i % W); const long long t = i / W; const int iy = (int)(t % H); const long long pl = t / H;
+    for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < (IT)total; i += (IT)gridDim.x * 256) {
+        const int ix = (int)(i % W); const IT t = i / W; const int iy = (int)(t % H); const IT pl = t / H;
         // windows with oy*s - pad <= iy <= oy*s - pad + k - 1
         const int oy0 = max(0, (iy + pad - k + s) / s), oy1 = min(OH - 1, (iy + pad) / s);
         const int ox0 = max(0, (ix + pad - k + s) / s), ox1 = min(OW - 1, (ix + pad) / s);
@@ -314,11 +322,12 @@ __device__ __forceinline__ void bil_src(int o, float scale, int in, int& i0, int
     if (src < 0.f) src = 0.f;
     i0 = (int)src; i1 = i0 + (i0 < in - 1 ? 1 : 0); l1 = src - (float)i0;
 }
+template <typename IT>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            long long total, int H, int W, int OH, int OW) {
     const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+    for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < (IT)total; i += (IT)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const IT t = i / OW; const int oy = (int)(t % OH); const IT pl = t / OH;
         int y0, y1, x0, x1; float ly, lx;
         bil_src(oy, sh, H, y0, y1, ly); bil_src(ox, sw, W, x0, x1, lx);
         const float* px = x + pl * H * W;
@@ -326,11 +335,12 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
                ly * ((1.f - lx) * px[y1 * W + x0] + lx * px[y1 * W + x1]);
     }
 }
+template <typename IT>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                            long long total, int H, int W, int OH, int OW) {
     const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ox = (int)(i % OW); const long long t = i / OW; const int oy = (int)(t % OH); const long long pl = t / OH;
+    for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < (IT)total; i += (IT)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const IT t = i / OW; const int oy = (int)(t % OH); const IT pl = t / OH;
         int y0, y1, x0, x1; float ly, lx;
         bil_src(oy, sh, H, y0, y1, ly); bil_src(ox, sw, W, x0, x1, lx);
         float* px = dx + pl * H * W;
@@ -552,7 +562,7 @@ int mogan_maxpool_fwd_ex(const float* x, float* y, long long y_bstride, uint8_t*
     const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
     if (y_bstride < 0) y_bstride = (long long)C * OH * OW;
     const long long n = (long long)B * C * OH * OW;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, idx, n, H, W, OH, OW, k, s, C,
+    POOL_LAUNCH(maxpool_fwd_kernel, n, dim3(nblk(n)), dim3(256), 0, stream, x, y, idx, n, H, W, OH, OW, k, s, C,
                        y_bstride);
     return ok_launch();
 }
@@ -566,7 +576,7 @@ int mogan_maxpool_bwd_ex(const uint8_t* idx, const float* dy, long long dy_bstri
     const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
     if (dy_bstride < 0) dy_bstride = (long long)C * OH * OW;
     const long long n = (long long)B * C * H * W;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, idx, dy, dx, n, H, W, OH, OW, k, s, C,
+    POOL_LAUNCH(maxpool_bwd_kernel, n, dim3(nblk(n)), dim3(256), 0, stream, idx, dy, dx, n, H, W, OH, OW, k, s, C,
                        dy_bstride, relu_of, accumulate);
     return ok_launch();
 }
@@ -578,7 +588,7 @@ int mogan_avgpool_fwd(const float* x, float* y, int planes, int H, int W, int k,
     const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
     if (planes <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
     const long long n = (long long)planes * OH * OW;
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW, k, s, pad);
+    POOL_LAUNCH(avgpool_fwd_kernel, n, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW, k, s, pad);
     return ok_launch();
 }
 int mogan_avgpool_bwd_ex(const float* dy, float* dx, const float* relu_of, int accumulate, int planes, int H, int W, int k,
@@ -586,7 +596,7 @@ int mogan_avgpool_bwd_ex(const float* dy, float* dx, const float* relu_of, int a
     if (planes <= 0 || k <= 0 || s <= 0) return MOGAN_ERR_SHAPE;
     const int OH = (H + 2 * pad - k) / s + 1, OW = (W + 2 * pad - k) / s + 1;
     const long long n = (long long)planes * H * W;
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW, k, s, pad, relu_of,
+    POOL_LAUNCH(avgpool_bwd_kernel, n, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW, k, s, pad, relu_of,
                        accumulate);
     return ok_launch();
 }
@@ -597,14 +607,14 @@ int mogan_avgpool_bwd(const float* dy, float* dx, int planes, int H, int W, int 
 int mogan_bilinear_fwd(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
     const long long n = (long long)planes * OH * OW;
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW);
+    POOL_LAUNCH(bilinear_fwd_kernel, n, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, H, W, OH, OW);
     return ok_launch();
 }
 int mogan_bilinear_bwd(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, hipStream_t stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return MOGAN_ERR_SHAPE;
     zero_fill(dx, (size_t)planes * H * W, stream);
     const long long n = (long long)planes * OH * OW;
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW);
+    POOL_LAUNCH(bilinear_bwd_kernel, n, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, H, W, OH, OW);
     return ok_launch();
 }
 

@@ -667,8 +667,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const ReduceP q) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= q.n) return;
-    const long long img = i / q.Mcms, rem = i - img * q.Mcms;
-    const int m = (int)(rem / q.cms);
+    long long img, rem; int m;
+    if (q.n < (1ll << 31)) {              // (uniform) 32-bit index arithmetic: two 64-bit divisions per element otherwise
+        const unsigned iu = (unsigned)i, im = iu / (unsigned)q.Mcms, r = iu - im * (unsigned)q.Mcms;
+        img = im; rem = r; m = (int)(r / (unsigned)q.cms);
+    } else {
+        img = i / q.Mcms; rem = i - img * q.Mcms; m = (int)(rem / q.cms);
+    }
     float* dst = out + img * q.ybs + rem;
     if (m >= q.msplit) dst = q.out2 + img * q.ybs2 + (rem - (long long)q.msplit * q.cms);
     const float* p = ws + i;

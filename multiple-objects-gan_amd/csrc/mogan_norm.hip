@@ -279,6 +279,122 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+
+// -------------------------------------------------------------------------------- one-launch BatchNorm for small maps
+// B*HW <= SMALL_NE values per channel (<= 16x16 maps at B = 16; BatchNorm1d): ONE block per output channel (GLU: per pair)
+// does what bn_partial + bn_finalize + bn_act_fwd (and bn_bwd_partial + finalize + apply) do in three launches -- pass 1
+// reduces over the channel, pass 2 re-reads the L2-resident values and applies.  Same arithmetic (fp64 sums, float apply).
+constexpr int SMALL_NE = 4096;
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           float* __restrict__ y, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, int B, int C, int HW, float eps,
+                                                           float momentum, float slope) {
+    __shared__ double sh[16];
+    __shared__ float st[4];
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.x, NE = B * HW;
+    constexpr int NCH = (ACT == MOGAN_ACT_GLU) ? 2 : 1;
+    double acc[2 * NCH];
+#pragma unroll
+    for (int k = 0; k < 2 * NCH; ++k) acc[k] = 0.0;
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        const int b = e / HW, pos = e - b * HW;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const double v = x[((size_t)b * C + c + k * Cy) * HW + pos];
+            acc[2 * k] += v; acc[2 * k + 1] += v * v;
+        }
+    }
+    block_sum<2 * NCH>(acc, sh);
+    if (threadIdx.x == 0) {
+        const double n = (double)NE;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = c + k * Cy;
+            const double m = acc[2 * k] / n;
+            double var = acc[2 * k + 1] / n - m * m; if (var < 0) var = 0;
+            const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+            mean[ch] = mu; invstd[ch] = is;
+            if (rmean) rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mu;
+            if (rvar) {
+                const double unb = n > 1 ? var * n / (n - 1.0) : var;
+                rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+            }
+            st[2 * k] = mu; st[2 * k + 1] = is;
+        }
+    }
+    __syncthreads();
+    const float sc = gamma[c] * st[1], shf = beta[c] - st[0] * sc;
+    float sc2 = 0.f, sh2 = 0.f;
+    if (ACT == MOGAN_ACT_GLU) { sc2 = gamma[c + Cy] * st[3]; sh2 = beta[c + Cy] - st[2] * sc2; }
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        const int b = e / HW, pos = e - b * HW;
+        const size_t ix = ((size_t)b * C + c) * HW + pos, iy = ((size_t)b * Cy + c) * HW + pos;
+        float t = x[ix] * sc + shf;
+        if (ACT == MOGAN_ACT_GLU) t = t * sigmoidf_(x[ix + (size_t)Cy * HW] * sc2 + sh2);
+        if (ACT == MOGAN_ACT_RELU) t = t > 0.f ? t : 0.f;
+        if (ACT == MOGAN_ACT_LRELU) t = t > 0.f ? t : t * slope;
+        if (res) t += res[iy];
+        y[iy] = t;
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int B, int C, int HW, float slope,
+                                                           int accumulate) {
+    __shared__ double sh_[16];
+    __shared__ float sums[4];
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.x, NE = B * HW;
+    const float mu = mean[c], is = invstd[c];
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+    float mu2 = 0, is2 = 0, sc2 = 0, sh2 = 0;
+    if (ACT == MOGAN_ACT_GLU) { mu2 = mean[c + Cy]; is2 = invstd[c + Cy]; sc2 = gamma[c + Cy] * is2; sh2 = beta[c + Cy] - mu2 * sc2; }
+    double acc[4] = {0, 0, 0, 0};
+    float dummy = 0;
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        const int b = e / HW, pos = e - b * HW;
+        const size_t ia = ((size_t)b * C + c) * HW + pos;
+        const float xa = x[ia], xg = (ACT == MOGAN_ACT_GLU) ? x[ia + (size_t)Cy * HW] : 0.f;
+        float da, dg;
+        act_bwd<ACT>(xa, xg, dy[((size_t)b * Cy + c) * HW + pos], sc, sh, sc2, sh2, slope, da, dg, dummy);
+        acc[0] += da; acc[1] += (double)da * ((xa - mu) * is);
+        if (ACT == MOGAN_ACT_GLU) { acc[2] += dg; acc[3] += (double)dg * ((xg - mu2) * is2); }
+    }
+    block_sum<4>(acc, sh_);
+    if (threadIdx.x == 0) {
+        sums[0] = (float)acc[0]; sums[1] = (float)acc[1]; sums[2] = (float)acc[2]; sums[3] = (float)acc[3];
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + sums[0];
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sums[1];
+        if (ACT == MOGAN_ACT_GLU) {
+            if (dbeta) dbeta[c + Cy] = (accumulate ? dbeta[c + Cy] : 0.f) + sums[2];
+            if (dgamma) dgamma[c + Cy] = (accumulate ? dgamma[c + Cy] : 0.f) + sums[3];
+        }
+    }
+    __syncthreads();
+    const float inv_n = 1.f / ((float)B * (float)HW);
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        const int b = e / HW, pos = e - b * HW;
+        const size_t ia = ((size_t)b * C + c) * HW + pos, ig = ia + (size_t)Cy * HW;
+        const float xa = x[ia], xg = (ACT == MOGAN_ACT_GLU) ? x[ig] : 0.f;
+        float da, dg;
+        act_bwd<ACT>(xa, xg, dy[((size_t)b * Cy + c) * HW + pos], sc, sh, sc2, sh2, slope, da, dg, dummy);
+        dx[ia] = sc * (da - sums[0] * inv_n - (xa - mu) * is * sums[1] * inv_n);
+        if (ACT == MOGAN_ACT_GLU) dx[ig] = sc2 * (dg - sums[2] * inv_n - (xg - mu2) * is2 * sums[3] * inv_n);
+    }
+}
+
+// (BatchNorm1d, HW == 1, keeps its thread-per-channel kernels: a block per channel would be 16 values wide)
+static bool bn_small_ok(int B, int C, int HW) { return HW >= 16 && (long long)B * HW <= SMALL_NE && C <= 65535 * 2; }
+
 // -------------------------------------------------------------------------------- eval affine
 template <int ACT, bool BWD>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -310,6 +426,11 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* mean, const
                        const float* beta, float* dx, float* dgamma, float* dbeta, int B, int C, int HW, float slope,
                        int accumulate, void* ws, hipStream_t stream) {
     const int Cy = ACT == MOGAN_ACT_GLU ? C / 2 : C;
+    if (bn_small_ok(B, C, HW)) {           // small map: one launch (bn_small_bwd_kernel)
+        hipLaunchKernelGGL((bn_small_bwd_kernel<ACT>), dim3(Cy), dim3(256), 0, stream, x, dy, mean, invstd, gamma, beta, dx,
+                           dgamma, dbeta, B, C, HW, slope, accumulate);
+        return ok_launch();
+    }
     Split s = make_split(B, C, HW);
     const int YS = s.bs * s.hs;
     double* part = (double*)ws;
@@ -377,6 +498,31 @@ int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)part, C, YS,
                        (double)B * HW, eps, momentum, mean, invstd, running_mean, running_var);
+    return ok_launch();
+}
+
+// statistics + apply in one call: small maps (B*HW <= 4096 values per channel) take ONE launch, larger ones the three of
+// mogan_bn_stats + mogan_bn_act_fwd.  mean / invstd are written for the backward as by mogan_bn_stats.
+int mogan_bn_act_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* running_mean,
+                           float* running_var, float* mean, float* invstd, float* y, int B, int C, int HW, int act, float slope,
+                           float eps, float momentum, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0 || (act == MOGAN_ACT_GLU && (C & 1))) return MOGAN_ERR_SHAPE;
+    if (!bn_small_ok(B, C, HW)) {
+        int rc = mogan_bn_stats(x, B, C, HW, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream);
+        return rc ? rc : mogan_bn_act_fwd(x, mean, invstd, gamma, beta, residual, y, B, C, HW, act, slope, stream);
+    }
+    const int Cy = act == MOGAN_ACT_GLU ? C / 2 : C;
+#define MOGAN_SMALL_CASE(A) case A: hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Cy), dim3(256), 0, stream, x, gamma, beta, \
+                                                       residual, y, mean, invstd, running_mean, running_var, B, C, HW, eps,   \
+                                                       momentum, slope); break;
+    switch (act) {
+        MOGAN_SMALL_CASE(MOGAN_ACT_NONE)
+        MOGAN_SMALL_CASE(MOGAN_ACT_RELU)
+        MOGAN_SMALL_CASE(MOGAN_ACT_LRELU)
+        MOGAN_SMALL_CASE(MOGAN_ACT_GLU)
+        default: return MOGAN_ERR_SHAPE;
+    }
+#undef MOGAN_SMALL_CASE
     return ok_launch();
 }
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mogan_bn_ws_bytes": [I, I, I],
     "mogan_bn_stats": [P, I, I, I, F, F, P, P, P, P, P, Z, P],
     "mogan_bn_act_fwd": [P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "mogan_bn_act_fwd_fused": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, P, Z, P],
     "mogan_bn_act_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P, Z, P],
     "mogan_affine_act_fwd": [P, P, P, P, I, I, I, I, F, P],
     "mogan_affine_act_bwd": [P, P, P, P, P, I, I, I, I, F, P],

@@ -648,17 +648,15 @@ class BNActFn(torch.autograd.Function):
         wsp, wsn = workspace(dev)
         if need > wsn:
             raise lib.MoganHipError("workspace too small for bn (%d > %d)" % (need, wsn))
-        # three launches (partial sums, finalize, apply).  Folding the finalize into the apply pass (every block re-reducing
-        # its channel's partial sums behind a barrier) was built and measured in round 2: the same single-stream kernel time,
-        # but 3 % SLOWER in the multi-stream step (302 -> 292 img/s) -- the apply kernels' tens of thousands of small blocks
-        # each gained a dependent load + barrier -- so it was dropped.
-        call("mogan_bn_stats", ptr(x), B, C, HW, eps, momentum, ptr(stats[0]), ptr(stats[1]),
-             ptr(running_mean), ptr(running_var), wsp, wsn, stream_ptr())
+        # one call: small maps (<= 4096 values per channel) take ONE launch (a block per channel reduces, finalises and applies),
+        # larger ones three (partial sums, finalize, apply).  Folding the finalize into the apply pass of the LARGE maps
+        # (every block re-reducing its channel's partial sums behind a barrier) was built and measured in round 2: the same
+        # single-stream kernel time, but 3 % SLOWER in the multi-stream step (302 -> 292 img/s), so it was dropped.
         Cy = C // 2 if act == ACT_GLU else C
         y = torch.empty((B, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
         res = _c(residual) if residual is not None else None
-        call("mogan_bn_act_fwd", ptr(x), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(res), ptr(y),
-             B, C, HW, act, slope, stream_ptr())
+        call("mogan_bn_act_fwd_fused", ptr(x), ptr(gamma), ptr(beta), ptr(res), ptr(running_mean), ptr(running_var),
+             ptr(stats[0]), ptr(stats[1]), ptr(y), B, C, HW, act, slope, eps, momentum, wsp, wsn, stream_ptr())
         if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
             ACT_TRACE.append((act, y))
         ctx.save_for_backward(x, gamma, beta, stats)

@@ -220,7 +220,7 @@ def _act_ref(y, act):
     return y
 
 
-@pytest.mark.parametrize("shape", [(4, 8, 8, 8), (3, 6, 15, 15), (16, 24), (2, 10, 64, 64), (5, 4, 3, 3)])
+@pytest.mark.parametrize("shape", [(4, 8, 8, 8), (3, 6, 15, 15), (16, 24), (2, 10, 64, 64), (5, 4, 3, 3), (16, 6, 16, 16), (17, 6, 16, 16)])
 @pytest.mark.parametrize("act", ["none", "relu", "lrelu", "glu"])
 @pytest.mark.parametrize("res", [False, True])
 def test_bn_act(shape, act, res):

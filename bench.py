@@ -388,6 +388,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-text-prefetch", action="store_true", help="text-encode every batch at the start of its own step")
     ap.add_argument("--debug-losses", action="store_true", help="print the losses of every step (adds a host sync)")
     ap.add_argument("--workload", default="attngan", choices=["attngan"] + list(WORKLOADS),
                     help="attngan = the headline metric (default); the others are the secondary BASELINE configs "
@@ -440,6 +441,10 @@ def main():
         b = dict(batch)
         b["z"] = torch.randn(B, cfg.GAN.Z_DIM, device=device, generator=gen)         # trainer.py:294
         b["eps"] = torch.randn(B, cfg.GAN.CONDITION_DIM, device=device, generator=gen)  # model.py:336
+        # the train loop hands the NEXT batch's captions to the engine with every step (one text encoding per step, as in
+        # trainer.py:281-289, software-pipelined one step ahead; condGANTrainer.train does the same)
+        if not args.no_text_prefetch and not engine.use_graph:
+            engine.prefetch_text(batch["captions"], batch["cap_lens_cpu"])
         return engine.step(b)
 
     for _ in range(args.warmup):

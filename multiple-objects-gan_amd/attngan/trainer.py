@@ -532,7 +532,7 @@ class TrainEngine:
                 cur0.wait_event(ready)
         self._phase("text+Gfwd")
         if "words_embs" not in b:        # trainer.py:281-289 (eager path: after the fork above)
-            b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
+            b["words_embs"], b["sent_emb"], b["mask"] = self._text_for(b)
         fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"],
                                         b["label_one_hot"], b.get("eps"))
         out = {}
@@ -596,6 +596,7 @@ class TrainEngine:
             self._phase("D tails + G-step D fwd")
             for i in order[::-1]:
                 d_tail(i)
+            self._text_in_window()
             for s in self.side:
                 cur.wait_stream(s)
             self._phase("G backward")
@@ -738,7 +739,7 @@ class TrainEngine:
             cur.wait_event(ready)
         self._phase("text+Gfwd")
         if "words_embs" not in b:
-            b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
+            b["words_embs"], b["sent_emb"], b["mask"] = self._text_for(b)
         st["sent_emb"].copy_(b["sent_emb"])                # (main stream; the branches wait for it below)
         fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
         out, parts = {}, {}
@@ -771,6 +772,7 @@ class TrainEngine:
         for i in range(nD - 1)[::-1]:
             branch(i)
         self._phase("D tails + G-step D fwd")
+        self._text_in_window()
         for s in self.side:
             cur.wait_stream(s)
         self._phase("G backward")
@@ -792,6 +794,30 @@ class TrainEngine:
         out.update({k: v.detach() for k, v in parts.items()})
         self._phase("end")
         return out
+
+    # -- text embeddings one step ahead --------------------------------------------------------------------------------
+    def prefetch_text(self, captions, cap_lens_cpu):
+        """trainer.py:281-289 for the NEXT batch: call this BEFORE step(current batch).  The frozen text encoder (Embedding +
+        bi-LSTM, ~80 tiny launches, 0.7 ms) needs the captions only; the step runs it on the main stream right after the generator's
+        forward, where that stream otherwise idles for ~25 ms waiting for the discriminator / Inception branches, instead of in front
+        of the next generator forward.  (A separate stream did not help: its packets share an in-order hardware queue with the
+        branch streams and finished just as late.)  step() picks the result up when it is given the very same captions tensor."""
+        self._tx_next = (captions, cap_lens_cpu)
+
+    def _text_in_window(self):
+        """called by the step between the generator forward and the join with the side branches"""
+        nxt, self._tx_next = getattr(self, "_tx_next", None), None
+        if nxt is None:
+            return
+        w, s_, m = self.encode_text(nxt[0], nxt[1])
+        self._tx_ready = (nxt[0], (w, s_, m))
+
+    def _text_for(self, b):
+        """the batch's text embeddings: prefetched (see prefetch_text; same stream, so no event) or computed here"""
+        hit, self._tx_ready = getattr(self, "_tx_ready", None), None
+        if hit is not None and hit[0] is b["captions"]:
+            return hit[1]
+        return self.encode_text(b["captions"], b["cap_lens_cpu"])
 
     def encode_text(self, captions, cap_lens):
         """trainer.py:281-289."""
@@ -1195,14 +1221,28 @@ class condGANTrainer(object):
             sampler = getattr(self.data_loader, "sampler", None)
             if hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)                   # DistributedSampler: a new partition of the epoch per epoch
-            for data in self.data_loader:
+            def prepared(data):
                 if feeder is not None:
                     imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data_raw(data, feeder)
                 else:
                     imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data(data, self.device)
-                batch = dict(imgs=imgs, captions=captions, cap_lens=cap_lens, cap_lens_cpu=cap_lens.cpu(),
-                             class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot,
-                             z=torch.randn(captions.shape[0], nz, device=self.device))
+                return dict(imgs=imgs, captions=captions, cap_lens=cap_lens, cap_lens_cpu=cap_lens.cpu(),
+                            class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot)
+
+            # one batch of look-ahead: while step k runs, batch k+1 is already on the device and its captions go through the frozen
+            # text encoder (TrainEngine.prefetch_text) -- trainer.py:276-289 software-pipelined, one text encoding per batch as there
+            loader = iter(self.data_loader)
+            first = next(loader, None)
+            nxt = prepared(first) if first is not None else None
+            while nxt is not None:
+                batch = nxt
+                batch["z"] = torch.randn(batch["captions"].shape[0], nz, device=self.device)
+                imgs, captions, cap_lens, tmi, label_one_hot = (batch[k] for k in ("imgs", "captions", "cap_lens", "tmi",
+                                                                                   "label_one_hot"))
+                data = next(loader, None)
+                nxt = prepared(data) if data is not None else None
+                if nxt is not None and not self.use_graph:
+                    self.engine.prefetch_text(nxt["captions"], nxt["cap_lens_cpu"])
                 logs = self.engine.step(batch)
                 if gen_iterations % 1000 == 0:        # trainer.py:320-351: the reference increments gen_iterations before
                     # this test, i.e. it first logs / saves at iteration 1000; here the very first iteration is included

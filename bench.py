@@ -174,7 +174,7 @@ def roofline_leg(engine, run_step, steps=2):
     for i in range(n):
         m, c, launches, flops, ms = buf[5 * i:5 * i + 5]
         if int(m) >= 7:         # packed-weight path of the deep discriminator layers (csrc/mogan_pgemm.hip)
-            name = "pgemm_kernel<%s,%s>" % ("fwd" if int(m) == 7 else "dgrad", ("128x64", "128x128", "256x64")[int(c)])
+            name = "pgemm_kernel<%s,%s>" % ({7: "fwd", 8: "dgrad", 9: "wgrad"}[int(m)], ("128x64", "128x128", "256x64")[int(c)])
         elif m < 4:
             name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)])
         elif int(m) == 6:

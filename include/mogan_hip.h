@@ -197,6 +197,12 @@ int mogan_conv2d_fwd_pk(const float* x, const void* wpk, float* y, int B, int Ci
 int mogan_conv2d_dgrad_pk(const float* dy, const void* wpk, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
                           int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream);
 int mogan_pk_debug_force(int take_all, int cfg, int split);
+/* weight gradient of the same weight-heavy layers on the packed kernels: dY and the transposed im2col matrix of x are packed per
+ * call into the workspace (ws_bytes >= what mogan_pk_wgrad_eligible checks: ~ (Cout + Cin*KH*KW) * B*OH*OW * 6 bytes), dW
+ * (Cout,Cin,KH,KW) is written or (accumulate != 0) added to.  Same fp32 products as mogan_conv2d_wgrad, other summation order. */
+int mogan_pk_wgrad_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, size_t ws_bytes);
+int mogan_conv2d_wgrad_pk(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                          int stride, int ph, int pw, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* Deep block = conv -> BatchNorm2d (training statistics) -> LeakyReLU / ReLU / nothing on a map with B*OH*OW <= 2048 values per
  * channel (downBlock / Block3x3_leakRelu of the deep discriminator layers, model.py:575-613, 616-642): the packed-weight GEMM

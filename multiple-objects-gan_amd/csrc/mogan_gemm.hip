@@ -1039,7 +1039,7 @@ int mogan_prof_dump(const char* path) {
 // out: rows of 5 doubles {mode, cfg, launches, algorithmic flops, milliseconds}, one per (mode,cfg) seen
 int mogan_prof_collect(double* out, int max_rows) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    double acc[9][NCFG][3] = {};
+    double acc[10][NCFG][3] = {};
     for (auto& r : g_prof) {
         hipEventSynchronize(r.e1);
         float ms = 0.f;
@@ -1049,7 +1049,7 @@ int mogan_prof_collect(double* out, int max_rows) {
     }
     g_prof.clear();
     int n = 0;
-    for (int m = 0; m < 9; ++m)
+    for (int m = 0; m < 10; ++m)
         for (int c = 0; c < NCFG; ++c)
             if (acc[m][c][0] > 0 && n < max_rows) {
                 double* o = out + 5 * n++;

@@ -409,6 +409,65 @@ __global__ __launch_bounds__(256) void wpack2_kernel(const Wpack2P p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ weight gradient operands
+// dW[co][r] (+)= sum_n dY[co][n] * Xcol[r][n], r = (ci, kh, kw), n = (img, oy, ox): the same GEMM kernel with the roles dealt
+// anew -- dY takes the place of the weights (A panels over K = n, zero-padded to a multiple of 32), the transposed im2col matrix
+// the place of the pixel panel (one "pixel" per row r, its "channels" are the n), the output (Cout x Cin*KH*KW, row-major) IS dW.
+// Both operands are packed per call: the deep layers have K = B*OH*OW <= a few thousand, so the im2col matrix is small
+// (<= 150 MB) while the 300 MB read-modify-write of dW and the 77 GFLOP stay what they are.
+__global__ __launch_bounds__(256) void dypack_kernel(const float* __restrict__ dy, unsigned char* __restrict__ A, int Cout, int OHW,
+                                                     int Npix, int KS) {
+    const long long it = (long long)blockIdx.x * 256 + threadIdx.x;           // (m-tile, k-step, lane)
+    const int lane = (int)(it & 63);
+    const long long u = it >> 6;
+    const int ks = (int)(u % KS), mt = (int)(u / KS);
+    const int co = mt * 32 + (lane & 31);
+    const int n0 = ks * 16 + (lane >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + j;
+        float t = 0.f;
+        if (co < Cout && n < Npix) { const int img = n / OHW, pix = n - img * OHW; t = dy[((size_t)img * Cout + co) * OHW + pix]; }
+        v[j] = t;
+    }
+    uint32_t w[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x6_split2(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+    unsigned char* d = A + ((size_t)mt * KS + ks) * 3072 + lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *(uint4*)(d + pl * 1024) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
+struct XtP { const float* x; unsigned char* P; int Cin, Hs, Ws, KH, KW, s, ph, pw, OH, OW, Npix, KG; long long total; };
+__global__ __launch_bounds__(256) void xtpack_kernel(const XtP p) {
+    const long long it = (long long)blockIdx.x * 256 + threadIdx.x;           // (row r, group of 8 n)
+    if (it >= p.total) return;
+    const int g8 = (int)(it % (p.KG * 4)), r = (int)(it / (p.KG * 4));
+    const int KHW = p.KH * p.KW, ci = r / KHW, tap = r - ci * KHW, kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int OHW = p.OH * p.OW;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = g8 * 8 + j;
+        float t = 0.f;
+        if (n < p.Npix) {
+            const int img = n / OHW, pix = n - img * OHW, oy = pix / p.OW, ox = pix - oy * p.OW;
+            const int iy = oy * p.s - p.ph + kh, ix = ox * p.s - p.pw + kw;
+            if ((unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws)
+                t = p.x[(((size_t)img * p.Cin + ci) * p.Hs + iy) * p.Ws + ix];
+        }
+        v[j] = t;
+    }
+    uint32_t w[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x6_split2(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+    unsigned char* d = p.P + ((size_t)r * p.KG + (g8 >> 2)) * 192 + (g8 & 3) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *(uint4*)(d + pl * 64) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
+
 // ------------------------------------------------------------------------------------------------ fused tails
 // conv -> BatchNorm(train) -> LeakyReLU/ReLU of a deep layer has B*OH*OW <= 2048 values per channel: ONE block computes the
 // batch statistics of 8 channels, applies them and hands the next layer its pixel panel -- instead of split-K reduce,
@@ -744,7 +803,7 @@ namespace {
 // forward GEMM from a ready pixel panel; slabs stay in ws when keep_slabs (see run_pk)
 static int pk_fwd_from_panel(const void* panel, const void* wpk, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
                              int stride, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t stream, bool keep_slabs,
-                             int* nsplit_out) {
+                             int* nsplit_out, int accumulate = 0, int prof_mode = 7) {
     PkGeom g;
     if (!pk_geom(Cout, Cin, KH, KW, stride, 0, g) || B <= 0) return MOGAN_ERR_SHAPE;
     const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
@@ -755,9 +814,9 @@ static int pk_fwd_from_panel(const void* panel, const void* wpk, float* y, int B
     p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)panel; p.C = y;
     p.M = Cout; p.N = B * OH * OW; p.K = g.K; p.Mt = g.Mt; p.KS = g.KS; p.a_cls_stride = g.cls_bytes;
     p.a_bytes = (unsigned)g.cls_bytes; p.p_bytes = (unsigned)pbytes; p.ntile = g.K / 32; p.slab = (long long)B * Cout * OH * OW;
-    p.accumulate = 0; p.dgrad = 0; p.ncls = 1; p.Cc = Cin; p.CG = Cin / 32; p.PH = Hs; p.PW = Ws; p.RH = OH; p.RW = OW;
+    p.accumulate = accumulate; p.dgrad = 0; p.ncls = 1; p.Cc = Cin; p.CG = Cin / 32; p.PH = Hs; p.PW = Ws; p.RH = OH; p.RW = OW;
     p.s = stride; p.ph = ph; p.pw = pw; p.nkw = KW; p.outH = OH; p.outW = OW;
-    const int rc = run_pk(p, ws, ws_bytes, 7, stream, keep_slabs);
+    const int rc = run_pk(p, ws, ws_bytes, prof_mode, stream, keep_slabs);
     if (nsplit_out) *nsplit_out = p.nsplit;
     return rc;
 }
@@ -823,6 +882,49 @@ int mogan_pk_weight_pack_both(const float* w, void* wpk_fwd, void* wpk_dgrad, in
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+static bool wgrad_pk_sizes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int& OH, int& OW,
+                           int& Kpad, long long& R, size_t& abytes, size_t& pbytes) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Hs <= 0 || Ws <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return false;
+    OH = (Hs + 2 * ph - KH) / stride + 1; OW = (Ws + 2 * pw - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return false;
+    const long long npix = (long long)B * OH * OW;
+    if (npix > (1 << 20)) return false;
+    Kpad = (int)((npix + 31) / 32 * 32);
+    R = (long long)Cin * KH * KW;
+    abytes = up256((size_t)((Cout + 31) / 32) * 32 * Kpad * 6);
+    pbytes = up256((size_t)R * Kpad * 6);
+    return pbytes < (1ull << 32) && (long long)Cout * R < (1ll << 31);
+}
+
+int mogan_pk_wgrad_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, size_t ws_bytes) {
+    int OH, OW, Kpad; long long R; size_t ab, pb;
+    if (!wgrad_pk_sizes(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, OH, OW, Kpad, R, ab, pb)) return 0;
+    if (ab + pb > ws_bytes) return 0;
+    if (g_pk_force) return 1;
+    // measured (tools/time_pk_wgrad.py): ahead of the implicit-GEMM kernel only where dW is large (>= 16M elements: the epilogue's
+    // read-modify-write is most of the work and the 128x64 tiles stream it best) and K pays for the two packs
+    return OH * OW <= 64 && Kpad >= 512 && (long long)Cout * R >= (16ll << 20);
+}
+
+int mogan_conv2d_wgrad_pk(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                          int stride, int ph, int pw, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    int OH, OW, Kpad; long long R; size_t ab, pb;
+    if (!dy || !x || !dw || !wgrad_pk_sizes(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, OH, OW, Kpad, R, ab, pb)) return MOGAN_ERR_SHAPE;
+    if (!ws || ab + pb > ws_bytes) return MOGAN_ERR_WS;
+    unsigned char* A = (unsigned char*)ws;
+    unsigned char* P = A + ab;
+    const int Mt = (Cout + 31) / 32, KS = Kpad / 16, npix = B * OH * OW;
+    hipLaunchKernelGGL(dypack_kernel, dim3((unsigned)cdiv((long long)Mt * KS * 64, 256)), dim3(256), 0, stream, dy, A, Cout, OH * OW,
+                       npix, KS);
+    XtP q{};
+    q.x = x; q.P = P; q.Cin = Cin; q.Hs = Hs; q.Ws = Ws; q.KH = KH; q.KW = KW; q.s = stride; q.ph = ph; q.pw = pw; q.OH = OH; q.OW = OW;
+    q.Npix = npix; q.KG = Kpad / 32; q.total = R * (Kpad / 8);
+    hipLaunchKernelGGL(xtpack_kernel, dim3((unsigned)cdiv(q.total, 256)), dim3(256), 0, stream, q);
+    // dW (Cout x R) = "1x1 convolution" of the R-pixel, Kpad-channel panel with the Cout x Kpad "filters" dY
+    return pk_fwd_from_panel(P, A, dw, 1, Kpad, (int)R, 1, Cout, 1, 1, 1, 0, 0, (char*)ws + ab + pb, ws_bytes - ab - pb, stream, false,
+                             nullptr, accumulate, 9);
 }
 
 size_t mogan_pk_panel_bytes(int B, int C, int HW) { return (B > 0 && C > 0 && HW > 0) ? (size_t)B * HW * C * 6 : 0; }

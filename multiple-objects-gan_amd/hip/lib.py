@@ -43,6 +43,8 @@ SIGNATURES = {
     "mogan_conv2d_fwd_pk": [P, P, P] + [I] * 10 + [P, Z, P],
     "mogan_conv2d_dgrad_pk": [P, P, P] + [I] * 10 + [P, Z, P],
     "mogan_pk_debug_force": [I, I, I],
+    "mogan_pk_wgrad_eligible": [I] * 10 + [Z],
+    "mogan_conv2d_wgrad_pk": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_pk_panel_bytes": [I, I, I],
     "mogan_deep_block_eligible": [I] * 11,
     "mogan_deep_conv_bn_act_fwd": [P] * 11 + [I] * 10 + [F, F, I, F, P, Z, P],

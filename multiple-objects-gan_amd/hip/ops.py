@@ -194,7 +194,9 @@ def _is_upconv(w_shape, stride, ph, pw, up):
 # pass); anything else that writes weights calls FlatAdam.touch() / invalidate_all_packs().  A parameter without the
 # attribute (plain modules, the kernel tests' default) takes the unpacked kernels.
 PK_ENABLED = os.environ.get("MOGAN_PK", "1") != "0"
-PK_STATS = {"fwd": 0, "dgrad": 0, "packs": 0}      # launches through the packed path (tests, diagnostics)
+PK_STATS = {"fwd": 0, "dgrad": 0, "wgrad": 0, "packs": 0}      # launches through the packed path (tests, diagnostics)
+PK_WGRAD = os.environ.get("MOGAN_PK_WGRAD", "1") != "0"          # the deep layers' weight gradients on the packed kernels too
+_pk_wgrad_elig = {}
 _PK_GLOBAL = [0]
 
 
@@ -337,6 +339,16 @@ def conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=None, accumulate=False)
     Cout, _, KH, KW = w_shape
     wsp, wsn = workspace(dy.device)
     dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=dy.device)
+    if PK_ENABLED and PK_WGRAD and not up:
+        key = (B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, wsn)
+        e = _pk_wgrad_elig.get(key)
+        if e is None:
+            e = _pk_wgrad_elig[key] = bool(lib.load().mogan_pk_wgrad_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, wsn))
+        if e:
+            call("mogan_conv2d_wgrad_pk", ptr(dy), ptr(x), ptr(dw), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw,
+                 1 if accumulate else 0, wsp, wsn, stream_ptr())
+            PK_STATS["wgrad"] = PK_STATS.get("wgrad", 0) + 1
+            return dw
     if _is_upconv(w_shape, stride, ph, pw, up):
         call("mogan_upconv3x3_wgrad", ptr(dy), ptr(x), ptr(dw), B, Cin, Hs, Ws, Cout, 1 if accumulate else 0, wsp, wsn,
              stream_ptr())
@@ -438,6 +450,7 @@ def pk_debug_force(take_all, cfg=-1, split=0):
     """test hook (mogan_pk_debug_force) + the host-side eligibility caches it invalidates"""
     lib.load().mogan_pk_debug_force(int(take_all), int(cfg), int(split))
     _deep_elig.clear()
+    _pk_wgrad_elig.clear()
 
 
 def deep_block_eligible(x, w, stride, ph, pw, act):

@@ -591,6 +591,47 @@ def test_packed_weight_convolution(case, force):
         ops.pk_debug_force(0, -1, 0)
 
 
+PK_WGRAD_CASES = PK_CASES + [
+    (4, 20, 9, 7, 50, 3, 2, 1),        # nothing aligned: Cin, Cout, the map and K = 4*5*4 = 80 output pixels (padded to 96)
+    (33, 16, 4, 4, 40, 4, 1, 0),       # 1x1 outputs: K = 33
+]
+
+
+@pytest.mark.parametrize("case", PK_WGRAD_CASES)
+@pytest.mark.parametrize("force", [(-1, 0), (0, 2), (1, 1), (2, 3)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_packed_weight_gradient(case, force, accumulate):
+    """mogan_conv2d_wgrad_pk: dW = dY x im2col(x)^T on the packed-operand kernel (dY and the transposed im2col matrix packed per
+    call) against fp64, every tile shape, with K-splits, written and accumulated."""
+    B, Cin, H, W, Cout, k, s, pad = case
+    ops.pk_debug_force(1, force[0], force[1])
+    before = ops.PK_STATS["wgrad"]
+    try:
+        x = T("pwx%s" % (case,), (B, Cin, H, W))
+        w = T("pww%s" % (case,), (Cout, Cin, k, k), 0.2).requires_grad_(True)
+        ref = F.conv2d(x.double(), w.double(), None, s, pad)
+        g = T("pwg%s" % (case,), ref.shape)
+        ref.backward(g.double())
+        base = T("pwb%s" % (case,), w.shape)
+        out = base.clone().to(DEV) if accumulate else torch.full(w.shape, float("nan"), device=DEV)
+        dw = ops.conv2d_wgrad(g.to(DEV), x.to(DEV), w.shape, s, pad, pad, 0, out=out, accumulate=accumulate)
+        torch.cuda.synchronize()
+        assert ops.PK_STATS["wgrad"] == before + 1, "the packed weight-gradient path was not taken"
+        _check(dw, w.grad + (base.double() if accumulate else 0.0), what="wgrad")
+    finally:
+        ops.pk_debug_force(0, -1, 0)
+
+
+def test_packed_weight_gradient_eligibility():
+    e = lib.load().mogan_pk_wgrad_eligible
+    ws = 256 << 20
+    assert e(32, 1536, 8, 8, 3072, 4, 4, 2, 1, 1, ws) == 1 and e(32, 768, 16, 16, 1536, 4, 4, 2, 1, 1, ws) == 1
+    assert e(32, 384, 16, 16, 384, 4, 4, 2, 1, 1, ws) == 0           # small dW: the implicit-GEMM kernel is ahead
+    assert e(16, 96, 128, 128, 192, 4, 4, 2, 1, 1, ws) == 0          # wide map: the im2col matrix would be the large operand
+    assert e(32, 1536, 8, 8, 3072, 4, 4, 2, 1, 1, 1 << 20) == 0      # operands do not fit the workspace
+    assert e(4, 1536, 4, 4, 768, 3, 3, 1, 1, 1, ws) == 0             # K = 64 output pixels: not worth two packs
+
+
 def test_packed_weight_eligibility():
     """mogan_pk_conv_eligible: the deep discriminator layers of the benchmark qualify, wide / thin / misaligned ones do not."""
     e = lib.load().mogan_pk_conv_eligible

@@ -271,6 +271,19 @@ class ChunkedReducer:
         self.done.append(ev)
         self.launched.add(ci)
 
+    def reduce_now(self):
+        """Branch graphs: the backward that fills the bucket is one replayed hipGraph -- no hook fires, nothing can leave early.
+        The whole bucket, chunk by chunk (the first chunks are summed while the later ones still travel), behind everything
+        queued on the current stream; the current stream then waits for all of them.  The learned schedule of the eager path
+        (`expected`) is left alone."""
+        self.counts, self.done, self.launched, self.late, self.active, self.early = {}, [], set(), [], False, 0
+        for ci in range(len(self.chunks)):
+            self._launch(ci)
+        cur = torch.cuda.current_stream()
+        for ev in self.done:
+            cur.wait_event(ev)
+        return len(self.chunks)
+
     def finish(self):
         """after the backward (and the weight-gradient join): reduce the chunks not yet on their way, then make the current
         stream wait for all of them"""
@@ -330,7 +343,12 @@ class TrainEngine:
         # structure of the eager step is unchanged.  MOGAN_BRANCH_GRAPHS=0 / branch_graphs=False: everything eager.
         if branch_graphs is None:
             branch_graphs = os.environ.get("MOGAN_BRANCH_GRAPHS", "1") != "0"
-        self.branch_graphs = bool(branch_graphs) and self.multi_stream and not self.distributed and not use_graph
+        # Under data parallelism the second graph of a branch is cut once more, between the backward and Adam: the bucket's
+        # all-reduce is issued eagerly between the two replays (collectives are not captured); MOGAN_BRANCH_GRAPHS_DP=0 keeps
+        # the eager step with its hook-driven ChunkedReducer for the discriminators as well.
+        if self.distributed and os.environ.get("MOGAN_BRANCH_GRAPHS_DP", "1") == "0":
+            branch_graphs = False
+        self.branch_graphs = bool(branch_graphs) and self.multi_stream and not use_graph
         self._bg = None
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
         bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
@@ -659,9 +677,14 @@ class TrainEngine:
         st["fake"] = [t.detach().clone() for t in fake_imgs]
         B = b["z"].shape[0]
         real_labels, fake_labels = b["z"].new_ones(B), b["z"].new_zeros(B)
-        bg = {"static": st, "gR": [], "gU": [], "out": [], "calls": [], "B": B}
+        bg = {"static": st, "gR": [], "gU": [], "gA": [], "out": [], "calls": [], "B": B}
         torch.cuda.synchronize()
         counter = self.bn_counter
+        # no collective may be captured: the reducers' hooks (armed by zero_grad) stay silent while the backward is recorded
+        hooks = [(o, o.on_zero) for o in self.optDs if getattr(o, "on_zero", None) is not None]
+        for o, _ in hooks:
+            o.on_zero = None
+            self.reducers[id(o)].active = False
         for i in range(nD):
             s = self.side[i]
             if os.environ.get("MOGAN_BG_WGRAD", "0") != "0":      # 1: fork the weight gradients inside the branch graphs (measured: a forked graph replays slowly, 47.1 vs 42.1 ms per step)
@@ -670,16 +693,14 @@ class TrainEngine:
             pool = torch.cuda.graph_pool_handle()
             calls0 = list(counter.calls)
             gR, gU = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            gA = torch.cuda.CUDAGraph() if self.distributed else None
             with _lib.capture_guard():
                 with torch.cuda.graph(gR, pool=pool, stream=s):
                     self.optDs[i].zero_grad()
                     feat = _call_d(netsD[i], st["imgs"][i], kw.get("local_labels"), kw.get("transf_matrices"),
                                    kw.get("transf_matrices_inv"))
-                with torch.cuda.graph(gU, pool=pool, stream=s):
-                    errD = discriminator_loss(netsD[i], st["imgs"][i], st["fake"][i], st["sent_emb"], real_labels, fake_labels,
-                                              None, real_features=feat, **kw)
-                    with ops.wgrad_overlap():
-                        errD.backward()
+                def tail(errD):
+                    # Adam (+ re-pack), then the generator-step forward through the updated D_i and its image gradient
                     self._opt_step(self.optDs[i], None)
                     for p in netsD[i].parameters():
                         p.requires_grad_(False)
@@ -688,11 +709,24 @@ class TrainEngine:
                     g_img, = torch.autograd.grad(g_loss, leaf)
                     for p in netsD[i].parameters():
                         p.requires_grad_(True)
-                    out = (errD.detach(), g_loss.detach(), g_img)
-            del feat, errD, g_loss, leaf
-            bg["gR"].append(gR); bg["gU"].append(gU); bg["out"].append(out)
+                    return (errD.detach(), g_loss.detach(), g_img)
+
+                with torch.cuda.graph(gU, pool=pool, stream=s):
+                    errD = discriminator_loss(netsD[i], st["imgs"][i], st["fake"][i], st["sent_emb"], real_labels, fake_labels,
+                                              None, real_features=feat, **kw)
+                    with ops.wgrad_overlap():
+                        errD.backward()
+                    if gA is None:
+                        out = tail(errD)
+                if gA is not None:
+                    with torch.cuda.graph(gA, pool=pool, stream=s):      # replayed behind the bucket's all-reduce
+                        out = tail(errD.detach())
+            del feat, errD
+            bg["gR"].append(gR); bg["gU"].append(gU); bg["gA"].append(gA); bg["out"].append(out)
             bg["calls"].append([a - c for a, c in zip(counter.calls, calls0)])     # BatchNorm calls the replays stand for
             counter.calls = calls0
+        for o, h in hooks:
+            o.on_zero = h
         torch.cuda.synchronize()
         return bg
 
@@ -753,6 +787,13 @@ class TrainEngine:
             with torch.cuda.stream(s):
                 st["fake"][i].copy_(fake_imgs[i].detach())
                 bg["gU"][i].replay()
+                if bg["gA"][i] is not None:                # data parallel: sum the bucket over the ranks, then Adam and the rest
+                    red = self.reducers.get(id(self.optDs[i]))
+                    if red is not None:
+                        red.reduce_now()
+                    elif not self._debug_no_ar:
+                        allreduce_flat(self.optDs[i].g, None)
+                    bg["gA"][i].replay()
             for j, n in enumerate(bg["calls"][i]):
                 self.bn_counter.calls[j] += n
 
@@ -788,7 +829,7 @@ class TrainEngine:
         with ops.wgrad_overlap():
             torch.autograd.backward(list(fake_imgs) + [kl_loss], grads + [None])
         self._phase("G adam")
-        self._opt_step(self.optG, None)
+        self._opt_step(self.optG, self._allreduce_async(self.optG))
         self.bn_counter.flush()
         out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach(), fake_last=fake_imgs[-1].detach())
         out.update({k: v.detach() for k, v in parts.items()})

@@ -193,8 +193,12 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 # (4,0) 357-364 img/s in seven runs on three boxes, (4,2) 361, (3,3) 341-349, (4,1) 329, (4,3) 326-332, (4,4) 350, (5..8, 0)
 # 257-264.  With the RCCL process group of a 1-GPU world: (3,3) 338-342, (4,3) 344-346, (4,0) 324-332.  A single process
 # therefore runs on (4 queues, no idle streams) -- its stream creation order is fixed by this code alone --, a member of a
-# process group keeps the (3 queues, 3 idle streams) plateau, because how many streams RCCL creates on a real multi-GPU
-# node has not been measured by the builder.
+# process group kept the (3 queues, 3 idle streams) plateau.
+#
+# Round 3, discriminator branches as hipGraphs also under data parallelism (trainer.py, MOGAN_BRANCH_GRAPHS_DP): member of a
+# 1-rank RCCL group (tools/dp_bg_probe.sh): (4,3) 395 / 395, (4,2) 395, (4,0) 366, (3,3) 364 img/s; eager branches (4,3) 373,
+# (3,3) 370 -- a member of a process group now runs on (4 queues, 3 idle streams); RCCL's stream count on a real multi-GPU
+# node is still unmeasured by the builder (GPU_MAX_HW_QUEUES / MOGAN_RESERVED_STREAMS override both).
 HW_QUEUES_DEFAULT = "3"
 _reserved = []
 
@@ -205,7 +209,7 @@ def _single_process():
 
 def hw_queue_defaults():
     """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above)"""
-    return ("4", 0) if _single_process() else (HW_QUEUES_DEFAULT, 3)
+    return ("4", 0) if _single_process() else ("4", 3)
 
 
 def configure_hw_queues():

@@ -213,6 +213,23 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const float* pxa = x + ((size_t)b * C + c) * HW;
         const float* pxg = pxa + (size_t)Cy * HW;
         const float* pdy = dy + ((size_t)b * Cy + c) * HW;
+        if ((HW & 3) == 0) {                       // (h0, h1 are multiples of 4 then: Split::hper is)
+            for (int i = h0 + threadIdx.x * 4; i < h1; i += 1024) {
+                const float4 xa4 = *(const float4*)(pxa + i), dy4 = *(const float4*)(pdy + i);
+                float4 xg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ACT == MOGAN_ACT_GLU) xg4 = *(const float4*)(pxg + i);
+                const float xa_[4] = {xa4.x, xa4.y, xa4.z, xa4.w}, xg_[4] = {xg4.x, xg4.y, xg4.z, xg4.w};
+                const float dy_[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float da, dg;
+                    act_bwd<ACT>(xa_[k], xg_[k], dy_[k], sc, sh, sc2, sh2, slope, da, dg, dummy);
+                    acc[0] += da; acc[1] += (double)da * ((xa_[k] - mu) * is);
+                    if (ACT == MOGAN_ACT_GLU) { acc[2] += dg; acc[3] += (double)dg * ((xg_[k] - mu2) * is2); }
+                }
+            }
+            continue;
+        }
         for (int i = h0 + threadIdx.x; i < h1; i += 256) {
             const float xa = pxa[i], xg = (ACT == MOGAN_ACT_GLU) ? pxg[i] : 0.f;
             float da, dg;
@@ -276,6 +293,151 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (ACT == MOGAN_ACT_GLU) {
         const int cg = c + Cy;
         dx[ig] = sc2 * (dg - sums[cg * 2] * inv_n - (xg - mu2) * is2 * sums[cg * 2 + 1] * inv_n);
+    }
+}
+
+
+// -------------------------------------------------------------------------------- finalize folded into the apply pass
+// HW % 4 == 0 maps beyond the one-launch size: the per-channel reduction of the partial sums (bn_finalize_kernel /
+// bn_bwd_finalize_kernel, one tiny launch each) moves into the apply kernels -- every wave sums its channel's YS partial
+// entries (lanes stride the entries, xor-butterfly: all lanes hold the same fp64 totals, no LDS, no barrier) and the block
+// (first tile of the first image) also writes what the finalize kernel wrote: mean / invstd / running statistics, dgamma / dbeta.
+// Two launches per direction instead of three; each block covers 4096 values of one (image, channel) plane.
+__device__ __forceinline__ double wave_allsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int NV, int STRIDE>
+__device__ __forceinline__ void part_sums(const double* __restrict__ part, int c, int YS, double (&a)[NV]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] = 0.0;
+    for (int y = lane; y < YS; y += 64)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) a[k] += part[((size_t)c * YS + y) * STRIDE + k];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] = wave_allsum(a[k]);
+}
+__device__ __forceinline__ void stats_of(const double (&a)[2], double n, float eps, float& mean, float& invstd, double& var) {
+    const double m = a[0] / n;
+    var = a[1] / n - m * m; if (var < 0) var = 0;
+    mean = (float)m; invstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+__device__ __forceinline__ void write_stats(int c, float mean, float invstd, double var, double n, float momentum,
+                                            float* __restrict__ mo, float* __restrict__ io, float* __restrict__ rmean,
+                                            float* __restrict__ rvar) {
+    mo[c] = mean; io[c] = invstd;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    if (rvar) {
+        const double unb = n > 1 ? var * n / (n - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+constexpr int FUSED_PER = 4096;     // values of one plane per block
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_fwd_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ res, float* __restrict__ y,
+                                                                 float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                                 float* __restrict__ rmean, float* __restrict__ rvar, int C, int HW,
+                                                                 int YS, double n, float eps, float momentum, float slope,
+                                                                 int writer) {
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.y % Cy, b = blockIdx.y / Cy;
+    const bool wr = writer && blockIdx.x == 0 && b == 0 && threadIdx.x == 0;
+    double a[2], var;
+    float mu, is, mu2 = 0.f, is2 = 0.f;
+    part_sums<2, 2>(part, c, YS, a);
+    stats_of(a, n, eps, mu, is, var);
+    if (wr) write_stats(c, mu, is, var, n, momentum, mean_o, invstd_o, rmean, rvar);
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+    float sc2 = 0.f, sh2 = 0.f;
+    if (ACT == MOGAN_ACT_GLU) {
+        const int cg = c + Cy;
+        part_sums<2, 2>(part, cg, YS, a);
+        stats_of(a, n, eps, mu2, is2, var);
+        if (wr) write_stats(cg, mu2, is2, var, n, momentum, mean_o, invstd_o, rmean, rvar);
+        sc2 = gamma[cg] * is2; sh2 = beta[cg] - mu2 * sc2;
+    }
+    const float* px = x + ((size_t)b * C + c) * HW;
+    float* py = y + ((size_t)b * Cy + c) * HW;
+    const float* pr = res ? res + ((size_t)b * Cy + c) * HW : nullptr;
+    const int i0 = blockIdx.x * FUSED_PER, i1 = min(HW, i0 + FUSED_PER);
+    for (int i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+        const float4 t = *(const float4*)(px + i);
+        const float v[4] = {t.x, t.y, t.z, t.w};
+        float o[4];
+        if (ACT == MOGAN_ACT_GLU) {
+            const float4 u = *(const float4*)(px + (size_t)Cy * HW + i);
+            const float g[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[k] * sc + sh) * sigmoidf_(g[k] * sc2 + sh2);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float w = v[k] * sc + sh;
+                if (ACT == MOGAN_ACT_RELU) w = w > 0.f ? w : 0.f;
+                if (ACT == MOGAN_ACT_LRELU) w = w > 0.f ? w : w * slope;
+                o[k] = w;
+            }
+        }
+        if (pr) { const float4 r = *(const float4*)(pr + i); o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+        *(float4*)(py + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const double* __restrict__ part, float* __restrict__ dx,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int HW,
+                                                                 int YS, float slope, float inv_n, int accumulate, int writer) {
+    constexpr int NV = (ACT == MOGAN_ACT_GLU) ? 4 : 2;
+    const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
+    const int c = blockIdx.y % Cy, b = blockIdx.y / Cy, cg = c + Cy;
+    double a[NV];
+    part_sums<NV, 4>(part, c, YS, a);
+    const float s0 = (float)a[0], s1 = (float)a[1];
+    float s2 = 0.f, s3 = 0.f;
+    if (ACT == MOGAN_ACT_GLU) { s2 = (float)a[NV - 2]; s3 = (float)a[NV - 1]; }
+    if (writer && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s0;
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s1;
+        if (ACT == MOGAN_ACT_GLU) {
+            if (dbeta) dbeta[cg] = (accumulate ? dbeta[cg] : 0.f) + s2;
+            if (dgamma) dgamma[cg] = (accumulate ? dgamma[cg] : 0.f) + s3;
+        }
+    }
+    const float mu = mean[c], is = invstd[c];
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+    float mu2 = 0, is2 = 0, sc2 = 0, sh2 = 0;
+    if (ACT == MOGAN_ACT_GLU) { mu2 = mean[cg]; is2 = invstd[cg]; sc2 = gamma[cg] * is2; sh2 = beta[cg] - mu2 * sc2; }
+    const float* pxa = x + ((size_t)b * C + c) * HW;
+    const float* pxg = pxa + (size_t)Cy * HW;
+    const float* pdy = dy + ((size_t)b * Cy + c) * HW;
+    float* pda = dx + ((size_t)b * C + c) * HW;
+    float* pdg = pda + (size_t)Cy * HW;
+    const int i0 = blockIdx.x * FUSED_PER, i1 = min(HW, i0 + FUSED_PER);
+    float dummy = 0;
+    for (int i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+        const float4 xa4 = *(const float4*)(pxa + i), dy4 = *(const float4*)(pdy + i);
+        float4 xg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACT == MOGAN_ACT_GLU) xg4 = *(const float4*)(pxg + i);
+        const float xa_[4] = {xa4.x, xa4.y, xa4.z, xa4.w}, xg_[4] = {xg4.x, xg4.y, xg4.z, xg4.w}, dy_[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
+        float oa[4], og[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float da, dg;
+            act_bwd<ACT>(xa_[k], xg_[k], dy_[k], sc, sh, sc2, sh2, slope, da, dg, dummy);
+            oa[k] = sc * (da - s0 * inv_n - (xa_[k] - mu) * is * s1 * inv_n);
+            og[k] = (ACT == MOGAN_ACT_GLU) ? sc2 * (dg - s2 * inv_n - (xg_[k] - mu2) * is2 * s3 * inv_n) : 0.f;
+        }
+        *(float4*)(pda + i) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        if (ACT == MOGAN_ACT_GLU) *(float4*)(pdg + i) = make_float4(og[0], og[1], og[2], og[3]);
     }
 }
 
@@ -393,6 +555,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 }
 
 // (BatchNorm1d, HW == 1, keeps its thread-per-channel kernels: a block per channel would be 16 values wide)
+static bool bn_fused_env() { static const bool on = !(getenv("MOGAN_BN_FUSED") && getenv("MOGAN_BN_FUSED")[0] == '0'); return on; }
+static bool bn_fused_ok(int HW) { return (HW & 3) == 0 && HW >= 64 && bn_fused_env(); }
 static bool bn_small_ok(int B, int C, int HW) { return HW >= 16 && (long long)B * HW <= SMALL_NE && C <= 65535 * 2; }
 
 // -------------------------------------------------------------------------------- eval affine
@@ -437,11 +601,20 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* mean, const
     float* sums = (float*)((char*)ws + (size_t)C * YS * 4 * sizeof(double));
     hipLaunchKernelGGL((bn_bwd_partial_kernel<ACT>), dim3(Cy, YS), dim3(256), 0, stream, x, dy, mean, invstd, gamma,
                        beta, B, C, HW, s, slope, part);
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<ACT>), dim3((Cy + 255) / 256), dim3(256), 0, stream,
-                       (const double*)part, C, YS, sums, dgamma, dbeta, accumulate);
     const float inv_n = 1.f / ((float)B * (float)HW);
     const int bchunk = 65535 / Cy;
     if (bchunk < 1) return MOGAN_ERR_SHAPE;
+    if (bn_fused_ok(HW)) {                 // finalize folded into the apply pass: two launches
+        for (int b0 = 0; b0 < B; b0 += bchunk) {
+            const int nb = B - b0 < bchunk ? B - b0 : bchunk;
+            hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<ACT>), dim3((HW + FUSED_PER - 1) / FUSED_PER, nb * Cy), dim3(256), 0, stream,
+                               x + (size_t)b0 * C * HW, dy + (size_t)b0 * Cy * HW, mean, invstd, gamma, beta, (const double*)part,
+                               dx + (size_t)b0 * C * HW, dgamma, dbeta, C, HW, YS, slope, inv_n, accumulate, b0 == 0 ? 1 : 0);
+        }
+        return ok_launch();
+    }
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<ACT>), dim3((Cy + 255) / 256), dim3(256), 0, stream,
+                       (const double*)part, C, YS, sums, dgamma, dbeta, accumulate);
     for (int b0 = 0; b0 < B; b0 += bchunk) {
         const int nb = B - b0 < bchunk ? B - b0 : bchunk;
         hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT>), dim3((HW + 255) / 256, nb * Cy), dim3(256), 0, stream,
@@ -507,11 +680,38 @@ int mogan_bn_act_fwd_fused(const float* x, const float* gamma, const float* beta
                            float* running_var, float* mean, float* invstd, float* y, int B, int C, int HW, int act, float slope,
                            float eps, float momentum, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (B <= 0 || C <= 0 || HW <= 0 || (act == MOGAN_ACT_GLU && (C & 1))) return MOGAN_ERR_SHAPE;
+    const int Cy = act == MOGAN_ACT_GLU ? C / 2 : C;
+    if (!bn_small_ok(B, C, HW) && bn_fused_ok(HW) && Cy <= 65535) {
+        if (!ws || ws_bytes < mogan_bn_ws_bytes(B, C, HW)) return MOGAN_ERR_WS;
+        const Split s = make_split(B, C, HW);
+        const int YS = s.bs * s.hs;
+        if (YS > 65535) return MOGAN_ERR_SHAPE;
+        double* part = (double*)ws;
+        hipLaunchKernelGGL(bn_partial_kernel, dim3(C, YS), dim3(256), 0, stream, x, B, C, HW, s, part);
+        const int bchunk = 65535 / Cy;
+        for (int b0 = 0; b0 < B; b0 += bchunk) {
+            const int nb = B - b0 < bchunk ? B - b0 : bchunk;
+            const dim3 grid((HW + FUSED_PER - 1) / FUSED_PER, nb * Cy);
+#define MOGAN_FUSED_CASE(A) case A: hipLaunchKernelGGL((bn_fwd_apply_fused_kernel<A>), grid, dim3(256), 0, stream,                 \
+                                                       x + (size_t)b0 * C * HW, (const double*)part, gamma, beta,                     \
+                                                       residual ? residual + (size_t)b0 * Cy * HW : nullptr, y + (size_t)b0 * Cy * HW, \
+                                                       mean, invstd, running_mean, running_var, C, HW, YS, (double)B * HW, eps,      \
+                                                       momentum, slope, b0 == 0 ? 1 : 0); break;
+            switch (act) {
+                MOGAN_FUSED_CASE(MOGAN_ACT_NONE)
+                MOGAN_FUSED_CASE(MOGAN_ACT_RELU)
+                MOGAN_FUSED_CASE(MOGAN_ACT_LRELU)
+                MOGAN_FUSED_CASE(MOGAN_ACT_GLU)
+                default: return MOGAN_ERR_SHAPE;
+            }
+#undef MOGAN_FUSED_CASE
+        }
+        return ok_launch();
+    }
     if (!bn_small_ok(B, C, HW)) {
         int rc = mogan_bn_stats(x, B, C, HW, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream);
         return rc ? rc : mogan_bn_act_fwd(x, mean, invstd, gamma, beta, residual, y, B, C, HW, act, slope, stream);
     }
-    const int Cy = act == MOGAN_ACT_GLU ? C / 2 : C;
 #define MOGAN_SMALL_CASE(A) case A: hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Cy), dim3(256), 0, stream, x, gamma, beta, \
                                                        residual, y, mean, invstd, running_mean, running_var, B, C, HW, eps,   \
                                                        momentum, slope); break;

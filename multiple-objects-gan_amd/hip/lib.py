@@ -198,7 +198,10 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 # Round 3, discriminator branches as hipGraphs also under data parallelism (trainer.py, MOGAN_BRANCH_GRAPHS_DP): member of a
 # 1-rank RCCL group (tools/dp_bg_probe.sh): (4,3) 395 / 395, (4,2) 395, (4,0) 366, (3,3) 364 img/s; eager branches (4,3) 373,
 # (3,3) 370 -- a member of a process group now runs on (4 queues, 3 idle streams); RCCL's stream count on a real multi-GPU
-# node is still unmeasured by the builder (GPU_MAX_HW_QUEUES / MOGAN_RESERVED_STREAMS override both).
+# node is still unmeasured by the builder (GPU_MAX_HW_QUEUES / MOGAN_RESERVED_STREAMS override both).  One process without a
+# group, same round (tools/queue_probe_single.sh, one box, interleaved): (4,2) 390.7 / 391.0, (4,0) 385.6 / 387.4, (4,3) 366, (4,1)
+# 367 -- with the branch graphs the weight-gradient streams of the discriminators are idle and the best slot assignment moved;
+# both kinds of process now use (4 queues, 2 idle streams).
 HW_QUEUES_DEFAULT = "3"
 _reserved = []
 
@@ -209,7 +212,7 @@ def _single_process():
 
 def hw_queue_defaults():
     """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above)"""
-    return ("4", 0) if _single_process() else ("4", 3)
+    return ("4", 2)
 
 
 def configure_hw_queues():

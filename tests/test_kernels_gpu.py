@@ -220,7 +220,10 @@ def _act_ref(y, act):
     return y
 
 
-@pytest.mark.parametrize("shape", [(4, 8, 8, 8), (3, 6, 15, 15), (16, 24), (2, 10, 64, 64), (5, 4, 3, 3), (16, 6, 16, 16), (17, 6, 16, 16)])
+# one-launch path (<= 4096 values per channel), two-launch path (HW % 4 == 0: finalize folded into the apply pass; (3,4,96,96): three
+# tiles per plane, the last one partial), three-launch path ((20,4,15,15): odd plane size beyond the one-launch limit)
+@pytest.mark.parametrize("shape", [(4, 8, 8, 8), (3, 6, 15, 15), (16, 24), (2, 10, 64, 64), (5, 4, 3, 3), (16, 6, 16, 16), (17, 6, 16, 16),
+                                   (3, 4, 96, 96), (20, 4, 15, 15)])
 @pytest.mark.parametrize("act", ["none", "relu", "lrelu", "glu"])
 @pytest.mark.parametrize("res", [False, True])
 def test_bn_act(shape, act, res):

@@ -349,6 +349,11 @@ class TrainEngine:
         if self.distributed and os.environ.get("MOGAN_BRANCH_GRAPHS_DP", "1") == "0":
             branch_graphs = False
         self.branch_graphs = bool(branch_graphs) and self.multi_stream and not use_graph
+        # ... and, single process only (under data parallelism the generator's bucket leaves in chunks DURING its eager backward),
+        # the generator too: forward / backward + Adam + EMA as two hipGraphs of one pool on the main stream (MOGAN_G_GRAPHS=0:
+        # eager generator).  One pair per shape of the text tensors (the padded caption length of a batch), at most
+        # MOGAN_G_GRAPH_VARIANTS (4) pairs; batches beyond that run the generator eagerly.
+        self.g_graphs = self.branch_graphs and not self.distributed and os.environ.get("MOGAN_G_GRAPHS", "1") != "0"
         self._bg = None
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
         bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
@@ -730,6 +735,56 @@ class TrainEngine:
         torch.cuda.synchronize()
         return bg
 
+    def _g_capture(self, b):
+        """Generator forward, and generator backward + Adam/EMA, as two hipGraphs (one memory pool; replayed on the main
+        stream).  Static inputs: z, eps, the text tensors, labels / boxes; the backward graph reads the discriminator graphs'
+        static outputs (g_loss_i, d g_loss_i / d fake_i) and static copies of the DAMSM branch's results."""
+        from ..hip import lib as _lib
+        bg, st, nD = self._bg, self._bg["static"], len(self.netsD)
+        B, dev = bg["B"], b["z"].device
+        gs = {k: b[k].clone() for k in ("z", "words_embs", "mask", "tmi", "label_one_hot")}
+        gs["eps"] = b["eps"].clone() if b.get("eps") is not None else torch.randn(B, cfg.GAN.CONDITION_DIM, device=dev)
+        gs["damsm_grad"] = torch.zeros_like(st["fake"][nD - 1])
+        gs["w_loss"], gs["s_loss"] = torch.zeros((), device=dev), torch.zeros((), device=dev)
+        if getattr(self, "_g_cap_stream", None) is None:
+            self._g_cap_stream = torch.cuda.Stream()          # capture only: the graphs replay on the main stream
+        counter, cap = self.bn_counter, self._g_cap_stream
+        calls0 = list(counter.calls)
+        pool = torch.cuda.graph_pool_handle()
+        gF, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with _lib.capture_guard():
+            with torch.cuda.graph(gF, pool=pool, stream=cap):
+                fake_imgs, _, mu, logvar = self.netG(gs["z"], st["sent_emb"], gs["words_embs"], gs["mask"], gs["tmi"],
+                                                     gs["label_one_hot"], gs["eps"])
+            with torch.cuda.graph(gB, pool=pool, stream=cap):
+                self.optG.zero_grad()
+                parts = {"g_loss%d" % i: bg["out"][i][1] for i in range(nD)}
+                parts["w_loss"], parts["s_loss"] = gs["w_loss"], gs["s_loss"]
+                kl_loss = KL_loss(mu, logvar)
+                errG_total = ops.scalar_sum([generator_total(parts, nD), kl_loss.detach()])
+                grads = [bg["out"][i][2] for i in range(nD)]
+                grads[nD - 1] = ops.add(grads[nD - 1], gs["damsm_grad"])
+                with ops.wgrad_overlap():
+                    torch.autograd.backward(list(fake_imgs) + [kl_loss], grads + [None])
+                self._opt_step(self.optG, None)
+                gout = (errG_total.detach(), kl_loss.detach())
+        calls = [a - c for a, c in zip(counter.calls, calls0)]
+        counter.calls = calls0
+        torch.cuda.synchronize()
+        return {"gF": gF, "gB": gB, "gs": gs, "fake": [t.detach() for t in fake_imgs], "gout": gout, "calls": calls}
+
+    def _g_graph_for(self, b):
+        """the generator graph pair for this batch's text shapes (captured at first use), or None: eager generator"""
+        if not self.g_graphs:
+            return None
+        key = (tuple(b["words_embs"].shape), tuple(b["mask"].shape))
+        table = self._bg.setdefault("G", {})
+        g = table.get(key)
+        if g is None and len(table) < int(os.environ.get("MOGAN_G_GRAPH_VARIANTS", "4")):
+            g = table[key] = self._g_capture(b)
+        return g
+
     def _branch_graph_step(self, b, real_labels, fake_labels, match_labels):
         """device_step with the discriminator branches replayed as hipGraphs (same streams, same order, same results)."""
         netG, netsD, nD = self.netG, self.netsD, len(self.netsD)
@@ -775,7 +830,19 @@ class TrainEngine:
         if "words_embs" not in b:
             b["words_embs"], b["sent_emb"], b["mask"] = self._text_for(b)
         st["sent_emb"].copy_(b["sent_emb"])                # (main stream; the branches wait for it below)
-        fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
+        gg = self._g_graph_for(b)
+        if gg is not None:
+            gs = gg["gs"]
+            for k in ("z", "words_embs", "mask", "tmi", "label_one_hot"):
+                gs[k].copy_(b[k])
+            if b.get("eps") is not None:
+                gs["eps"].copy_(b["eps"])
+            else:
+                gs["eps"].normal_()                         # model.py:333-338: drawn per forward
+            gg["gF"].replay()
+            fake_imgs, mu, logvar = gg["fake"], None, None
+        else:
+            fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
         out, parts = {}, {}
         self._phase("D heads + Inception")
 
@@ -817,11 +884,26 @@ class TrainEngine:
         for s in self.side:
             cur.wait_stream(s)
         self._phase("G backward")
-        self.optG.zero_grad()
         for i in range(nD):
             errD, g_loss, _ = bg["out"][i]
             out["errD%d" % i] = errD.clone()
             parts["g_loss%d" % i] = g_loss.clone()
+        if gg is not None:
+            gs = gg["gs"]
+            gs["damsm_grad"].copy_(damsm_grad)
+            gs["w_loss"].copy_(parts["w_loss"])
+            gs["s_loss"].copy_(parts["s_loss"])
+            gg["gB"].replay()
+            for j, n in enumerate(gg["calls"]):
+                self.bn_counter.calls[j] += n
+            self._phase("G adam")
+            self.bn_counter.flush()
+            out.update(errG=gg["gout"][0].clone(), kl=gg["gout"][1].clone(), fake64=fake_imgs[0].clone(),
+                       fake_last=fake_imgs[-1].clone())
+            out.update({k: v.detach() for k, v in parts.items()})
+            self._phase("end")
+            return out
+        self.optG.zero_grad()
         kl_loss = KL_loss(mu, logvar)
         errG_total = ops.scalar_sum([generator_total(parts, nD), kl_loss.detach()])          # the logged value
         grads = [bg["out"][i][2] for i in range(nD)]

@@ -234,16 +234,19 @@ def test_g_net_eval_mode():
     assert all(int(v) == 0 for k, v in G.state_dict().items() if k.endswith("num_batches_tracked"))
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs", "branch_graphs_eager_g"])
 def test_two_train_steps(mode):
     """the op order of the step (fake images generated once, each D updated
     before generator_loss forwards through it), Adam, EMA, BN running statistics -- eager, as one
-    replayed hipGraph, and with the discriminator branches replayed as hipGraphs beside the eager generator (the default)."""
+    replayed hipGraph, with the discriminator branches and the generator (forward / backward + Adam) replayed as hipGraphs
+    (the default), and with the discriminator branches as hipGraphs beside an eager generator."""
     from mogan_amd.attngan.trainer import TrainEngine
     g = golden("step")
     G, Ds, enc = _build_all()
-    eng = TrainEngine(None, enc, G, Ds, use_graph=mode == "graph", branch_graphs=mode == "branch_graphs")
-    assert eng.branch_graphs == (mode == "branch_graphs")
+    eng = TrainEngine(None, enc, G, Ds, use_graph=mode == "graph", branch_graphs=mode.startswith("branch_graphs"))
+    assert eng.branch_graphs == mode.startswith("branch_graphs") and eng.g_graphs == eng.branch_graphs
+    if mode == "branch_graphs_eager_g":
+        eng.g_graphs = False
     nets = [("G", G)] + [("D%d" % i, D) for i, D in enumerate(Ds)]
     init = {n: {k: probe(v) for k, v in net.state_dict().items()} for n, net in nets}
     for step in range(2):
@@ -277,6 +280,8 @@ def test_two_train_steps(mode):
             for k, v in net.named_parameters():
                 deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))])
             deltas.check(0.15 if n == "G" else 0.05, what="%s step %d" % (n, step))
+    if mode.startswith("branch_graphs"):
+        assert len(eng._bg.get("G", {})) == (1 if mode == "branch_graphs" else 0)      # one generator graph pair, replayed twice
 
 
 @pytest.mark.parametrize("global_loss", [False, True])

@@ -349,11 +349,13 @@ class TrainEngine:
         if self.distributed and os.environ.get("MOGAN_BRANCH_GRAPHS_DP", "1") == "0":
             branch_graphs = False
         self.branch_graphs = bool(branch_graphs) and self.multi_stream and not use_graph
-        # ... and, single process only (under data parallelism the generator's bucket leaves in chunks DURING its eager backward),
-        # the generator too: forward / backward + Adam + EMA as two hipGraphs of one pool on the main stream (MOGAN_G_GRAPHS=0:
-        # eager generator).  One pair per shape of the text tensors (the padded caption length of a batch), at most
-        # MOGAN_G_GRAPH_VARIANTS (4) pairs; batches beyond that run the generator eagerly.
-        self.g_graphs = self.branch_graphs and not self.distributed and os.environ.get("MOGAN_G_GRAPHS", "1") != "0"
+        # Optional (MOGAN_G_GRAPHS=1, single process only): the generator too -- forward / backward + Adam + EMA as two hipGraphs
+        # of one pool on the main stream, one pair per shape of the text tensors (the padded caption length of a batch), at most
+        # MOGAN_G_GRAPH_VARIANTS (4) pairs.  Host enqueue 34.5 -> 10.0 ms per step, the forward chain 6.3 -> 5.65 ms -- and the
+        # backward 10.2 -> 12.6 ms, because its weight gradients then run in line instead of on the side stream (372-373 vs 387.5
+        # img/s; with the fork captured, MOGAN_G_WGRAD_FORK=1: 380.6-382.2; B = 4: 204 vs 213, B = 8: 290 vs 298): off by default,
+        # there for hosts whose python is slower than the GPU's 40 ms step.
+        self.g_graphs = self.branch_graphs and not self.distributed and os.environ.get("MOGAN_G_GRAPHS", "0") != "0"
         self._bg = None
         self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
         bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
@@ -749,9 +751,15 @@ class TrainEngine:
         if getattr(self, "_g_cap_stream", None) is None:
             self._g_cap_stream = torch.cuda.Stream()          # capture only: the graphs replay on the main stream
         counter, cap = self.bn_counter, self._g_cap_stream
+        if os.environ.get("MOGAN_G_WGRAD_FORK", "0") != "0":      # experiment: fork the weight gradients inside the backward graph
+            ops.CAPTURE_WGRAD_OK.add(cap.cuda_stream)
         calls0 = list(counter.calls)
         pool = torch.cuda.graph_pool_handle()
         gF, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # autograd graphs of earlier (eager) iterations must be gone: an AccumulateGrad node that survives from them belongs to the
+        # main stream, and the engine would then pull that stream into the capture (a forked graph -- those replay slowly)
+        import gc
+        gc.collect()
         torch.cuda.synchronize()
         with _lib.capture_guard():
             with torch.cuda.graph(gF, pool=pool, stream=cap):

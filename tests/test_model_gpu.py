@@ -234,19 +234,18 @@ def test_g_net_eval_mode():
     assert all(int(v) == 0 for k, v in G.state_dict().items() if k.endswith("num_batches_tracked"))
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs", "branch_graphs_eager_g"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs", "branch_graphs_and_g"])
 def test_two_train_steps(mode):
     """the op order of the step (fake images generated once, each D updated
     before generator_loss forwards through it), Adam, EMA, BN running statistics -- eager, as one
-    replayed hipGraph, with the discriminator branches and the generator (forward / backward + Adam) replayed as hipGraphs
-    (the default), and with the discriminator branches as hipGraphs beside an eager generator."""
+    replayed hipGraph, with the discriminator branches as hipGraphs beside an eager generator (the default), and with the
+    generator (forward / backward + Adam) replayed as hipGraphs as well (MOGAN_G_GRAPHS=1)."""
     from mogan_amd.attngan.trainer import TrainEngine
     g = golden("step")
     G, Ds, enc = _build_all()
     eng = TrainEngine(None, enc, G, Ds, use_graph=mode == "graph", branch_graphs=mode.startswith("branch_graphs"))
-    assert eng.branch_graphs == mode.startswith("branch_graphs") and eng.g_graphs == eng.branch_graphs
-    if mode == "branch_graphs_eager_g":
-        eng.g_graphs = False
+    assert eng.branch_graphs == mode.startswith("branch_graphs") and not eng.g_graphs
+    eng.g_graphs = mode == "branch_graphs_and_g"
     nets = [("G", G)] + [("D%d" % i, D) for i, D in enumerate(Ds)]
     init = {n: {k: probe(v) for k, v in net.state_dict().items()} for n, net in nets}
     for step in range(2):
@@ -281,7 +280,7 @@ def test_two_train_steps(mode):
                 deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))])
             deltas.check(0.15 if n == "G" else 0.05, what="%s step %d" % (n, step))
     if mode.startswith("branch_graphs"):
-        assert len(eng._bg.get("G", {})) == (1 if mode == "branch_graphs" else 0)      # one generator graph pair, replayed twice
+        assert len(eng._bg.get("G", {})) == (1 if eng.g_graphs else 0)      # one generator graph pair, replayed twice
 
 
 @pytest.mark.parametrize("global_loss", [False, True])

@@ -270,6 +270,17 @@ int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, con
 int mogan_bn_act_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* running_mean,
                            float* running_var, float* mean, float* invstd, float* y, int B, int C, int HW, int act, float slope,
                            float eps, float momentum, void* ws, size_t ws_bytes, hipStream_t stream);
+/* G BatchNorm(train)+activation calls on the G groups of B images of one (G*B, C, HW) tensor, one launch each way (the object
+ * pathways of INIT_STAGE_G / D_NET64, model.py:395-407, 662-672: one BatchNorm call per object): group g uses its own
+ * batch statistics (mean / invstd: G x C floats, group-major), the running statistics are updated G times in group order, d gamma /
+ * d beta sum over the groups.  B*HW <= 4096 per group (mogan_bn_act_grouped_eligible), any HW >= 1. */
+int mogan_bn_act_grouped_eligible(int G, int B, int C, int HW);
+int mogan_bn_act_grouped_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* mean,
+                             float* invstd, float* y, int G, int B, int C, int HW, int act, float slope, float eps, float momentum,
+                             hipStream_t stream);
+int mogan_bn_act_grouped_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float* dx, float* dgamma, float* dbeta, int G, int B, int C, int HW, int act, float slope, int accumulate,
+                             hipStream_t stream);
 /* dy (B,Cy,HW) -> dx (B,C,HW), dgamma[C], dbeta[C] (accumulate != 0 adds into dgamma/dbeta).
  * The residual branch's gradient is dy itself. ws REQUIRED (mogan_bn_ws_bytes). */
 int mogan_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
@@ -293,6 +304,9 @@ int mogan_bias_add(float* y, const float* bias, int rows, int C, int HW, hipStre
 int mogan_bias_grad(const float* dy, float* dbias, int rows, int C, int HW, int accumulate, hipStream_t stream);
 /* y = a + b (n elements); y = a*alpha */
 int mogan_add(const float* a, const float* b, float* y, long long n, hipStream_t stream);
+/* y = ((x_0 + x_1) + x_2) + ... over the G groups of n values of x (G*n values); backward: dx_g = dy for every group */
+int mogan_group_sum(const float* x, float* y, long long n, int G, hipStream_t stream);
+int mogan_group_bcast(const float* dy, float* dx, long long n, int G, hipStream_t stream);
 int mogan_scale(const float* a, float alpha, float* y, long long n, hipStream_t stream);
 
 /* softmax over L of x viewed as (outer, L, inner), y = softmax(scale*x) restricted to the first

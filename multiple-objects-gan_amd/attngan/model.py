@@ -9,6 +9,8 @@ nn.Conv2d / nn.BatchNorm* / nn.Linear whose class names still contain 'Conv' / '
 nn.Sequential is a `FusedSeq` that walks its children and issues fused HIP launches
 (upsample+conv, BN+GLU/LeakyReLU/ReLU, BN+residual), and there is no CPU path.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
@@ -20,11 +22,24 @@ from .GlobalAttention import GlobalAttentionGeneral as ATT_NET
 from . import inception
 
 MAX_OBJECTS = 3
+# The reference's python loops over the objects as ONE batch of MAX_OBJECTS*B samples (object-major) with per-object BatchNorm
+# statistics (FusedSeq(..., groups=G)); 0 = the literal loops (same results; A/B switch)
+BATCH_OBJECTS = os.environ.get("MOGAN_OBJ_BATCH", "1") != "0"
 
 
 def stn(image, transformation_matrix, size):
     """model.py:17-21; align_corners is explicit (cfg.STN_ALIGN_CORNERS)."""
     return ops.stn(image, transformation_matrix, size, bool(cfg.STN_ALIGN_CORNERS))
+
+
+def _objects_first(t, G):
+    """(B, >= G, ...) per-object tensor -> (G, B, ...): the objects of the reference's loops as the slow batch index"""
+    return t[:, :G].transpose(0, 1)
+
+
+def _sum_objects(h, G):
+    """(G*B, ...) object-major -> (B, ...): h_0 + h_1 + ... in the loop's order (model.py:113,406,671)"""
+    return ops.group_sum(h, G)
 
 
 def conv1x1(in_planes, out_planes, bias=False):
@@ -73,12 +88,18 @@ class BBOX_NET(nn.Module):
             conv3x3(c // 4, c // 8, stride=2), HipBatchNorm2d(c // 8), nn.LeakyReLU(0.2, inplace=True))
 
     def forward(self, labels, transf_matr_inv):
-        B = labels.shape[0]
-        label_layout = None
-        for idx in range(MAX_OBJECTS):
-            lab = labels[:, idx].reshape(B, self.c_dim, 1, 1).expand(B, self.c_dim, 16, 16)
-            lab = stn(lab, transf_matr_inv[:, idx], (B, self.c_dim, 16, 16))
-            label_layout = lab if label_layout is None else ops.add(label_layout, lab)
+        B, G = labels.shape[0], MAX_OBJECTS
+        if not BATCH_OBJECTS:
+            label_layout = None
+            for idx in range(G):
+                lab = labels[:, idx].reshape(B, self.c_dim, 1, 1).expand(B, self.c_dim, 16, 16)
+                lab = stn(lab, transf_matr_inv[:, idx], (B, self.c_dim, 16, 16))
+                label_layout = lab if label_layout is None else ops.add(label_layout, lab)
+            return self.encode(label_layout).view(B, -1)
+        # the reference's loop over the objects (model.py:105-114) as ONE batch of G*B samples, object-major
+        lab = _objects_first(labels, G).reshape(G * B, self.c_dim, 1, 1).expand(G * B, self.c_dim, 16, 16)
+        lab = stn(lab, _objects_first(transf_matr_inv, G).reshape(G * B, 2, 3), (G * B, self.c_dim, 16, 16))
+        label_layout = _sum_objects(lab, G)
         return self.encode(label_layout).view(B, -1)
 
 
@@ -220,6 +241,25 @@ class INIT_STAGE_G(nn.Module):
         self.upsample4 = upBlock(ngf // 8, ngf // 16)
 
     def forward(self, z_code, c_code, transf_matrices_inv, label_one_hot):
+        B, G = z_code.shape[0], MAX_OBJECTS
+        if not BATCH_OBJECTS:
+            return self._forward_looped(z_code, c_code, transf_matrices_inv, label_one_hot)
+        # the object loop of model.py:395-407 as ONE batch of G*B samples (object-major); every BatchNorm inside still sees one
+        # object's B samples per "call" (groups=G: own statistics, running statistics updated object after object)
+        cc = c_code.unsqueeze(0).expand(G, B, c_code.shape[1]).reshape(G * B, -1)
+        lab = self.label(torch.cat((cc, _objects_first(label_one_hot, G).reshape(G * B, -1)), 1), groups=G)
+        h = lab.view(G * B, self.ef_dim, 1, 1).expand(G * B, self.ef_dim, 4, 4)
+        h = self.local2(self.local1(h, groups=G), groups=G)
+        h = stn(h, _objects_first(transf_matrices_inv, G).reshape(G * B, 2, 3), h.shape)
+        h_code_locals = _sum_objects(h, G)
+        bbox_code = self.bbox_net(lab.view(G, B, self.ef_dim).transpose(0, 1), transf_matrices_inv)
+        out_code = self.fc(torch.cat((c_code, z_code, bbox_code), 1)).view(-1, self.gf_dim, 4, 4)
+        out_code = self.upsample2(self.upsample1(out_code))
+        out_code = torch.cat((out_code, h_code_locals), 1)
+        return self.upsample4(self.upsample3(out_code))
+
+    def _forward_looped(self, z_code, c_code, transf_matrices_inv, label_one_hot):
+        """the literal loop of model.py:395-407 (MOGAN_OBJ_BATCH=0)"""
         B = z_code.shape[0]
         local_labels, h_code_locals = [], None
         for idx in range(MAX_OBJECTS):
@@ -364,14 +404,25 @@ class D_NET64(_D_BASE):
                               nn.LeakyReLU(0.2, inplace=True))
 
     def forward(self, image, label, transf_matrices, transf_matrices_inv):
-        B = image.shape[0]
-        h_code_locals = None
-        for idx in range(MAX_OBJECTS):
-            lab = label[:, idx].reshape(B, 81, 1, 1).expand(B, 81, 16, 16)
-            h = stn(image, transf_matrices[:, idx], (B, image.shape[1], 16, 16))
-            h = self.local(torch.cat((h, lab), 1))
-            h = stn(h, transf_matrices_inv[:, idx], (B, h.shape[1], 16, 16))
-            h_code_locals = h if h_code_locals is None else ops.add(h_code_locals, h)
+        B, G = image.shape[0], MAX_OBJECTS
+        if not BATCH_OBJECTS:
+            h_code_locals = None
+            for idx in range(G):
+                lab = label[:, idx].reshape(B, 81, 1, 1).expand(B, 81, 16, 16)
+                h = stn(image, transf_matrices[:, idx], (B, image.shape[1], 16, 16))
+                h = self.local(torch.cat((h, lab), 1))
+                h = stn(h, transf_matrices_inv[:, idx], (B, h.shape[1], 16, 16))
+                h_code_locals = h if h_code_locals is None else ops.add(h_code_locals, h)
+            return self._trunk(image, h_code_locals)
+        # the object loop of model.py:662-672 as ONE batch of G*B samples (object-major), BatchNorm per object (groups=G)
+        lab = _objects_first(label, G).reshape(G * B, 81, 1, 1).expand(G * B, 81, 16, 16)
+        img = image.unsqueeze(0).expand((G,) + tuple(image.shape)).reshape((G * B,) + tuple(image.shape[1:]))
+        h = stn(img, _objects_first(transf_matrices, G).reshape(G * B, 2, 3), (G * B, image.shape[1], 16, 16))
+        h = self.local(torch.cat((h, lab), 1), groups=G)
+        h = stn(h, _objects_first(transf_matrices_inv, G).reshape(G * B, 2, 3), (G * B, h.shape[1], 16, 16))
+        return self._trunk(image, _sum_objects(h, G))
+
+    def _trunk(self, image, h_code_locals):
         h = ops.act(self.conv1(image), ops.ACT_LRELU, 0.2)
         h = self.bn2.fused(self.conv2(h), ops.ACT_LRELU, 0.2)
         h = torch.cat((h, h_code_locals), 1)

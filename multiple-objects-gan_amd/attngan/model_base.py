@@ -63,7 +63,19 @@ class _HipBNMixin:
         return ops.deep_conv_bn_act(x, conv.weight, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
                                     self.eps, self.momentum, conv.stride[0], ph, pw)
 
-    def fused(self, x, act=ops.ACT_NONE, slope=0.2, residual=None):
+    def fused(self, x, act=ops.ACT_NONE, slope=0.2, residual=None, groups=1):
+        """groups > 1: x holds `groups` batches one behind the other, each of which the reference passes through this layer in a
+        call of its own (one BatchNorm call per object): own batch statistics per group, running statistics and the
+        call counter updated group after group -- one launch where the maps are small, else one call per group."""
+        if self.training and groups > 1:
+            assert residual is None
+            if ops.bn_groups_ok(x, groups):
+                for _ in range(groups):
+                    self._count_call()
+                return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope, None, self.eps,
+                                  self.momentum, groups=groups)
+            n = x.shape[0] // groups
+            return torch.cat([self.fused(x[g * n:(g + 1) * n], act, slope) for g in range(groups)])
         if self.training:
             self._count_call()
             return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
@@ -111,10 +123,12 @@ class FusedSeq(nn.Sequential):
     [Upsample] conv|linear [BN [GLU|LeakyReLU|ReLU]] , a trailing BN may take a residual."""
 
     @staticmethod
-    def _deep_block(mods, i, x, up, residual):
+    def _deep_block(mods, i, x, up, residual, groups=1):
         """conv (no bias) -> BatchNorm2d (training) [-> LeakyReLU / ReLU] on a small map with packed weights: one fused deep
         block (model.py:575-613, 616-642); returns (output, index behind the matched children) or None"""
         m, n = mods[i], len(mods)
+        if groups > 1:
+            return None                                   # (per-group statistics: the grouped BatchNorm kernels)
         if up or not isinstance(m, HipConv2d) or m.bias is not None or i + 1 >= n or m.stride[0] != m.stride[1]:
             return None
         bn = mods[i + 1]
@@ -135,7 +149,8 @@ class FusedSeq(nn.Sequential):
             return None
         return bn.fused_with_conv(x, m, code, slope), j
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, groups=1):
+        """groups: see _HipBNMixin.fused (the convolutions / linears see one batch of groups*B samples)"""
         mods = list(self)
         i, n, up = 0, len(mods), False
         while i < n:
@@ -145,7 +160,7 @@ class FusedSeq(nn.Sequential):
                 continue
             if isinstance(m, (HipConv2d, HipLinear)):
                 assert not (up and isinstance(m, HipLinear)), "nn.Upsample in front of a Linear"
-                deep = self._deep_block(mods, i, x, up, residual)
+                deep = self._deep_block(mods, i, x, up, residual, groups)
                 if deep is not None:
                     x, i = deep
                     continue
@@ -159,7 +174,7 @@ class FusedSeq(nn.Sequential):
                         i += 1
                     else:
                         code = ops.ACT_NONE
-                    x = bn.fused(x, code, slope, residual if i == n else None)
+                    x = bn.fused(x, code, slope, residual if i == n else None, groups)
                 continue
             code, slope = _act_of(m)
             if code is not None:

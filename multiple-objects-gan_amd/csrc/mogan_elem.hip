@@ -98,6 +98,19 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int G) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float t = x[i];
+        for (int g = 1; g < G; ++g) t += x[(long long)g * n + i];
+        y[i] = t;
+    }
+}
+__global__ __launch_bounds__(256) void group_bcast_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long n, int G) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float t = dy[i];
+        for (int g = 0; g < G; ++g) dx[(long long)g * n + i] = t;
+    }
+}
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ y, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
@@ -466,6 +479,18 @@ int mogan_bias_grad(const float* dy, float* dbias, int rows, int C, int HW, int 
 int mogan_add(const float* a, const float* b, float* y, long long n, hipStream_t stream) {
     if (n <= 0) return n == 0 ? 0 : MOGAN_ERR_SHAPE;
     hipLaunchKernelGGL(add_kernel, dim3(nblk(n)), dim3(256), 0, stream, a, b, y, n);
+    return ok_launch();
+}
+// y[i] = ((x[i] + x[n+i]) + x[2n+i]) + ... over the G groups of n values (the object pathways' h_0 + h_1 + h_2, in the loop's
+// order); its backward: every group receives dy
+int mogan_group_sum(const float* x, float* y, long long n, int G, hipStream_t stream) {
+    if (n <= 0 || G <= 0) return n == 0 ? 0 : MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(group_sum_kernel, dim3(nblk(n)), dim3(256), 0, stream, x, y, n, G);
+    return ok_launch();
+}
+int mogan_group_bcast(const float* dy, float* dx, long long n, int G, hipStream_t stream) {
+    if (n <= 0 || G <= 0) return n == 0 ? 0 : MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(group_bcast_kernel, dim3(nblk(n)), dim3(256), 0, stream, dy, dx, n, G);
     return ok_launch();
 }
 int mogan_scale(const float* a, float alpha, float* y, long long n, hipStream_t stream) {

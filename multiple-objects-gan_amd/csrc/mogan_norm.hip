@@ -454,12 +454,16 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
                                                            float* __restrict__ y, float* __restrict__ mean,
                                                            float* __restrict__ invstd, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, int B, int C, int HW, float eps,
-                                                           float momentum, float slope) {
+                                                           float momentum, float slope, int G) {
     __shared__ double sh[16];
     __shared__ float st[4];
     const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
     const int c = blockIdx.x, NE = B * HW;
     constexpr int NCH = (ACT == MOGAN_ACT_GLU) ? 2 : 1;
+    // G > 1: the batch holds G groups of B images, each normalised with its OWN statistics -- G BatchNorm calls in sequence (the
+    // running statistics are updated group after group, as G calls would), one launch (the object pathways)
+    for (int grp = 0; grp < G; ++grp, x += (size_t)B * C * HW, y += (size_t)B * Cy * HW, mean += C, invstd += C) {
+    if (grp) __syncthreads();
     double acc[2 * NCH];
 #pragma unroll
     for (int k = 0; k < 2 * NCH; ++k) acc[k] = 0.0;
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         if (res) t += res[iy];
         y[iy] = t;
     }
+    }
 }
 
 template <int ACT>
@@ -511,11 +516,14 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int B, int C, int HW, float slope,
-                                                           int accumulate) {
+                                                           int accumulate, int G) {
     __shared__ double sh_[16];
     __shared__ float sums[4];
     const int Cy = (ACT == MOGAN_ACT_GLU) ? C / 2 : C;
     const int c = blockIdx.x, NE = B * HW;
+    for (int grp = 0; grp < G; ++grp, x += (size_t)B * C * HW, dy += (size_t)B * Cy * HW, dx += (size_t)B * C * HW, mean += C,
+             invstd += C, accumulate = 1) {           // (d gamma / d beta: the groups' contributions add up)
+    if (grp) __syncthreads();
     const float mu = mean[c], is = invstd[c];
     const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
     float mu2 = 0, is2 = 0, sc2 = 0, sh2 = 0;
@@ -551,6 +559,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         act_bwd<ACT>(xa, xg, dy[((size_t)b * Cy + c) * HW + pos], sc, sh, sc2, sh2, slope, da, dg, dummy);
         dx[ia] = sc * (da - sums[0] * inv_n - (xa - mu) * is * sums[1] * inv_n);
         if (ACT == MOGAN_ACT_GLU) dx[ig] = sc2 * (dg - sums[2] * inv_n - (xg - mu2) * is2 * sums[3] * inv_n);
+    }
     }
 }
 
@@ -592,7 +601,7 @@ static int bn_bwd_impl(const float* x, const float* dy, const float* mean, const
     const int Cy = ACT == MOGAN_ACT_GLU ? C / 2 : C;
     if (bn_small_ok(B, C, HW)) {           // small map: one launch (bn_small_bwd_kernel)
         hipLaunchKernelGGL((bn_small_bwd_kernel<ACT>), dim3(Cy), dim3(256), 0, stream, x, dy, mean, invstd, gamma, beta, dx,
-                           dgamma, dbeta, B, C, HW, slope, accumulate);
+                           dgamma, dbeta, B, C, HW, slope, accumulate, 1);
         return ok_launch();
     }
     Split s = make_split(B, C, HW);
@@ -714,7 +723,7 @@ int mogan_bn_act_fwd_fused(const float* x, const float* gamma, const float* beta
     }
 #define MOGAN_SMALL_CASE(A) case A: hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Cy), dim3(256), 0, stream, x, gamma, beta, \
                                                        residual, y, mean, invstd, running_mean, running_var, B, C, HW, eps,   \
-                                                       momentum, slope); break;
+                                                       momentum, slope, 1); break;
     switch (act) {
         MOGAN_SMALL_CASE(MOGAN_ACT_NONE)
         MOGAN_SMALL_CASE(MOGAN_ACT_RELU)
@@ -723,6 +732,51 @@ int mogan_bn_act_fwd_fused(const float* x, const float* gamma, const float* beta
         default: return MOGAN_ERR_SHAPE;
     }
 #undef MOGAN_SMALL_CASE
+    return ok_launch();
+}
+
+// G BatchNorm(train) + activation calls on the G groups of B images of one (G*B, C, HW) tensor in ONE launch each way: group g is
+// normalised with its own batch statistics (mean / invstd: G x C, group-major), the running statistics are updated G times in group
+// order, d gamma / d beta sum over the groups.  Needs B*HW <= 4096 values per channel and group (any HW >= 1).
+int mogan_bn_act_grouped_eligible(int G, int B, int C, int HW) {
+    return G >= 1 && B >= 1 && C >= 1 && HW >= 1 && (long long)B * HW <= SMALL_NE && C <= 65535 * 2 &&
+           (long long)G * B * C * HW < (1ll << 31) ? 1 : 0;
+}
+
+int mogan_bn_act_grouped_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* mean,
+                             float* invstd, float* y, int G, int B, int C, int HW, int act, float slope, float eps, float momentum,
+                             hipStream_t stream) {
+    if (!mogan_bn_act_grouped_eligible(G, B, C, HW) || (act == MOGAN_ACT_GLU && (C & 1))) return MOGAN_ERR_SHAPE;
+    const int Cy = act == MOGAN_ACT_GLU ? C / 2 : C;
+#define MOGAN_GRP_CASE(A) case A: hipLaunchKernelGGL((bn_small_fwd_kernel<A>), dim3(Cy), dim3(256), 0, stream, x, gamma, beta, \
+                                                     (const float*)nullptr, y, mean, invstd, running_mean, running_var, B, C, HW, eps, \
+                                                     momentum, slope, G); break;
+    switch (act) {
+        MOGAN_GRP_CASE(MOGAN_ACT_NONE)
+        MOGAN_GRP_CASE(MOGAN_ACT_RELU)
+        MOGAN_GRP_CASE(MOGAN_ACT_LRELU)
+        MOGAN_GRP_CASE(MOGAN_ACT_GLU)
+        default: return MOGAN_ERR_SHAPE;
+    }
+#undef MOGAN_GRP_CASE
+    return ok_launch();
+}
+
+int mogan_bn_act_grouped_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float* dx, float* dgamma, float* dbeta, int G, int B, int C, int HW, int act, float slope, int accumulate,
+                             hipStream_t stream) {
+    if (!mogan_bn_act_grouped_eligible(G, B, C, HW) || (act == MOGAN_ACT_GLU && (C & 1))) return MOGAN_ERR_SHAPE;
+    const int Cy = act == MOGAN_ACT_GLU ? C / 2 : C;
+#define MOGAN_GRP_CASE(A) case A: hipLaunchKernelGGL((bn_small_bwd_kernel<A>), dim3(Cy), dim3(256), 0, stream, x, dy, mean, invstd, gamma, \
+                                                     beta, dx, dgamma, dbeta, B, C, HW, slope, accumulate, G); break;
+    switch (act) {
+        MOGAN_GRP_CASE(MOGAN_ACT_NONE)
+        MOGAN_GRP_CASE(MOGAN_ACT_RELU)
+        MOGAN_GRP_CASE(MOGAN_ACT_LRELU)
+        MOGAN_GRP_CASE(MOGAN_ACT_GLU)
+        default: return MOGAN_ERR_SHAPE;
+    }
+#undef MOGAN_GRP_CASE
     return ok_launch();
 }
 

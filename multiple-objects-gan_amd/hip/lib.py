@@ -58,6 +58,9 @@ SIGNATURES = {
     "mogan_bn_ws_bytes": [I, I, I],
     "mogan_bn_stats": [P, I, I, I, F, F, P, P, P, P, P, Z, P],
     "mogan_bn_act_fwd": [P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "mogan_bn_act_grouped_eligible": [I, I, I, I],
+    "mogan_bn_act_grouped_fwd": [P] * 8 + [I] * 5 + [F, F, F, P],
+    "mogan_bn_act_grouped_bwd": [P] * 9 + [I] * 5 + [F, I, P],
     "mogan_bn_act_fwd_fused": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, P, Z, P],
     "mogan_bn_act_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P, Z, P],
     "mogan_affine_act_fwd": [P, P, P, P, I, I, I, I, F, P],
@@ -67,6 +70,8 @@ SIGNATURES = {
     "mogan_bias_add": [P, P, I, I, I, P],
     "mogan_bias_grad": [P, P, I, I, I, I, P],
     "mogan_add": [P, P, P, L, P],
+    "mogan_group_sum": [P, P, L, I, P],
+    "mogan_group_bcast": [P, P, L, I, P],
     "mogan_scale": [P, F, P, L, P],
     "mogan_softmax_fwd": [P, P, P, L, I, L, F, P],
     "mogan_softmax_bwd": [P, P, P, P, L, I, L, F, P],

@@ -662,9 +662,9 @@ class BNActFn(torch.autograd.Function):
         if need > wsn:
             raise lib.MoganHipError("workspace too small for bn (%d > %d)" % (need, wsn))
         # one call: small maps (<= 4096 values per channel) take ONE launch (a block per channel reduces, finalises and applies),
-        # larger ones three (partial sums, finalize, apply).  Folding the finalize into the apply pass of the LARGE maps
-        # (every block re-reducing its channel's partial sums behind a barrier) was built and measured in round 2: the same
-        # single-stream kernel time, but 3 % SLOWER in the multi-stream step (302 -> 292 img/s), so it was dropped.
+        # larger ones two (partial sums; apply with the reduction of the partial sums folded in: per wave, an xor-butterfly, no
+        # barrier -- round 2's version of that fold, every block re-reducing behind a barrier, was 3 % slower in the step and
+        # dropped; this one is +0.3 %), planes whose size is not a multiple of 4 three.
         Cy = C // 2 if act == ACT_GLU else C
         y = torch.empty((B, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
         res = _c(residual) if residual is not None else None
@@ -700,8 +700,63 @@ class BNActFn(torch.autograd.Function):
         return dx, dg, db, (dy if has_res else None), None, None, None, None, None, None
 
 
+class BNActGroupedFn(torch.autograd.Function):
+    """`groups` training-mode BatchNorm(+activation) calls on the groups of B images of one (groups*B, C, ...) tensor in one launch
+    each way: own batch statistics per group, running statistics updated group after group (the per-object BatchNorm calls of the
+    object pathways, model.py:395-407, 662-672)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, act, slope, eps, momentum, groups):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        N, C, HW = _bchw(x)
+        B = N // groups
+        stats = torch.empty((2, groups, C), dtype=torch.float32, device=x.device)
+        Cy = C // 2 if act == ACT_GLU else C
+        y = torch.empty((N, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        call("mogan_bn_act_grouped_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(stats[0]),
+             ptr(stats[1]), ptr(y), groups, B, C, HW, act, slope, eps, momentum, stream_ptr())
+        if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
+            for g in range(groups):                      # (one entry per reference call, in call order)
+                ACT_TRACE.append((act, y[g * B:(g + 1) * B]))
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (act, slope, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        act, slope, groups = ctx.cfg
+        dy = _c(dy)
+        N, C, HW = _bchw(x)
+        dx = torch.empty_like(x)
+        gg, gb = _grad_buf(gamma), _grad_buf(beta)
+        direct = gg is not None and gb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        if direct:
+            dg, db = gg, gb
+        else:
+            dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+            dg, db = dgb[0], dgb[1]
+        call("mogan_bn_act_grouped_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(dx), ptr(dg),
+             ptr(db), groups, N // groups, C, HW, act, slope, 1 if direct else 0, stream_ptr())
+        if direct:
+            _grad_hit(gg)
+            _grad_hit(gb)
+            dg = db = None
+        return dx, dg, db, None, None, None, None, None, None, None
+
+
+def bn_groups_ok(x, groups):
+    """can `groups` BatchNorm calls on this (groups*B, C, ...) tensor go out as one launch (B*HW <= 4096 values per channel)?"""
+    N, C, HW = _bchw(x)
+    return groups > 1 and N % groups == 0 and bool(lib.load().mogan_bn_act_grouped_eligible(groups, N // groups, C, HW))
+
+
 def bn_act(x, gamma, beta, running_mean, running_var, act=ACT_NONE, slope=0.2, residual=None, eps=1e-5,
-           momentum=0.1):
+           momentum=0.1, groups=1):
+    if groups > 1:
+        assert residual is None
+        return BNActGroupedFn.apply(x, gamma, beta, running_mean, running_var, act, float(slope), float(eps), float(momentum),
+                                    int(groups))
     return BNActFn.apply(x, gamma, beta, residual, running_mean, running_var, act, float(slope), float(eps),
                          float(momentum))
 
@@ -783,6 +838,29 @@ class AddFn(torch.autograd.Function):
 
 def add(a, b):
     return AddFn.apply(a, b)
+
+
+class GroupSumFn(torch.autograd.Function):
+    """(G*B, ...) -> (B, ...): x_0 + x_1 + ... over the G groups of B samples, in that order (model.py:113,406,671)."""
+
+    @staticmethod
+    def forward(ctx, x, G):
+        x = _c(x)
+        y = torch.empty((x.shape[0] // G,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        call("mogan_group_sum", ptr(x), ptr(y), y.numel(), G, stream_ptr())
+        ctx.G = G
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty((dy.shape[0] * ctx.G,) + tuple(dy.shape[1:]), dtype=torch.float32, device=dy.device)
+        call("mogan_group_bcast", ptr(dy), ptr(dx), dy.numel(), ctx.G, stream_ptr())
+        return dx, None
+
+
+def group_sum(x, G):
+    return GroupSumFn.apply(x, int(G))
 
 
 # ------------------------------------------------------------------------------- softmax

@@ -220,6 +220,67 @@ def _act_ref(y, act):
     return y
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 6, 8, 8), (3, 16, 12, 15, 15), (2, 5, 10), (3, 16, 8, 16, 16)])
+@pytest.mark.parametrize("act", ["none", "relu", "lrelu", "glu"])
+def test_bn_act_grouped(shape, act):
+    """mogan_bn_act_grouped_fwd/bwd: G BatchNorm(train)+activation calls on the G groups of one (G*B, C, ...) tensor in one launch
+    each way = G separate calls in sequence (own statistics per group, running statistics updated group after group, d gamma / d beta
+    summed) -- against fp64 and against the looped HIP calls; (2,5,10) is a BatchNorm1d."""
+    G, B, C = shape[:3]
+    full = (G * B, C) + tuple(shape[3:])
+    x = T("gbx%s" % (shape,), full, 1.5, 0.3).requires_grad_(True)
+    gm = T("gbg%d" % C, (C,), 0.2, 1.0).requires_grad_(True)
+    bt = T("gbb%d" % C, (C,), 0.2).requires_grad_(True)
+    rm, rv = T("gbrm%d" % C, (C,), 0.1), T("gbrv%d" % C, (C,), 0.1).abs() + 1
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    outs = []
+    for g in range(G):
+        yb = F.batch_norm(x.double()[g * B:(g + 1) * B], rm_ref, rv_ref, gm.double(), bt.double(), True, 0.1, 1e-5)
+        outs.append(_act_ref(yb, act))
+    ref = torch.cat(outs)
+    go = T("gbgo%s%s" % (shape, act), ref.shape)
+    ref.backward(go.double())
+    code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "glu": ops.ACT_GLU}[act]
+    xd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, gm, bt))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    assert ops.bn_groups_ok(xd, G)
+    y = ops.bn_act(xd, gd, bd, rmd, rvd, code, 0.2, None, 1e-5, 0.1, groups=G)
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    _check(y, ref, what="y")
+    _check(xd.grad, x.grad, what="dx")
+    _check(gd.grad, gm.grad, what="dgamma")
+    _check(bd.grad, bt.grad, what="dbeta")
+    _check(rmd, rm_ref, what="running_mean")
+    _check(rvd, rv_ref, what="running_var")
+    # ... and bit for bit what G calls of the one-group path give
+    x2, g2, b2 = (t.detach().to(DEV).requires_grad_(True) for t in (x, gm, bt))
+    rm2, rv2 = rm.to(DEV), rv.to(DEV)
+    y2 = torch.cat([ops.bn_act(x2[g * B:(g + 1) * B], g2, b2, rm2, rv2, code, 0.2, None, 1e-5, 0.1) for g in range(G)])
+    y2.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    if len(shape) > 3 and shape[3] * shape[4] >= 16:          # (the looped BatchNorm1d takes the thread-per-channel kernels)
+        assert torch.equal(y, y2) and torch.equal(xd.grad, x2.grad) and torch.equal(rmd, rm2) and torch.equal(rvd, rv2)
+    else:
+        _check(y, y2.double().cpu(), what="y vs loop")
+    assert not ops.bn_groups_ok(torch.empty(3 * 32, 4, 16, 16, device=DEV), 3)        # 8192 values per channel and group
+
+
+def test_group_sum():
+    x = T("gsx", (3 * 5, 7, 4, 4)).requires_grad_(True)
+    ref = x.double().view(3, 5, 7, 4, 4).sum(0)
+    g = T("gsg", ref.shape)
+    ref.backward(g.double())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.group_sum(xd, 3)
+    y.backward(g.to(DEV))
+    torch.cuda.synchronize()
+    _check(y, ref, what="sum")
+    _check(xd.grad, x.grad, what="broadcast")
+    v = xd.detach().view(3, 5, 7, 4, 4)
+    assert torch.equal(y, (v[0] + v[1]) + v[2])               # the loop's order
+
+
 # one-launch path (<= 4096 values per channel), two-launch path (HW % 4 == 0: finalize folded into the apply pass; (3,4,96,96): three
 # tiles per plane, the last one partial), three-launch path ((20,4,15,15): odd plane size beyond the one-launch limit)
 @pytest.mark.parametrize("shape", [(4, 8, 8, 8), (3, 6, 15, 15), (16, 24), (2, 10, 64, 64), (5, 4, 3, 3), (16, 6, 16, 16), (17, 6, 16, 16),

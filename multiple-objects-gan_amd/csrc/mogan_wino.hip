@@ -699,8 +699,11 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
     const int nchunk = B * (H / 2) * (W / (2 * WCT));
     const int tiles_mn = ((Cout + BM - 1) / BM) * ((Cin + WBN - 1) / WBN);
     // one 8-wave block per CU and ONE round of blocks: the K-split partials (16 x Cout x Cin floats per split) are what the
-    // finish pass has to read back (256 blocks: 156 / 137 TF direct-equivalent at 128x128 / 64x64; 512: 147 / 117)
-    static const int wg_blocks = getenv("MOGAN_WINO_WG_BLOCKS") ? atoi(getenv("MOGAN_WINO_WG_BLOCKS")) : 256;
+    // finish pass has to read back (256 blocks: 156 / 137 TF direct-equivalent at 128x128 / 64x64; 512: 147 / 117).  In the train step
+    // this kernel runs on the weight-gradient side stream BESIDE the generator's data-gradient chain: with 256 persistent blocks it
+    // holds every CU for ~240 us and the chain's short kernels queue behind it; 192 blocks leave a quarter of the CUs to the chain:
+    // 405.0 / 406.6 vs 402.3 / 399.3 img/s (224: 404.4, 160: 403.6; tools/wino_wg_blocks_probe.sh) -- the default since round 3
+    static const int wg_blocks = getenv("MOGAN_WINO_WG_BLOCKS") ? atoi(getenv("MOGAN_WINO_WG_BLOCKS")) : 192;
     int nsplit = wg_blocks / tiles_mn;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nchunk / 8) nsplit = nchunk / 8 > 0 ? nchunk / 8 : 1;

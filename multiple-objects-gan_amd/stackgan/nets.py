@@ -12,6 +12,7 @@ signatures, forward signatures, return structure and state_dict keys are the ref
 
 Everything runs on libmogan_hip.so (FusedSeq -> fused conv / BN+act launches); there is no CPU path.
 """
+import os
 from dataclasses import dataclass
 
 import torch
@@ -115,6 +116,22 @@ class D_GET_LOGITS(nn.Module):
         return self.outlogits(h_code).view(-1)
 
 
+# The reference's python loops over the objects as ONE batch of K*B samples (object-major) with per-object BatchNorm statistics
+# (FusedSeq(..., groups=K): SURVEY F11), as in attngan/model.py; MOGAN_OBJ_BATCH=0 = the literal loops (same results; A/B switch)
+BATCH_OBJECTS = os.environ.get("MOGAN_OBJ_BATCH", "1") != "0"
+
+
+def _objects_first(t, K):
+    """(B, >= K, ...) per-object tensor -> (K*B, ...), the objects as the slow batch index"""
+    v = t[:, :K].transpose(0, 1)
+    return v.reshape((K * t.shape[0],) + tuple(t.shape[2:]))
+
+
+def _repeat_batch(t, K):
+    """(B, ...) -> (K*B, ...): the same B samples once per object"""
+    return t.unsqueeze(0).expand((K,) + tuple(t.shape)).reshape((K * t.shape[0],) + tuple(t.shape[1:]))
+
+
 def _tile(vec, size):
     """(B,C) -> (B,C,size,size) contiguous (label replicated spatially before the STN paste)."""
     B, C = vec.shape
@@ -137,7 +154,11 @@ class BBOX_NET(nn.Module):
         self.out_dim = (c // 8) * 4
 
     def forward(self, labels, transf_matr_inv, max_objects):
-        B = labels.shape[0]
+        B, K = labels.shape[0], max_objects
+        if BATCH_OBJECTS:
+            lab = ops.stn(_tile(_objects_first(labels, K), 16), _objects_first(transf_matr_inv, K), (K * B, self.in_dim, 16, 16),
+                          bool(self.cfg.STN_ALIGN_CORNERS))
+            return self.encode(ops.group_sum(lab, K)).view(B, -1)
         layout = None
         for idx in range(max_objects):
             lab = ops.stn(_tile(labels[:, idx], 16), transf_matr_inv[:, idx], (B, self.in_dim, 16, 16),
@@ -184,19 +205,28 @@ class STAGE1_G(nn.Module):
 
     def generate(self, c_code, noise, transf_matrices_inv, label_one_hot, max_objects):
         """-> (fake_img, local_labels (B,K,ef))"""
-        v, B = self.variant, noise.shape[0]
-        labels, canvas = [], None
-        for idx in range(max_objects):
+        v, B, K = self.variant, noise.shape[0], max_objects
+        if BATCH_OBJECTS:
+            lab = _objects_first(label_one_hot, K)
             if v.label_net:
-                src = label_one_hot[:, idx] if c_code is None else torch.cat((c_code, label_one_hot[:, idx]), 1)
-                lab = self.label(src)
-            else:
-                lab = label_one_hot[:, idx]
-            labels.append(lab)
-            h = self.local2(self.local1(_tile(lab, 4)))
-            h = ops.stn(h, transf_matrices_inv[:, idx], tuple(h.shape), self._align())
-            canvas = h if canvas is None else ops.add(canvas, h)
-        local_labels = torch.stack(labels, 1)
+                lab = self.label(lab if c_code is None else torch.cat((_repeat_batch(c_code, K), lab), 1), groups=K)
+            h = self.local2(self.local1(_tile(lab, 4), groups=K), groups=K)
+            h = ops.stn(h, _objects_first(transf_matrices_inv, K), tuple(h.shape), self._align())
+            canvas = ops.group_sum(h, K)
+            local_labels = lab.view(K, B, -1).transpose(0, 1)
+        else:
+            labels, canvas = [], None
+            for idx in range(max_objects):
+                if v.label_net:
+                    src = label_one_hot[:, idx] if c_code is None else torch.cat((c_code, label_one_hot[:, idx]), 1)
+                    lab = self.label(src)
+                else:
+                    lab = label_one_hot[:, idx]
+                labels.append(lab)
+                h = self.local2(self.local1(_tile(lab, 4)))
+                h = ops.stn(h, transf_matrices_inv[:, idx], tuple(h.shape), self._align())
+                canvas = h if canvas is None else ops.add(canvas, h)
+            local_labels = torch.stack(labels, 1)
         parts = [noise] + ([c_code] if c_code is not None else [])
         if self.cfg.USE_BBOX_LAYOUT:
             parts.append(self.bbox_net(local_labels, transf_matrices_inv, max_objects))
@@ -237,17 +267,29 @@ class STAGE1_D(nn.Module):
 
     def _encode_img(self, image, label, transf_matrices, transf_matrices_inv, max_objects):
         B, v, ndf = image.shape[0], self.variant, self.df_dim
-        canvas = None
-        for idx in range(max_objects):
-            crop = ops.stn(image, transf_matrices[:, idx], (B, image.shape[1], 16, 16), self._align())
-            h = self.local(torch.cat((crop, _tile(label[:, idx], 16)), 1))
-            h = ops.stn(h, transf_matrices_inv[:, idx], (B, ndf * 2, 16, 16), self._align())
-            canvas = h if canvas is None else ops.add(canvas, h)
+        canvas = self._object_canvas(image, label, transf_matrices, transf_matrices_inv, max_objects, 16)
         h = ops.act(self.conv1(image), ops.ACT_LRELU, 0.2)
         h = self.bn2.fused(self.conv2(h), ops.ACT_LRELU, 0.2)
         h = torch.cat((h, canvas), 1)
         h = self.bn3.fused(self.conv3(h), ops.ACT_LRELU, 0.2)
         return self.bn4.fused(self.conv4(h), ops.ACT_LRELU, 0.2)
+
+    def _object_canvas(self, image, label, transf_matrices, transf_matrices_inv, K, size):
+        """per object: STN crop + tiled label -> self.local -> STN paste; summed over the objects"""
+        B, ndf = image.shape[0], self.df_dim
+        if BATCH_OBJECTS:
+            crop = ops.stn(_repeat_batch(image, K), _objects_first(transf_matrices, K), (K * B, image.shape[1], size, size),
+                           self._align())
+            h = self.local(torch.cat((crop, _tile(_objects_first(label, K), size)), 1), groups=K)
+            h = ops.stn(h, _objects_first(transf_matrices_inv, K), (K * B, ndf * 2, size, size), self._align())
+            return ops.group_sum(h, K)
+        canvas = None
+        for idx in range(K):
+            crop = ops.stn(image, transf_matrices[:, idx], (B, image.shape[1], size, size), self._align())
+            h = self.local(torch.cat((crop, _tile(label[:, idx], size)), 1))
+            h = ops.stn(h, transf_matrices_inv[:, idx], (B, ndf * 2, size, size), self._align())
+            canvas = h if canvas is None else ops.add(canvas, h)
+        return canvas
 
     def forward(self, image, label, transf_matrices, transf_matrices_inv, max_objects=None):
         return self._encode_img(image, label, transf_matrices, transf_matrices_inv,
@@ -302,6 +344,9 @@ class STAGE2_G(nn.Module):
         stage1_img = stage1_img.detach()
         encoded_img = self.encoder(stage1_img)
         c_code, mu, logvar = self.ca_net(text_embedding, eps)
+        if BATCH_OBJECTS:
+            return self._forward_batched(stage1_img, encoded_img, c_code, mu, logvar, transf_matrices_inv, transf_matrices_s2,
+                                         transf_matrices_inv_s2, label_one_hot, max_objects)
         labels = [self.label(torch.cat((c_code, label_one_hot[:, idx]), 1)) for idx in range(max_objects)] \
             if self.cfg.USE_BBOX_LAYOUT else None
         parts = [encoded_img, _tile(c_code, 16)]
@@ -326,6 +371,26 @@ class STAGE2_G(nn.Module):
         h_code = torch.cat((h_code, canvas), 1)
         h_code = self.upsample4(self.upsample3(h_code))
         return stage1_img, self.img(h_code), mu, logvar, torch.stack(labels, 1)
+
+    def _forward_batched(self, stage1_img, encoded_img, c_code, mu, logvar, transf_matrices_inv, transf_matrices_s2,
+                         transf_matrices_inv_s2, label_one_hot, K):
+        """the two object loops of S/model.py:380-420 as batches of K*B samples (see BATCH_OBJECTS)"""
+        B, ef = c_code.shape[0], self.ef_dim
+        lab = self.label(torch.cat((_repeat_batch(c_code, K), _objects_first(label_one_hot, K)), 1), groups=K)      # (K*B, ef)
+        parts = [encoded_img, _tile(c_code, 16)]
+        if self.cfg.USE_BBOX_LAYOUT:
+            lay = ops.stn(_tile(lab, 16), _objects_first(transf_matrices_inv, K), (K * B, ef, 16, 16), self._align())
+            parts.append(ops.group_sum(lay, K))
+        h_code = self.residual(self.hr_joint(torch.cat(parts, 1)))
+        patch = ops.stn(_repeat_batch(h_code, K), _objects_first(transf_matrices_s2, K), (K * B, h_code.shape[1], 16, 16),
+                        self._align())
+        h = self.local2(self.local1(torch.cat((patch, _tile(lab, 16)), 1), groups=K), groups=K)
+        h = ops.stn(h, _objects_first(transf_matrices_inv_s2, K), (K * B, self.gf_dim, 64, 64), self._align())
+        canvas = ops.group_sum(h, K)
+        h_code = self.upsample2(self.upsample1(h_code))
+        h_code = torch.cat((h_code, canvas), 1)
+        h_code = self.upsample4(self.upsample3(h_code))
+        return stage1_img, self.img(h_code), mu, logvar, lab.view(K, B, ef).transpose(0, 1)
 
 
 class STAGE2_D(nn.Module):
@@ -360,12 +425,7 @@ class STAGE2_D(nn.Module):
 
     def _encode_img(self, image, label, transf_matrices, transf_matrices_inv, max_objects):
         B, ndf = image.shape[0], self.df_dim
-        canvas = None
-        for idx in range(max_objects):
-            crop = ops.stn(image, transf_matrices[:, idx], (B, image.shape[1], 32, 32), self._align())
-            h = self.local(torch.cat((crop, _tile(label[:, idx], 32)), 1))
-            h = ops.stn(h, transf_matrices_inv[:, idx], (B, ndf * 2, 32, 32), self._align())
-            canvas = h if canvas is None else ops.add(canvas, h)
+        canvas = STAGE1_D._object_canvas(self, image, label, transf_matrices, transf_matrices_inv, max_objects, 32)
         h = ops.act(self.conv1(image), ops.ACT_LRELU, 0.2)
         h = self.bn2.fused(self.conv2(h), ops.ACT_LRELU, 0.2)
         h = self.bn3.fused(self.conv3(h), ops.ACT_LRELU, 0.2)

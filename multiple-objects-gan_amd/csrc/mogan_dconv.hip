@@ -811,7 +811,10 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     p.lg_tx = __builtin_ctz(p.tiles_x); p.lg_ty = __builtin_ctz(p.tiles_y);
     const long long blocks = cdiv(p.N, 128) * cdiv(p.Cout, bm);
     const long long w_numel = (long long)p.Cout * p.N;
-    static const int wg_target = getenv("MOGAN_DSPLIT_WG") ? atoi(getenv("MOGAN_DSPLIT_WG")) : 640;
+    // block target of the pixel-tile split.  640 was the isolated optimum; in the step these launches run on the weight-gradient side
+    // stream beside the generator's data-gradient chain, and fewer, longer blocks leave it more of the chip: 384 -> 402.1 / 400.3 /
+    // 409.8 against 398.0 / 398.8 / 407.3 img/s (448: 401.2 / 401.1, 320: 398.2 / 400.1, 256: 394.6 / 395.1; tools/split_probe.sh)
+    static const int wg_target = getenv("MOGAN_DSPLIT_WG") ? atoi(getenv("MOGAN_DSPLIT_WG")) : 384;
     int nsplit = (int)std::min<long long>(cdiv(wg_target, blocks), std::max(1, p.ntiles / 2));
     if (nsplit > 1) {
         const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)w_numel)) : 0;

@@ -283,6 +283,50 @@ def test_two_train_steps(mode):
         assert len(eng._bg.get("G", {})) == (1 if eng.g_graphs else 0)      # one generator graph pair, replayed twice
 
 
+@pytest.mark.parametrize("B", [4, 20])
+def test_object_pathways_batched_equal_looped(B):
+    """The reference's loops over the objects (model.py:105-114, 395-407, 662-672) run as ONE batch of 3*B samples with per-object
+    BatchNorm statistics (model.BATCH_OBJECTS); this must give what the literal loops give -- outputs, every parameter gradient, the
+    BatchNorm running statistics and call counters -- for B = 4 (every grouped BatchNorm in one launch) and B = 20 (16x16 maps:
+    20*256 values per channel and object exceed the one-launch limit, the grouped call falls back to one call per object)."""
+    from helpers import rel_l2
+    from mogan_amd.attngan import model
+    bt = synthetic.to_device(synthetic.make_batch(B, words_num=5, nef=16, seed=77), DEV)
+    results = []
+    for batched in (True, False):
+        model.BATCH_OBJECTS = batched
+        try:
+            G, Ds, _ = _build_all()
+            fake, _, mu, logvar = G(bt["z"], bt["sent_emb"], bt["words_embs"], bt["mask"], bt["tmi"], bt["label_one_hot"], bt["eps"])
+            feat = Ds[0](fake[0], bt["label_one_hot"], bt["tm"], bt["tmi"])
+            loss = (feat * feat).mean() + sum((f * f).mean() for f in fake) + (mu * logvar).mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            res = {"fake%d" % i: f.detach() for i, f in enumerate(fake)}
+            res["feat"] = feat.detach()
+            for n, net in (("G", G), ("D", Ds[0])):
+                for k, v in net.named_parameters():
+                    if v.grad is not None:                       # (the logits heads of D_NET64 are not part of this loss)
+                        res["%s.grad.%s" % (n, k)] = v.grad.detach().clone()
+                for k, v in net.named_buffers():
+                    res["%s.buf.%s" % (n, k)] = v.detach().clone().float()
+            results.append(res)
+        finally:
+            model.BATCH_OBJECTS = True
+    a, b = results
+    assert a.keys() == b.keys()
+    worst = ("", 0.0)
+    for k in a:
+        if "num_batches_tracked" in k:
+            assert torch.equal(a[k], b[k]), k
+            continue
+        e = rel_l2(a[k], b[k])
+        if e > worst[1]:
+            worst = (k, e)
+        assert e <= 1e-5, (k, e)                      # measured: <= 6e-7 (other tile shapes and split-K factors in the batched convolutions)
+    print("worst:", worst)
+
+
 @pytest.mark.parametrize("global_loss", [False, True])
 def test_two_train_steps_through_rccl(global_loss, monkeypatch):
     """The N>1 code path on one GPU: process group "nccl" (= RCCL) with world_size 1, flat-bucket all-reduces on the

@@ -286,7 +286,7 @@ def family_build(name, device, batch=None):
     return tree, stage, B, cfg, model, G.to(device), D.to(device), desc
 
 
-def family_cpu_baseline(engine, cfg, tree, stage, B, bt_cpu):
+def family_cpu_baseline(engine, cfg, tree, stage, B, bt_cpu, dev_batch=None, timed_steps=3, budget_s=25.0):
     from oracle import stackgan_oracle as S
     ocfg = S.SCfg(tree, stage=stage, gf_dim=cfg.GAN.GF_DIM, df_dim=cfg.GAN.DF_DIM, cond_dim=cfg.GAN.CONDITION_DIM,
                   text_dim=cfg.TEXT.DIMENSION if tree == "coco" else 0, r_num=cfg.GAN.R_NUM)
@@ -297,19 +297,47 @@ def family_cpu_baseline(engine, cfg, tree, stage, B, bt_cpu):
             if k.startswith("STAGE1_G.") and v.is_floating_point():
                 v.requires_grad_(False)
     st = S.TrainState(G, S.from_state_dict(cpu(engine.netD.state_dict())), ocfg)
-    times, t_all = [], time.perf_counter()
-    for i in range(4):
+    # PARITY of the benchmarked computation at its stated size: the HIP engine and the oracle start from the same weights (the
+    # engine's, after the timed region; Adam moments reset on both sides), get the same batch incl. z / eps, and run one whole
+    # train step each (the oracle's is also its warm-up step)
+    hlogs = None
+    if dev_batch is not None:
+        torch.cuda.synchronize()
+        for o in (engine.optG, engine.optD):
+            o.m.zero_(); o.v.zero_(); o.state.zero_()
+        hlogs = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in engine.step(dict(dev_batch)).items()}
+        torch.cuda.synchronize()
+    times, t_all, ologs = [], time.perf_counter(), None
+    for i in range(1 + timed_steps):
         t0 = time.perf_counter()
-        S.train_step(st, bt_cpu)
+        logs = S.train_step(st, bt_cpu)
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > 25.0:
+        if i == 0:
+            ologs = logs
+        if time.perf_counter() - t_all > budget_s and len(times) >= 2:
             break
     timed = times[1:] if len(times) > 1 else times
     sec = sum(timed) / len(timed)
-    return dict(value=B / sec, unit="images/s", cores=torch.get_num_threads(), kind="port",
+    base = dict(value=B / sec, unit="images/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d timed step(s) of the same B=%d workload after %d warm-up step(s) "
                        "(oracle/stackgan_oracle.py, torch-CPU fp32, %.2f s/step)" % (len(timed), B,
                                                                                       len(times) - len(timed), sec))
+    if hlogs is None:
+        return base, None
+    parity = {}
+    keys = [k for k in ("errD", "errD_real", "errD_wrong", "errD_fake", "errG", "kl") if k in ologs and k in hlogs]
+    for k in keys:
+        h, o = float(hlogs[k]), float(ologs[k])
+        assert h == h and abs(h) != float("inf"), "non-finite %s in the HIP step" % k
+        parity[k + "_rel"] = abs(h - o) / (abs(o) + 1e-30)
+    assert torch.isfinite(hlogs["fake"]).all(), "non-finite generated images in the HIP step"
+    parity["img_max_abs"] = float((hlogs["fake"].cpu() - ologs["fake"]).abs().max())
+    parity["hip"] = {k: float(hlogs[k]) for k in keys}
+    parity["oracle"] = {k: float(ologs[k]) for k in keys}
+    parity["ok"] = bool(all(parity[k + "_rel"] <= 1e-4 for k in keys) and parity["img_max_abs"] <= 1e-3)
+    parity["what"] = ("one B=%d train step at the yml widths from the benchmarked engine's weights, same batch / z / eps: HIP vs "
+                      "the CPU oracle (losses: relative difference; generated images: max-abs)" % B)
+    return base, parity
 
 
 def run_family(name, args, device):
@@ -368,10 +396,11 @@ def run_family(name, args, device):
                            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                                        for r in rows[:8]]}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = family_cpu_baseline(engine, cfg, tree, stage, B, bt_cpu)
+        out["cpu_baseline"], out["parity"] = family_cpu_baseline(engine, cfg, tree, stage, B, bt_cpu, dev_batch=batch)
     print(json.dumps(out), flush=True)
     del engine, G, D
     torch.cuda.empty_cache()
+    return out
 
 
 
@@ -387,6 +416,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed steps of the CPU oracle leg after its warm-up step (25-30 s "
+                    "each on the GPU box's host; default 2 keeps the default run within minutes, BASELINE.md section 3 asks "
+                    "for 5: --cpu-steps 5)")
     ap.add_argument("--no-text-prefetch", action="store_true", help="text-encode every batch at the start of its own step")
     ap.add_argument("--debug-losses", action="store_true", help="print the losses of every step (adds a host sync)")
     ap.add_argument("--workload", default="attngan", choices=["attngan"] + list(WORKLOADS),
@@ -536,7 +568,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dev_batch = dict(batch)
         dev_batch.update(engine.encode_batch_for_cpu(batch))
-        out["cpu_baseline"], out["parity"] = cpu_baseline_leg(engine, bt_cpu, dev_batch, B, device)
+        out["cpu_baseline"], out["parity"] = cpu_baseline_leg(engine, bt_cpu, dev_batch, B, device, timed_steps=args.cpu_steps,
+                                                              budget_s=max(150.0, 45.0 * (1 + args.cpu_steps)))
+        out["cpu_baseline"]["sample"] += "; --cpu-steps %d%s" % (args.cpu_steps, "" if args.cpu_steps >= 5 else
+                                                               " (the default run's bounded sample; --cpu-steps 5 = BASELINE.md's five)")
     if world > 1 or force_dist:
         dist.destroy_process_group()
     if os.environ.get("MOGAN_CHAIN_EVENTS") and rank == 0:       # diagnostic: where the main stream (generator chain) spends the step

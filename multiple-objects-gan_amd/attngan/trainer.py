@@ -70,10 +70,16 @@ class FlatAdam:
         if isinstance(module, torch.nn.Module):
             module.register_load_state_dict_post_hook(lambda m, keys: self.touch())
 
+    repack_on_touch = False     # set by an engine that holds captured graphs: those read the packed copies without asking
+
     def touch(self):
         """the bucket's parameters were written (load_state_dict, a broadcast, a restore): packed copies are rebuilt at
-        their next use"""
+        their next use -- or right now, on the current stream, when replayed hipGraphs consume them (a replay never calls
+        WeightPacks.pointer(), so a lazily rebuilt copy would be a stale one until the graph's own post-Adam pack node ran)"""
         self._pk_cell[0] += 1
+        if self.repack_on_touch:
+            for pk in self.packs:
+                pk.repack()
 
     def repack(self):
         """the same, but the copies in use are rebuilt NOW on the current stream -- after the optimizer step (one pack per
@@ -389,6 +395,15 @@ class TrainEngine:
                 if o.numel * 4 >= 2 * c:
                     self.reducers[id(o)] = ChunkedReducer(o, c, torch.cuda.Stream())
 
+    def repack_all(self):
+        """Weights were written behind the optimizers' backs (load_params / invalidate_all_packs, a checkpoint restore) while
+        this engine holds captured graphs: rebuild every packed copy in use now and order the branch streams behind it."""
+        cur = torch.cuda.current_stream()
+        for o in [self.optG] + self.optDs:
+            o.repack()
+        for s in self.side:
+            s.wait_stream(cur)
+
     def sync_replicas(self, src=0):
         """Every rank starts from rank `src`'s weights, EMA shadow, optimizer state and BatchNorm buffers: the step only
         exchanges gradients, so replicas that differ at step 0 (per-rank init seeds, a checkpoint only rank 0 could read)
@@ -701,6 +716,13 @@ class TrainEngine:
             calls0 = list(counter.calls)
             gR, gU = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             gA = torch.cuda.CUDAGraph() if self.distributed else None
+            # The branch's results (errD_i, g_loss_i, d g_loss_i / d fake_i) are read by the MAIN stream during the generator's
+            # backward of step k, while gR of step k+1 may already replay on the branch stream (the `inputs_ready` early start):
+            # gR shares the private memory pool of gU / gA, so results living INSIDE that pool could be overwritten by gR's
+            # temporaries.  They are therefore copied, as the last nodes of the graph, into buffers allocated here, outside the
+            # pool; gR never touches those, and the next gU / gA writes them only behind `s.wait_stream(main)` of step k+1.
+            res = (torch.empty((), dtype=torch.float32, device=st["fake"][i].device),
+                   torch.empty((), dtype=torch.float32, device=st["fake"][i].device), torch.empty_like(st["fake"][i]))
             with _lib.capture_guard():
                 with torch.cuda.graph(gR, pool=pool, stream=s):
                     self.optDs[i].zero_grad()
@@ -716,7 +738,9 @@ class TrainEngine:
                     g_img, = torch.autograd.grad(g_loss, leaf)
                     for p in netsD[i].parameters():
                         p.requires_grad_(True)
-                    return (errD.detach(), g_loss.detach(), g_img)
+                    for dst, src in zip(res, (errD.detach(), g_loss.detach(), g_img)):
+                        dst.copy_(src)
+                    return res
 
                 with torch.cuda.graph(gU, pool=pool, stream=s):
                     errD = discriminator_loss(netsD[i], st["imgs"][i], st["fake"][i], st["sent_emb"], real_labels, fake_labels,
@@ -805,13 +829,18 @@ class TrainEngine:
             self.branch_graphs = False
             try:
                 wb = {k: v for k, v in b.items() if k != "inputs_ready"}
-                for _ in range(2):
-                    self.device_step(dict(wb))
-                with torch.no_grad():
-                    if "words_embs" not in b:
-                        b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
-                    fk, _, _, _ = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
+                # the warm-up draws random numbers (CA_NET's eps when the batch carries none): the generators are put back
+                # afterwards, so a run with branch graphs sees the same random stream as one without from step 1 on
+                with torch.random.fork_rng(devices=[b["z"].device]):
+                    for _ in range(2):
+                        self.device_step(dict(wb))
+                    with torch.no_grad():
+                        if "words_embs" not in b:
+                            b["words_embs"], b["sent_emb"], b["mask"] = self.encode_text(b["captions"], b["cap_lens_cpu"])
+                        fk, _, _, _ = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
                 self._bg = self._bg_capture(b, fk)
+                for o in [self.optG] + self.optDs:
+                    o.repack_on_touch = True
             finally:
                 self.branch_graphs = True
             self._restore(snap)
@@ -1025,6 +1054,8 @@ class TrainEngine:
                 ops.CAPTURE_WGRAD_OK.add(torch.cuda.current_stream().cuda_stream)
                 ops.precreate_wgrad_stream(torch.cuda.current_stream())
                 self._graph_out = self.device_step(st)
+            for o in [self.optG] + self.optDs:
+                o.repack_on_touch = True
             self._restore(snap)
         st = self._static
         for k in self._GRAPH_KEYS:
@@ -1357,8 +1388,14 @@ class condGANTrainer(object):
                     imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data_raw(data, feeder)
                 else:
                     imgs, captions, cap_lens, class_ids, keys, (tm, tmi), label_one_hot = prepare_data(data, self.device)
-                return dict(imgs=imgs, captions=captions, cap_lens=cap_lens, cap_lens_cpu=cap_lens.cpu(),
-                            class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot)
+                d = dict(imgs=imgs, captions=captions, cap_lens=cap_lens, cap_lens_cpu=cap_lens.cpu(),
+                         class_ids=class_ids, tm=tm, tmi=tmi, label_one_hot=label_one_hot)
+                # everything the D_i(real) branches read (images, labels, boxes) is queued on this stream by now -- host copies
+                # or the DeviceFeeder's kernels: with this event those branches of the batch's step start without waiting for
+                # the tail of the previous step on the main stream (TrainEngine.device_step; what bench.py times)
+                d["inputs_ready"] = torch.cuda.Event()
+                d["inputs_ready"].record()
+                return d
 
             # one batch of look-ahead: while step k runs, batch k+1 is already on the device and its captions go through the frozen
             # text encoder (TrainEngine.prefetch_text) -- trainer.py:276-289 software-pipelined, one text encoding per batch as there
@@ -1388,6 +1425,7 @@ class condGANTrainer(object):
                         self.save_img_results(netG, fixed_noise, s_, w, m, image_encoder, captions, cap_lens, epoch,
                                               tmi, label_one_hot, name='average')
                         load_params(netG, backup_para)
+                        self.engine.repack_all()     # (load_params marks every packed copy stale; graphs do not re-check)
                 gen_iterations += 1
             end_t = time.time()
             if logs:

@@ -207,17 +207,16 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 # group, same round (tools/queue_probe_single.sh, one box, interleaved): (4,2) 390.7 / 391.0, (4,0) 385.6 / 387.4, (4,3) 366, (4,1)
 # 367 -- with the branch graphs the weight-gradient streams of the discriminators are idle and the best slot assignment moved;
 # both kinds of process now use (4 queues, 2 idle streams).
-HW_QUEUES_DEFAULT = "3"
 _reserved = []
 
 
-def _single_process():
-    return int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MOGAN_FORCE_DIST")
-
-
 def hw_queue_defaults():
-    """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above)"""
-    return ("4", 2)
+    """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above).  The same
+    for a single process and for a member of a process group: torch's ProcessGroupNCCL adds ONE stream per device whatever the
+    world size, and that is the arrangement the 1-rank-group measurements above were taken with; what a real multi-GPU world
+    changes is how long that stream's kernels run, not how many streams exist.  MOGAN_HW_QUEUES / MOGAN_RESERVED_STREAMS (or
+    GPU_MAX_HW_QUEUES itself) override it for a node where this turns out wrong."""
+    return (os.environ.get("MOGAN_HW_QUEUES", "4"), 2)
 
 
 def configure_hw_queues():

@@ -465,6 +465,14 @@ def deep_block_eligible(x, w, stride, ph, pw, act):
     e = _deep_elig.get(key)
     if e is None:
         e = _deep_elig[key] = bool(lib.load().mogan_deep_block_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act))
+    if e:
+        # one weight used with two convolution geometries has packed copies for the first one only (WeightPacks.pointer
+        # returns None for the other): such a call takes the unfused path
+        pk = w._mogan_pk
+        for d in (0, 1):
+            slot = pk.slots.get(d)
+            if slot is not None and slot[3] != (stride, ph, pw):
+                return False
     return e
 
 
@@ -482,6 +490,8 @@ class DeepConvBNActFn(torch.autograd.Function):
         dev = x.device
         pk = w._mogan_pk
         wp = pk.pointer(0, B, Hs, Ws, stride, ph, pw)
+        if wp is None:          # (deep_block_eligible checks both directions; a NULL panel must never reach the kernel)
+            raise lib.MoganHipError("deep block: no packed forward copy of this weight for geometry %r" % ((stride, ph, pw),))
         f32 = dict(dtype=torch.float32, device=dev)
         y = torch.empty((B, Cout, OH, OW), **f32)
         z = torch.empty((B, Cout, OH, OW), **f32)
@@ -516,6 +526,8 @@ class DeepConvBNActFn(torch.autograd.Function):
         want_dx = ctx.needs_input_grad[0]
         dx = torch.empty(x.shape, dtype=torch.float32, device=dev) if want_dx else None
         wpd = w._mogan_pk.pointer(1, B, Hs, Ws, stride, ph, pw) if want_dx else None
+        if want_dx and wpd is None:
+            raise lib.MoganHipError("deep block: no packed data-gradient copy of this weight for geometry %r" % ((stride, ph, pw),))
         gg, gb = _grad_buf(gamma), _grad_buf(beta)
         want_gb = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         direct = gg is not None and gb is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]

@@ -103,3 +103,86 @@ def test_text_dataset_raw_mode_structure(fake_coco):
     assert u8.dtype == torch.uint8 and tuple(u8.shape) == (3, 268, 268, 3)
     assert tuple(caps.shape) == (3, 12, 1) and tuple(bbox.shape) == (3, 3, 4) and tuple(onehot.shape) == (3, 3, 81)
     np.testing.assert_allclose(bbox.numpy(), np.asarray(ds.bbox[:3], dtype=np.float32))
+
+
+# ---------------------------------------------------------------------------- pinned to the reference (tests/golden/datasets.npz)
+def _golden_datasets():
+    from helpers import GOLDEN
+    return np.load(os.path.join(GOLDEN, "datasets.npz"))
+
+
+def test_crop_imgs_and_draw_crop_against_the_reference_fixture():
+    """datasets.py:95-137 run by the REFERENCE (tests/golden/make_golden_datasets.py) on 48 seeded cases -- crop origin, flip,
+    box rescale, both clamps, absent objects: datasets.crop_imgs must reproduce the scaled boxes bit for bit (float64, same
+    draws in the same order) and the same crop; feeder.draw_crop (the device feeder's host half, float32 boxes as the raw
+    loader carries them) the same crop parameters and the boxes to float32 rounding; the theta matrices built from them
+    (datasets.py:331-339) to 1e-6."""
+    import datasets_cases as C
+    from mogan_amd.attngan import feeder
+    g = _golden_datasets()
+    img = C.crop_image()
+    ds = datasets.SyntheticTextDataset(length=1)
+    for case in range(C.N_CROP):
+        np.random.seed(500 + case)
+        crop, scaled = datasets.crop_imgs(img, C.crop_boxes(case))
+        assert scaled.dtype == np.float64
+        np.testing.assert_array_equal(scaled, g["crop_boxes"][case], err_msg="case %d" % case)
+        probe = [float(crop[0, 0, 0]), float(crop[0, 0, 255]), float(crop[2, 255, 0]), float(crop[1, 255, 255]),
+                 float(crop.double().sum())]
+        np.testing.assert_array_equal(np.asarray(probe), g["crop_probe"][case], err_msg="crop of case %d" % case)
+        tm, tmi = ds._matrices(scaled)
+        np.testing.assert_allclose(tm.numpy(), g["crop_mats"][case][0], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tmi.numpy(), g["crop_mats"][case][1], rtol=1e-5, atol=1e-5)
+        # the device feeder's host half: same draws -> same (h1, w1, flip); the crop it asks the kernel for is the reference's
+        np.random.seed(500 + case)
+        (h1, w1, flip), sb = feeder.draw_crop(C.crop_boxes(case).astype(np.float32), np.random)
+        want00 = g["crop_probe"][case][0]                     # = flat index of the crop's first element in channel 0
+        col = h1 + 255 if flip else h1
+        assert float(img[0, w1, col]) == want00, (case, h1, w1, flip)
+        np.testing.assert_allclose(sb, g["crop_boxes"][case], rtol=0, atol=2e-7)
+    # the fixture covers what it claims: both clamps, flips, absent objects
+    b = g["crop_boxes"]
+    assert np.any(np.isclose(b[:, :, 0] + b[:, :, 2], 0.999)) and np.any(np.isclose(b[:, :, 1] + b[:, :, 3], 0.999))
+    assert np.any(b[:, 2, 0] == -1) and np.any(b[:, 1, 0] == -1) and np.any(b[:, 0, 0] != -1)
+
+
+def test_one_hot_labels_and_captions_against_the_reference_fixture():
+    """datasets.py:341-349 (get_one_hot_labels) and 311-329 (get_caption, incl. the seeded random subset of a caption longer
+    than WORDS_NUM) as the reference computes them."""
+    import datasets_cases as C
+    g = _golden_datasets()
+    for i, lab in enumerate(C.label_cases()):
+        got = datasets._Base._one_hot(lab).numpy()
+        np.testing.assert_array_equal(got, g["onehot"][i])
+        np.testing.assert_array_equal(synthetic.one_hot_labels(lab.reshape(-1)).numpy(), g["onehot"][i])
+    cfg.TEXT.WORDS_NUM = C.T_WORDS
+    holder = datasets.TextDataset.__new__(datasets.TextDataset)
+    for i, cap in enumerate(C.caption_cases()):
+        holder.captions = [cap]
+        np.random.seed(900 + i)
+        x, n = holder.get_caption(0)
+        np.testing.assert_array_equal(x, g["cap_x"][i])
+        assert int(n) == int(g["cap_len"][i])
+
+
+@pytest.mark.parametrize("ev", [False, True])
+def test_prepare_data_against_the_reference_fixture(ev):
+    """datasets.py:28-68: every field of the minibatch re-ordered by descending caption length exactly as the reference does
+    (ties included), train and eval form."""
+    import datasets_cases as C
+    g = _golden_datasets()
+    tag = "pde" if ev else "pd"
+    imgs, caps, lens, cls, keys, tms, label, bbox = C.batch_case()
+    data = [list(imgs), caps, lens, cls, keys, list(tms), label] + ([bbox] if ev else [])
+    res = datasets.prepare_data(data, torch.device("cpu"), eval=ev)
+    for i, im in enumerate(res[0]):
+        np.testing.assert_array_equal(im.numpy(), g["%s_img%d" % (tag, i)])
+    np.testing.assert_array_equal(res[1].numpy(), g[tag + "_captions"])
+    np.testing.assert_array_equal(res[2].numpy(), g[tag + "_lens"])
+    np.testing.assert_array_equal(np.asarray(res[3]), g[tag + "_class_ids"])
+    assert list(res[4]) == list(g[tag + "_keys"])
+    np.testing.assert_array_equal(res[5][0].numpy(), g[tag + "_tm"])
+    np.testing.assert_array_equal(res[5][1].numpy(), g[tag + "_tmi"])
+    np.testing.assert_array_equal(res[6].numpy(), g[tag + "_label"])
+    if ev:
+        np.testing.assert_array_equal(res[7].numpy(), g[tag + "_bbox"])

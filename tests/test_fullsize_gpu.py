@@ -128,3 +128,66 @@ def test_full_width_train_step_properties():
     torch.cuda.synchronize()
     for k in ("errD0", "errD1", "errD2", "errG"):
         np.testing.assert_allclose(float(logs1[k]), float(logs[k]), rtol=2e-5, err_msg=k)
+
+
+def _bench_module():
+    import importlib
+    return importlib.import_module("bench")          # ROOT is on sys.path (conftest); importing runs no benchmark
+
+
+def test_headline_workload_one_step_against_the_oracle():
+    """BASELINE config 5's per-GPU shard -- full coco_train.yml widths, B = 16 -- through the default launch mode (generator
+    eager, discriminator branches replayed as hipGraphs, `inputs_ready` early start): after a few training steps (weights off
+    their initial values, as after bench.py's timed region) ONE step of the HIP engine against ONE step of the CPU oracle from
+    the same weights, z and eps.  This is bench.py's `parity` leg (bench.cpu_baseline_leg), here under -m gpu.
+    Stated fp32 tolerance: every loss 1e-4 relative (errG carries the DAMSM terms weighted by 50), generated images 1e-3
+    max-abs after the ~100-layer generator."""
+    from mogan_amd.attngan.trainer import TrainEngine, build_networks
+    bench = _bench_module()
+    set_coco_train_defaults()
+    cfg.TRAIN.BATCH_SIZE = B
+    te, ie, G, Ds = build_networks(device=DEV, seed=1234)
+    eng = TrainEngine(te, ie, G, Ds)
+    assert eng.branch_graphs
+    batch, bt_cpu = bench.make_device_batch(B, seed=0, device=torch.device(DEV))
+    torch.cuda.synchronize()
+    batch["inputs_ready"] = torch.cuda.Event()
+    batch["inputs_ready"].record()
+    gen = torch.Generator(device=DEV).manual_seed(1000)
+    for _ in range(4):
+        b = dict(batch)
+        b["z"] = torch.randn(B, cfg.GAN.Z_DIM, device=DEV, generator=gen)
+        b["eps"] = torch.randn(B, cfg.GAN.CONDITION_DIM, device=DEV, generator=gen)
+        eng.prefetch_text(batch["captions"], batch["cap_lens_cpu"])
+        eng.step(b)
+    torch.cuda.synchronize()
+    dev_batch = dict(batch)
+    dev_batch.update(eng.encode_batch_for_cpu(batch))
+    base, parity = bench.cpu_baseline_leg(eng, bt_cpu, dev_batch, B, torch.device(DEV), timed_steps=0)
+    print("parity", {k: v for k, v in parity.items() if k not in ("hip", "oracle", "what")})
+    for k in ("errD0", "errD1", "errD2", "errG", "w_loss", "s_loss"):
+        assert parity[k + "_rel"] <= 1e-4, (k, parity[k + "_rel"], parity["hip"], parity["oracle"])
+    assert parity["kl_rel"] <= 1e-4
+    assert parity["img64_max_abs"] <= 1e-3 and parity["img256_max_abs"] <= 1e-3
+    assert parity["ok"]
+
+
+@pytest.mark.parametrize("name", ["clevr", "coco_s2"])
+def test_secondary_workloads_one_step_against_the_oracle_at_their_stated_size(name):
+    """BASELINE configs 2 and 3 at the size they are quoted on (CLEVR B = 32; MS-COCO StackGAN stage II 256x256 B = 24, yml
+    widths): `bench.py --workload <name>` -- a few timed steps, then its `parity` object: one HIP step against one step of
+    oracle/stackgan_oracle.py from the benchmarked weights on the same batch / z / eps.  Losses 1e-4 relative, images 1e-3."""
+    import argparse
+    bench = _bench_module()
+    args = argparse.Namespace(family_batch=None, graph=False, no_graph=False, warmup=2, steps=3, no_roofline=True,
+                              no_cpu_baseline=False)
+    real = bench.family_cpu_baseline
+    bench.family_cpu_baseline = lambda *a, **k: real(*a, **dict(k, timed_steps=0))     # parity step only
+    try:
+        out = bench.run_family(name, args, torch.device(DEV))
+    finally:
+        bench.family_cpu_baseline = real
+    par = out["parity"]
+    print(name, {k: v for k, v in par.items() if k not in ("what",)})
+    assert out["config"]["batch_per_gpu"] == {"clevr": 32, "coco_s2": 24}[name]
+    assert par["ok"], par

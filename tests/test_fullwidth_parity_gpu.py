@@ -185,6 +185,63 @@ def test_full_width_gnet_forward_and_dnet256_loss_backward():
                                                        float(oerr.detach()), worst[0], worst[1], len(trace)))
 
 
+def test_full_width_gnet_backward_every_gradient_against_the_fp64_oracle():
+    """model.py:478-528 at coco_train.yml widths, B = 4: the generator's BACKWARD -- the Winograd F(2,3) data-gradient /
+    weight-gradient chains of the ResBlocks at 64x64 and 128x128, the up-conv identity kernels, the grouped BatchNorm backward of
+    the object pathway, the attention backward at 64x64 / 128x128 -- element for element against the fp64 oracle (which
+    tests/test_oracle_golden.py pins to the reference's fixtures), for a loss that is a fixed random linear functional of all
+    three images, mu and logvar, with the LeakyReLU decisions of the checked pass handed to the oracle (BBOX_NET; see above).
+    Stated tolerance: every G gradient tensor rel-L2 <= 1e-2 -- the stacked BN+GLU generator is
+    ill-conditioned in fp32, torch-fp32 itself is at 1.7e-3..3.2e-3 from fp64 there; the measured value is printed."""
+    from mogan_amd.attngan import model
+    from mogan_amd.hip import ops
+    from oracle import attngan_oracle as O
+    B, dt = 4, torch.float64
+    cpu = synthetic.make_batch(B, words_num=12, nef=256, seed=23)
+    bt = synthetic.to_device(cpu, DEV)
+    G = model.G_NET()
+    sdg = det_fill_state(G, "G.")
+    G = G.to(DEV).train()
+    ops.ACT_TRACE = []
+    try:
+        imgs, atts, mu, logvar = G(bt["z"], bt["sent_emb"], bt["words_embs"], bt["mask"], bt["tmi"], bt["label_one_hot"],
+                                   eps=bt["eps"])
+    finally:
+        trace, ops.ACT_TRACE = ops.ACT_TRACE, None
+    # cotangents scaled so that the three image terms weigh alike (sum over 3 * H * W * B elements each)
+    ups = [T("FW.gimg%d" % i, im.shape, 1.0 / float(im[0].numel()) ** 0.5) for i, im in enumerate(imgs)]
+    ups += [T("FW.gmu", mu.shape, 0.1), T("FW.glv", logvar.shape, 0.1)]
+    with ops.wgrad_overlap():
+        sum((t * u.to(DEV)).sum() for t, u in zip(list(imgs) + [mu, logvar], ups)).backward()
+    torch.cuda.synchronize()
+    og = O.from_state_dict(sdg, dtype=dt)
+    c64 = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in cpu.items()}
+    O.LRELU_MASKS = [(t > 0).cpu() for a, t in trace if a == ops.ACT_LRELU]
+    O.LRELU_FLIPS = []
+    try:
+        oimgs, oatts, omu, olv, _ = O.g_net(og, O.Cfg(), c64["z"], c64["sent_emb"], c64["words_embs"], c64["mask"],
+                                            c64["tmi"], c64["label_one_hot"], c64["eps"])
+        assert not O.LRELU_MASKS
+        flips = O.LRELU_FLIPS
+    finally:
+        O.LRELU_MASKS = O.LRELU_FLIPS = None
+    assert sum(f[0] for f in flips) <= 4, flips
+    for k, a, b in [("img%d" % (64 << i), imgs[i], oimgs[i]) for i in range(3)]:
+        assert max_abs(a, b) <= 1e-4, (k, max_abs(a, b))
+    sum((t * u.to(dt)).sum() for t, u in zip(list(oimgs) + [omu, olv], ups)).backward()
+    worst, rows = (0.0, ""), []
+    for k, p in G.named_parameters():
+        assert p.grad is not None and og[k].grad is not None, k
+        r = rel_l2(p.grad, og[k].grad)
+        rows.append((r, k))
+        worst = max(worst, (r, k))
+    rows.sort(reverse=True)
+    print("full-width G_NET backward vs fp64 oracle, B = %d: worst rel-L2 %.2e (%s); top 5: %s" % (
+        B, worst[0], worst[1], ["%s %.1e" % (k, r) for r, k in rows[:5]]))
+    for r, k in rows:
+        assert r <= 1e-2, "G d%s: rel-L2 %.3e vs the fp64 oracle" % (k, r)
+
+
 def test_rnn_encoder_vs_reference_fixture():
     """model.py:120-204: embedding + packed bidirectional LSTM (stock nn.LSTM on the device)."""
     import sys

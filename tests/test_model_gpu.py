@@ -234,29 +234,43 @@ def test_g_net_eval_mode():
     assert all(int(v) == 0 for k, v in G.state_dict().items() if k.endswith("num_batches_tracked"))
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs", "branch_graphs_and_g"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs", "branch_graphs_and_g", "branch_graphs_inputs_ready"])
 def test_two_train_steps(mode):
     """the op order of the step (fake images generated once, each D updated
     before generator_loss forwards through it), Adam, EMA, BN running statistics -- eager, as one
-    replayed hipGraph, with the discriminator branches as hipGraphs beside an eager generator (the default), and with the
-    generator (forward / backward + Adam) replayed as hipGraphs as well (MOGAN_G_GRAPHS=1)."""
+    replayed hipGraph, with the discriminator branches as hipGraphs beside an eager generator (the default), with the
+    generator (forward / backward + Adam) replayed as hipGraphs as well (MOGAN_G_GRAPHS=1), and -- branch_graphs_inputs_ready --
+    the way bench.py and condGANTrainer.train() drive the engine: every batch carries an `inputs_ready` event, so D_i(real) of
+    step 1 is replayed on its branch stream while the main stream is still in step 0's generator backward (no host
+    synchronisation between the two steps; the branch results the main stream reads live outside the graphs' pool)."""
     from mogan_amd.attngan.trainer import TrainEngine
     g = golden("step")
     G, Ds, enc = _build_all()
     eng = TrainEngine(None, enc, G, Ds, use_graph=mode == "graph", branch_graphs=mode.startswith("branch_graphs"))
     assert eng.branch_graphs == mode.startswith("branch_graphs") and not eng.g_graphs
     eng.g_graphs = mode == "branch_graphs_and_g"
+    early = mode == "branch_graphs_inputs_ready"
     nets = [("G", G)] + [("D%d" % i, D) for i, D in enumerate(Ds)]
     init = {n: {k: probe(v) for k, v in net.state_dict().items()} for n, net in nets}
-    for step in range(2):
-        bt = synthetic.to_device(synthetic.make_batch(4, words_num=5, nef=16, seed=100 + step), DEV)
-        logs = eng.step(bt)
+    bts = [synthetic.to_device(synthetic.make_batch(4, words_num=5, nef=16, seed=100 + step), DEV) for step in range(2)]
+    if early:
         torch.cuda.synchronize()
+        for bt in bts:
+            bt["inputs_ready"] = torch.cuda.Event()
+            bt["inputs_ready"].record()
+    all_logs = []
+    for step in range(2):
+        logs = eng.step(bts[step])
+        all_logs.append({k: v.clone() for k, v in logs.items()})
+        if early and step == 0:
+            continue                                   # straight into step 1: its D_i(real) replays overlap step 0's tail
+        torch.cuda.synchronize()
+        for st_, lg in enumerate(all_logs):
+            for k in ("errD0", "errD1", "errD2", "kl"):
+                np.testing.assert_allclose(float(lg[k]), float(g["s%d_" % st_ + k]), rtol=1e-4 * (1 + 9 * st_), err_msg=k)
+            np.testing.assert_allclose(float(lg["errG"]), float(g["s%d_errG" % st_]), rtol=2e-4 * (1 + 9 * st_))
+            close(lg["fake64"], g["s%d_fake64" % st_], 2e-4 * (1 + 9 * st_), 1e-3)
         p = "s%d_" % step
-        for k in ("errD0", "errD1", "errD2", "kl"):
-            np.testing.assert_allclose(float(logs[k]), float(g[p + k]), rtol=1e-4 * (1 + 9 * step), err_msg=k)
-        np.testing.assert_allclose(float(logs["errG"]), float(g[p + "errG"]), rtol=2e-4 * (1 + 9 * step))
-        close(logs["fake64"], g[p + "fake64"], 2e-4 * (1 + 9 * step), 1e-3)
         # Adam's first steps move every element by ~lr*sign(g): where |g| is at the fp32 noise floor the
         # sign is not reproducible (SURVEY §8(c)), which shows on the tiny 1-D tensors (a 12-element BN
         # bias of magnitude 0.1 moves by up to 2*lr per step) -> looser checksum tolerance for those

@@ -420,6 +420,11 @@ def main():
                     "each on the GPU box's host; default 2 keeps the default run within minutes, BASELINE.md section 3 asks "
                     "for 5: --cpu-steps 5)")
     ap.add_argument("--no-text-prefetch", action="store_true", help="text-encode every batch at the start of its own step")
+    ap.add_argument("--no-inputs-ready", action="store_true", help="A/B: D_i(real) of a step waits for the main stream (the "
+                    "tail of the previous step) instead of for the batch's inputs_ready event")
+    ap.add_argument("--dp-mode", default="both", choices=["both", "branch_graphs", "eager"],
+                    help="N > 1: discriminator branches as hipGraphs, eager, or (default) both measured in one run")
+    ap.add_argument("--no-comm-stats", action="store_true", help="N > 1: no timing events around the collectives")
     ap.add_argument("--debug-losses", action="store_true", help="print the losses of every step (adds a host sync)")
     ap.add_argument("--workload", default="attngan", choices=["attngan"] + list(WORKLOADS),
                     help="attngan = the headline metric (default); the others are the secondary BASELINE configs "
@@ -458,47 +463,84 @@ def main():
     cfg.TRAIN.BATCH_SIZE = B
     text_encoder, image_encoder, netG, netsD = build_networks(device=device, seed=1234)   # identical replicas
     use_graph = (world == 1) and args.graph and not args.no_graph
-    engine = TrainEngine(text_encoder, image_encoder, netG, netsD, distributed=world > 1 or force_dist,
-                         use_graph=use_graph and not force_dist)
+    dist_on = world > 1 or force_dist
     batch, bt_cpu = make_device_batch(B, seed=rank, device=device)
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     # the synthetic minibatch is resident in HBM before the timed region: tell the engine, so that the D(real)
-    # forwards of step n+1 need not queue behind the tail of step n on the main stream
+    # forwards of step n+1 need not queue behind the tail of step n on the main stream (condGANTrainer.train() records the
+    # same event behind its look-ahead batch's host-to-device copies / feeder kernels)
     torch.cuda.synchronize()
-    batch["inputs_ready"] = torch.cuda.Event()
-    batch["inputs_ready"].record()
+    if not args.no_inputs_ready:
+        batch["inputs_ready"] = torch.cuda.Event()
+        batch["inputs_ready"].record()
 
-    def run_step():
-        b = dict(batch)
-        b["z"] = torch.randn(B, cfg.GAN.Z_DIM, device=device, generator=gen)         # trainer.py:294
-        b["eps"] = torch.randn(B, cfg.GAN.CONDITION_DIM, device=device, generator=gen)  # model.py:336
-        # the train loop hands the NEXT batch's captions to the engine with every step (one text encoding per step, as in
-        # trainer.py:281-289, software-pipelined one step ahead; condGANTrainer.train does the same)
-        if not args.no_text_prefetch and not engine.use_graph:
-            engine.prefetch_text(batch["captions"], batch["cap_lens_cpu"])
-        return engine.step(b)
+    def make_runner(engine):
+        def run_step():
+            b = dict(batch)
+            b["z"] = torch.randn(B, cfg.GAN.Z_DIM, device=device, generator=gen)         # trainer.py:294
+            b["eps"] = torch.randn(B, cfg.GAN.CONDITION_DIM, device=device, generator=gen)  # model.py:336
+            # the train loop hands the NEXT batch's captions to the engine with every step (one text encoding per step, as in
+            # trainer.py:281-289, software-pipelined one step ahead; condGANTrainer.train does the same)
+            if not args.no_text_prefetch and not engine.use_graph:
+                engine.prefetch_text(batch["captions"], batch["cap_lens_cpu"])
+            return engine.step(b)
+        return run_step
 
-    for _ in range(args.warmup):
-        run_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logs = run_step()
-        if args.debug_losses:
-            print("step", {k: round(float(v), 4) for k, v in logs.items() if v.dim() == 0}, file=sys.stderr, flush=True)
-    host_elapsed = time.perf_counter() - t0             # all launches of the K steps queued (diagnostic: host- or GPU-bound?)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(engine, run_step):
+        """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; elapsed = MAX over ranks"""
+        for _ in range(args.warmup):
+            run_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        engine.comm.enabled = dist_on and not args.no_comm_stats
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            logs = run_step()
+            if args.debug_losses:
+                print("step", {k: round(float(v), 4) for k, v in logs.items() if v.dim() == 0}, file=sys.stderr, flush=True)
+        host_elapsed = time.perf_counter() - t0         # all launches of the K steps queued (diagnostic: host- or GPU-bound?)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        comm = engine.comm.report(args.steps) if engine.comm.enabled else None
+        engine.comm.enabled = False
+        return elapsed, host_elapsed, logs, comm
+
+    # Data parallel: the step has two launch modes for the discriminator branches (trainer.TrainEngine) -- replayed hipGraphs with
+    # each bucket's all-reduce issued between two replays ("branch_graphs"), or eager launches whose weight-gradient kernels
+    # release D_NET256's bucket chunk by chunk while its backward is still running ("eager").  Which one wins depends on how long
+    # the collectives take with real peers, so one invocation measures BOTH (same networks, a fresh engine each) and reports the
+    # better one as `value`, both under `modes`.
+    modes = [None]
+    if dist_on:
+        modes = [args.dp_mode] if args.dp_mode != "both" else ["branch_graphs", "eager"]
+    results, engine = {}, None
+    for mode in modes:
+        if engine is not None:
+            engine.close()
+            del engine, run_step
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+        if mode is not None:
+            os.environ["MOGAN_BRANCH_GRAPHS_DP"] = "1" if mode == "branch_graphs" else "0"
+        engine = TrainEngine(text_encoder, image_encoder, netG, netsD, distributed=dist_on, use_graph=use_graph and not force_dist)
+        run_step = make_runner(engine)
+        elapsed, host_elapsed, logs, comm = timed_region(engine, run_step)
+        results[mode] = dict(elapsed=elapsed, host_elapsed=host_elapsed, logs=logs, comm=comm,
+                             launch="hipGraph" if engine.use_graph else "%s, %d streams + wgrad side streams" % (
+                                 "generator eager + discriminator branches as hipGraphs" if engine.branch_graphs else "eager",
+                                 1 + (len(engine.side) if engine.multi_stream else 0)))
+    best = min(results, key=lambda m: results[m]["elapsed"])
+    elapsed, host_elapsed, logs = (results[best][k] for k in ("elapsed", "host_elapsed", "logs"))
 
     for k, v in logs.items():                           # a benchmark of a diverged computation is not a benchmark
         if torch.is_tensor(v) and v.dim() == 0:
@@ -513,12 +555,16 @@ def main():
         "config": {"workload": "MS-COCO AttnGAN 256x256 G+D train step: G_NET + D_NET64/128/256 + "
                                "GlobalAttentionGeneral + Inception/DAMSM losses (random-init), coco_train.yml "
                                "widths (GF 48, DF 96, T 12), fp32", "batch_per_gpu": B, "global_batch": world * B,
-                   "parallelism": "dp%d" % world,
-                   "launch": "hipGraph" if engine.use_graph else "%s, %d streams + wgrad side streams" % (
-                       "generator eager + discriminator branches as hipGraphs" if engine.branch_graphs else "eager",
-                       1 + (len(engine.side) if engine.multi_stream else 0))},
+                   "parallelism": "dp%d" % world, "launch": results[best]["launch"]},
         "losses": {k: float(v) for k, v in logs.items() if torch.is_tensor(v) and v.dim() == 0},
     }
+    if dist_on:
+        # per launch mode: throughput and, per gradient bucket, what its all-reduce cost and how much of it the consumer saw
+        out["dp"] = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "mode_reported": best,
+                     "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                     "modes": {m: {"value": world * B * args.steps / r["elapsed"], "ms_per_step": r["elapsed"] / args.steps * 1e3,
+                                   "host_enqueue_ms_per_step": r["host_elapsed"] / args.steps * 1e3, "launch": r["launch"],
+                                   "buckets": r["comm"]} for m, r in results.items()}}
     rows = None
     if not args.no_roofline:
         # EVERY rank runs these extra steps (they contain the gradient all-reduces: a rank-0-only leg would leave

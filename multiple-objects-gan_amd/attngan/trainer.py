@@ -160,12 +160,61 @@ class FlatAdam:
         self.touch()
 
 
-def allreduce_flat(flat_g, comm_stream=None):
+class CommStats:
+    """Per-bucket communication timing of the data-parallel step (bench.py --gpus N reports it; off by default: it creates
+    timing events around every collective and around every wait of a consumer).  Two figures per gradient bucket and step:
+      allreduce_ms  time the bucket's collectives took on the stream they execute on (peers' arrival included),
+      exposed_ms    time the consumer -- the stream that runs the bucket's Adam -- was held at its wait for them
+    (trainer.py:296, miscc/losses.py:146-193 are the reference's per-call gathers these collectives replace)."""
+
+    def __init__(self):
+        self.enabled, self.rec, self.meta = False, [], {}
+
+    def begin(self, name, kind, stream=None, nbytes=0):
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream) if stream is not None else ev.record()
+        m = self.meta.setdefault(name, {"bytes": 0, "collectives": 0})
+        if kind == "allreduce":
+            m["bytes"] += int(nbytes)
+            m["collectives"] += 1
+        return (name, kind, ev, stream)
+
+    def end(self, tok):
+        if tok is None:
+            return
+        name, kind, ev0, stream = tok
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(stream) if stream is not None else ev1.record()
+        self.rec.append((name, kind, ev0, ev1))
+
+    def report(self, steps):
+        """{bucket: {bytes, collectives, allreduce_ms, exposed_ms}} per step, averaged over `steps` recorded steps"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, m in self.meta.items():
+            out[name] = {"bytes_per_step": m["bytes"] // max(steps, 1), "collectives_per_step": m["collectives"] / max(steps, 1),
+                         "allreduce_ms": 0.0, "exposed_ms": 0.0}
+        for name, kind, e0, e1 in self.rec:
+            o = out.setdefault(name, {"bytes_per_step": 0, "collectives_per_step": 0, "allreduce_ms": 0.0, "exposed_ms": 0.0})
+            o["allreduce_ms" if kind == "allreduce" else "exposed_ms"] += e0.elapsed_time(e1) / max(steps, 1)
+        self.rec, self.meta = [], {}
+        return out
+
+
+def allreduce_flat(flat_g, comm_stream=None, stats=None, name=None):
     """Sum all-reduce of one flat gradient bucket over the default process group (RCCL on GPUs, gloo in
     the CPU tests).  With a side stream the collective is ordered after the work already queued on the
     current stream and an event is returned for the consumer (the bucket's Adam) to wait on."""
     if comm_stream is None:
+        # issued on the caller's stream: the process group orders the collective behind the work queued on it and the stream
+        # continues behind the collective -- its duration IS the consumer's wait
+        tok = stats.begin(name, "allreduce", nbytes=flat_g.numel() * 4) if stats is not None else None
         dist.all_reduce(flat_g)
+        if tok is not None:
+            stats.end(tok)
+            stats.rec.append((name, "exposed") + stats.rec[-1][2:])
         return None
     ev = torch.cuda.Event()
     ev.record()
@@ -191,8 +240,8 @@ class ChunkedReducer:
     makes the caller's stream wait for all chunks.  Same sums as one all-reduce of the whole bucket; the order of the
     collectives is a function of the model's structure only, hence identical on every rank."""
 
-    def __init__(self, flat, chunk_bytes, comm_stream):
-        self.flat, self.comm = flat, comm_stream
+    def __init__(self, flat, chunk_bytes, comm_stream, stats=None, name=None):
+        self.flat, self.comm, self.stats, self.name = flat, comm_stream, stats, name
         base = flat.g.data_ptr()
         self.base = base
         bounds, start = [], flat.numel
@@ -271,11 +320,23 @@ class ChunkedReducer:
                 self.comm.wait_event(ev)
         lo, hi = self.chunks[ci]
         with torch.cuda.stream(self.comm):
+            tok = self.stats.begin(self.name, "allreduce", nbytes=(hi - lo) * 4) if self.stats is not None else None
             dist.all_reduce(self.flat.g[lo:hi])
+            if tok is not None:
+                self.stats.end(tok)
             ev = torch.cuda.Event()
             ev.record()
         self.done.append(ev)
         self.launched.add(ci)
+
+    def _wait_all(self):
+        """the current stream (the bucket's consumer) waits for every chunk; the time it is held there is the exposed part"""
+        cur = torch.cuda.current_stream()
+        tok = self.stats.begin(self.name, "exposed") if self.stats is not None else None
+        for ev in self.done:
+            cur.wait_event(ev)
+        if tok is not None:
+            self.stats.end(tok)
 
     def reduce_now(self):
         """Branch graphs: the backward that fills the bucket is one replayed hipGraph -- no hook fires, nothing can leave early.
@@ -285,9 +346,7 @@ class ChunkedReducer:
         self.counts, self.done, self.launched, self.late, self.active, self.early = {}, [], set(), [], False, 0
         for ci in range(len(self.chunks)):
             self._launch(ci)
-        cur = torch.cuda.current_stream()
-        for ev in self.done:
-            cur.wait_event(ev)
+        self._wait_all()
         return len(self.chunks)
 
     def finish(self):
@@ -313,10 +372,24 @@ class ChunkedReducer:
         for ci in range(len(self.chunks)):
             if ci not in self.launched:
                 self._launch(ci)
-        cur = torch.cuda.current_stream()
-        for ev in self.done:
-            cur.wait_event(ev)
+        self._wait_all()
         return len(self.chunks)
+
+
+# HIP assigns a stream its hardware queue when the stream is created, round-robin over GPU_MAX_HW_QUEUES, and which streams
+# share a queue decides +-8 % of the step (hip/lib.py, "hardware queues").  The engines of one process therefore take their
+# streams from this table: the FIRST engine creates them in the one order the queue defaults were measured with, every later
+# engine (bench.py's second data-parallel launch mode, a test's second engine) runs on the very same streams and so on the
+# same queue layout -- instead of on whatever the next entries of torch's 32-stream pool happen to map to.
+_ENGINE_STREAMS = {}
+
+
+def _engine_stream(key):
+    key = (torch.cuda.current_device(),) + tuple(key)
+    s = _ENGINE_STREAMS.get(key)
+    if s is None:
+        s = _ENGINE_STREAMS[key] = torch.cuda.Stream()
+    return s
 
 
 class TrainEngine:
@@ -363,7 +436,7 @@ class TrainEngine:
         # there for hosts whose python is slower than the GPU's 40 ms step.
         self.g_graphs = self.branch_graphs and not self.distributed and os.environ.get("MOGAN_G_GRAPHS", "0") != "0"
         self._bg = None
-        self.side = [torch.cuda.Stream() for _ in range(len(netsD) + 1)]
+        self.side = [_engine_stream(("side", i)) for i in range(len(netsD) + 1)]
         bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
         if bmap:
             ids = [int(v) for v in bmap.split(",")]
@@ -377,6 +450,7 @@ class TrainEngine:
             ops.precreate_wgrad_stream(self.side[i])
         ops.precreate_wgrad_stream(torch.cuda.current_stream())
         self.comm_stream = None          # collectives are issued on the branch streams (see _allreduce_async)
+        self.comm = CommStats()          # per-bucket all-reduce / exposed time (enabled by bench.py for N > 1)
         self._debug_no_ar = bool(os.environ.get("MOGAN_DEBUG_NO_ALLREDUCE"))   # diagnostic: cost of the collectives' ordering
         if self.distributed and self.world > 1:
             self.sync_replicas()
@@ -393,7 +467,20 @@ class TrainEngine:
                     # -- h_net3 / img_net3 at the end of the bucket are differentiated first --, only the last chunk is exposed
                     c = min(chunk, max(8 << 20, o.numel * 4 // 3))
                 if o.numel * 4 >= 2 * c:
-                    self.reducers[id(o)] = ChunkedReducer(o, c, torch.cuda.Stream())
+                    self.reducers[id(o)] = ChunkedReducer(o, c, _engine_stream(("comm", self._bucket_name(o))), self.comm,
+                                                          self._bucket_name(o))
+
+    def _bucket_name(self, flat):
+        if flat is self.optG:
+            return "G"
+        return "D%d" % (64 << self.optDs.index(flat))
+
+    def close(self):
+        """Detach the engine from the process-global hooks (a second engine over the same networks follows: bench.py's two
+        data-parallel launch modes)."""
+        for r in self.reducers.values():
+            r.close()
+        self.reducers = {}
 
     def repack_all(self):
         """Weights were written behind the optimizers' backs (load_params / invalidate_all_packs, a checkpoint restore) while
@@ -433,7 +520,7 @@ class TrainEngine:
         # issued on the branch's own stream: the process group's internal stream orders the collective behind the work
         # queued on it and the branch continues (Adam) behind the collective; a dedicated communication stream only adds
         # a stream whose event wait blocks a hardware queue (measured slower)
-        return allreduce_flat(flat.g, None)
+        return allreduce_flat(flat.g, None, self.comm, self._bucket_name(flat))
 
     def _opt_step(self, flat, pending):
         if pending is not None:
@@ -896,7 +983,7 @@ class TrainEngine:
                     if red is not None:
                         red.reduce_now()
                     elif not self._debug_no_ar:
-                        allreduce_flat(self.optDs[i].g, None)
+                        allreduce_flat(self.optDs[i].g, None, self.comm, self._bucket_name(self.optDs[i]))
                     bg["gA"][i].replay()
             for j, n in enumerate(bg["calls"][i]):
                 self.bn_counter.calls[j] += n

@@ -272,9 +272,15 @@ class WeightPacks:
 
 
 def attach_packs(w, version_cell=None):
-    if getattr(w, "_mogan_pk", None) is None:
-        w._mogan_pk = WeightPacks(w, version_cell)
-    return w._mogan_pk
+    pk = getattr(w, "_mogan_pk", None)
+    if pk is None:
+        pk = w._mogan_pk = WeightPacks(w, version_cell)
+    elif version_cell is not None and pk.cell is not version_cell:
+        # a new owner (a second FlatAdam over the same network): its version counter rules from now on
+        pk.cell = version_cell
+        for slot in pk.slots.values():
+            slot[1] = -1
+    return pk
 
 
 def _packed(w, dgrad, B, Hs, Ws, stride, ph, pw, up):

@@ -325,6 +325,33 @@ int mogan_stn_fwd(const float* x, const float* theta, float* y, int B, int C, in
                   int align_corners, hipStream_t stream);
 int mogan_stn_bwd(const float* dy, const float* theta, float* dx, int B, int C, int Hin, int Win, int Hout,
                   int Wout, int align_corners, hipStream_t stream);
+/* The same with a shared / constant source (round 4; the object pathways' inputs without their materialised copies):
+ *   xB       x holds xB images and output sample b reads image b % xB -- `stn(image, transf_matrices[:, idx], ...)` for every
+ *            object idx from ONE copy of the image batch (model.py:663-665); dx then has xB images and collects all objects;
+ *   x_plane  x is (xB, C): one value per (image, channel), constant over the Hin x Win plane -- the label vector the
+ *            reference first .repeat()s over 16 x 16 (model.py:109-111); dx is (xB, C);
+ *   theta_G  > 0: theta is stored (B / theta_G, theta_G, 2, 3) -- the loader's (image, object) order -- while the batch is
+ *            object-major, sample b = g (B / theta_G) + b' using theta[b'][g] (the batched object loops); 0: theta[b]. */
+int mogan_stn_fwd_ex(const float* x, const float* theta, float* y, int B, int C, int Hin, int Win, int Hout, int Wout,
+                     int align_corners, int xB, int x_plane, int theta_G, hipStream_t stream);
+int mogan_stn_bwd_ex(const float* dy, const float* theta, float* dx, int B, int C, int Hin, int Win, int Hout, int Wout,
+                     int align_corners, int xB, int x_plane, int theta_G, hipStream_t stream);
+/* ---------------------------------------------------------------- channel concat with broadcast sources (round 4)
+ * dst (N, C_0 + ... + C_{nsrc-1}, HW) = the sources side by side along the channel axis -- torch.cat(..., 1) of model.py:
+ * 400-401, 418, 457, 633-634, 666, 703 together with the .repeat() / per-object indexing that feeds it, in ONE launch.
+ * Source i (C[i] channels) is addressed as
+ *     value(n, c, hw) = src[i][(n % rows[i]) * sb[i] + (n / rows[i]) * sg[i] + c * (bcast[i] ? 1 : HW) + (bcast[i] ? 0 : hw)]
+ *   plain (N, C, HW) tensor:                     rows = N,     sb = C HW, sg = 0, bcast = 0
+ *   (N, C) code repeated over the plane:         rows = N,     sb = C,    sg = 0, bcast = 1
+ *   (N/G, C, HW) tensor repeated for G objects:  rows = N / G, sb = C HW, sg = 0
+ *   label[:, g] of a (B, G, C) tensor, batch n = g B + b (object-major): rows = B, sb = G C, sg = C  (x HW when bcast = 0)
+ * mogan_concat_bwd: dsrc[i] (NULL = not wanted), in the source's own layout, = the sum of ddst over everything that read it
+ * (its channel slice; summed over the plane when bcast; summed over the repeats when rows < N and sg = 0).  nsrc <= MOGAN_CAT_MAX. */
+#define MOGAN_CAT_MAX 4
+int mogan_concat_fwd(const void* const* src, const int* C, const int* rows, const long long* sb, const long long* sg,
+                     const int* bcast, int nsrc, float* dst, int N, int HW, hipStream_t stream);
+int mogan_concat_bwd(const float* ddst, void* const* dsrc, const int* C, const int* rows, const long long* sb,
+                     const long long* sg, const int* bcast, int nsrc, int N, int HW, hipStream_t stream);
 /* bbox (N,4)=(x,y,w,h) -> theta (N,2,3), theta_inv (N,2,3)   (miscc/utils.py:16-49) */
 int mogan_bbox_to_theta(const float* bbox, float* theta, float* theta_inv, int N, hipStream_t stream);
 

@@ -37,6 +37,19 @@ def _objects_first(t, G):
     return t[:, :G].transpose(0, 1)
 
 
+def _stn_objects(x, theta, G, out_hw, plane=False):
+    """stn(x_g, theta[:, g], ...) for every object g as one object-major batch of G*B' samples (model.py:109-111, 402-404, 663-671):
+    x is (G*B', C, H, W) -- one map per (object, image) --, or (B', C, H, W) -- the same image for every object --, or, plane,
+    (G*B', C) -- a label vector the reference repeats over the plane first.  theta (B', G, 2, 3) stays in the loader's layout:
+    the kernel does the object-major lookup, and a shared / constant source is never materialised."""
+    Bp = theta.shape[0]
+    N = G * Bp
+    if theta.shape[1] != G:
+        theta = theta[:, :G].contiguous()
+    in_hw = out_hw if plane else tuple(x.shape[2:])
+    return ops.stn_shared(x, theta, N, in_hw, out_hw, bool(cfg.STN_ALIGN_CORNERS), plane=plane, theta_G=G)
+
+
 def _sum_objects(h, G):
     """(G*B, ...) object-major -> (B, ...): h_0 + h_1 + ... in the loop's order (model.py:113,406,671)"""
     return ops.group_sum(h, G)
@@ -96,9 +109,10 @@ class BBOX_NET(nn.Module):
                 lab = stn(lab, transf_matr_inv[:, idx], (B, self.c_dim, 16, 16))
                 label_layout = lab if label_layout is None else ops.add(label_layout, lab)
             return self.encode(label_layout).view(B, -1)
-        # the reference's loop over the objects (model.py:105-114) as ONE batch of G*B samples, object-major
-        lab = _objects_first(labels, G).reshape(G * B, self.c_dim, 1, 1).expand(G * B, self.c_dim, 16, 16)
-        lab = stn(lab, _objects_first(transf_matr_inv, G).reshape(G * B, 2, 3), (G * B, self.c_dim, 16, 16))
+        # the reference's loop over the objects (model.py:105-114) as ONE batch of G*B samples, object-major; the label vector is
+        # the transformer's constant source (no 16 x 16 copy of it)
+        lab = _objects_first(labels, G).reshape(G * B, self.c_dim)
+        lab = _stn_objects(lab, transf_matr_inv, G, (16, 16), plane=True)
         label_layout = _sum_objects(lab, G)
         return self.encode(label_layout).view(B, -1)
 
@@ -246,16 +260,18 @@ class INIT_STAGE_G(nn.Module):
             return self._forward_looped(z_code, c_code, transf_matrices_inv, label_one_hot)
         # the object loop of model.py:395-407 as ONE batch of G*B samples (object-major); every BatchNorm inside still sees one
         # object's B samples per "call" (groups=G: own statistics, running statistics updated object after object)
-        cc = c_code.unsqueeze(0).expand(G, B, c_code.shape[1]).reshape(G * B, -1)
-        lab = self.label(torch.cat((cc, _objects_first(label_one_hot, G).reshape(G * B, -1)), 1), groups=G)
-        h = lab.view(G * B, self.ef_dim, 1, 1).expand(G * B, self.ef_dim, 4, 4)
+        # (every concat / repeat of the loop body is one ops.cat_channels launch: c_code repeated for the G objects next to
+        # label_one_hot[:, g], the label code repeated over the 4 x 4 plane, ...)
+        onehot = label_one_hot if label_one_hot.shape[1] == G else label_one_hot[:, :G]
+        lab = self.label(ops.cat_channels([(c_code, ("rep", G)), (onehot, ("obj", G))], G * B), groups=G)
+        h = ops.cat_channels([(lab, "plane")], G * B, (4, 4))
         h = self.local2(self.local1(h, groups=G), groups=G)
-        h = stn(h, _objects_first(transf_matrices_inv, G).reshape(G * B, 2, 3), h.shape)
+        h = _stn_objects(h, transf_matrices_inv, G, tuple(h.shape[2:]))
         h_code_locals = _sum_objects(h, G)
         bbox_code = self.bbox_net(lab.view(G, B, self.ef_dim).transpose(0, 1), transf_matrices_inv)
-        out_code = self.fc(torch.cat((c_code, z_code, bbox_code), 1)).view(-1, self.gf_dim, 4, 4)
-        out_code = self.upsample2(self.upsample1(out_code))
-        out_code = torch.cat((out_code, h_code_locals), 1)
+        out_code = self.fc(ops.cat_channels([(c_code, "full"), (z_code, "full"), (bbox_code, "full")], B))
+        out_code = self.upsample2(self.upsample1(out_code.view(-1, self.gf_dim, 4, 4)))
+        out_code = ops.cat_channels([(out_code, "full"), (h_code_locals, "full")], B, tuple(out_code.shape[2:]))
         return self.upsample4(self.upsample3(out_code))
 
     def _forward_looped(self, z_code, c_code, transf_matrices_inv, label_one_hot):
@@ -290,7 +306,8 @@ class NEXT_STAGE_G(nn.Module):
     def forward(self, h_code, c_code, word_embs, mask):
         self.att.applyMask(mask)
         c_code, att = self.att(h_code, word_embs)
-        out_code = self.residual(torch.cat((h_code, c_code), 1))
+        out_code = self.residual(ops.cat_channels([(h_code, "full"), (c_code, "full")], h_code.shape[0],
+                                                  tuple(h_code.shape[2:])))
         return self.upsample(out_code), att
 
 
@@ -372,8 +389,9 @@ class D_GET_LOGITS(nn.Module):
 
     def forward(self, h_code, c_code=None):
         if self.bcondition and c_code is not None:
-            c_code = c_code.view(-1, self.ef_dim, 1, 1).expand(-1, self.ef_dim, 4, 4)
-            h_code = self.jointConv(torch.cat((h_code, c_code), 1))
+            # model.py:632-634: c_code repeated over the 4 x 4 map next to h_code, one launch
+            h_code = self.jointConv(ops.cat_channels([(h_code, "full"), (c_code.reshape(-1, self.ef_dim), "plane")],
+                                                     h_code.shape[0], tuple(h_code.shape[2:])))
         return self.outlogits(h_code).view(-1)
 
 
@@ -415,17 +433,18 @@ class D_NET64(_D_BASE):
                 h_code_locals = h if h_code_locals is None else ops.add(h_code_locals, h)
             return self._trunk(image, h_code_locals)
         # the object loop of model.py:662-672 as ONE batch of G*B samples (object-major), BatchNorm per object (groups=G)
-        lab = _objects_first(label, G).reshape(G * B, 81, 1, 1).expand(G * B, 81, 16, 16)
-        img = image.unsqueeze(0).expand((G,) + tuple(image.shape)).reshape((G * B,) + tuple(image.shape[1:]))
-        h = stn(img, _objects_first(transf_matrices, G).reshape(G * B, 2, 3), (G * B, image.shape[1], 16, 16))
-        h = self.local(torch.cat((h, lab), 1), groups=G)
-        h = stn(h, _objects_first(transf_matrices_inv, G).reshape(G * B, 2, 3), (G * B, h.shape[1], 16, 16))
+        # every object's crop reads the ONE image batch (no G-fold copy); the one-hot label rides into the concat as a code
+        # repeated over the 16 x 16 plane, straight from the loader's (B, G, 81) layout
+        onehot = label if label.shape[1] == G else label[:, :G]
+        h = _stn_objects(image, transf_matrices, G, (16, 16))
+        h = self.local(ops.cat_channels([(h, "full"), (onehot, ("obj_plane", G))], G * B, (16, 16)), groups=G)
+        h = _stn_objects(h, transf_matrices_inv, G, (16, 16))
         return self._trunk(image, _sum_objects(h, G))
 
     def _trunk(self, image, h_code_locals):
         h = ops.act(self.conv1(image), ops.ACT_LRELU, 0.2)
         h = self.bn2.fused(self.conv2(h), ops.ACT_LRELU, 0.2)
-        h = torch.cat((h, h_code_locals), 1)
+        h = ops.cat_channels([(h, "full"), (h_code_locals, "full")], h.shape[0], tuple(h.shape[2:]))
         h = self.bn3.fused(self.conv3(h), ops.ACT_LRELU, 0.2)
         return self.bn4.fused(self.conv4(h), ops.ACT_LRELU, 0.2)
 

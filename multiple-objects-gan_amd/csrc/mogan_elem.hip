@@ -426,6 +426,123 @@ __global__ void adam_prep_kernel(float* __restrict__ state, float lr, float beta
 
 }  // namespace
 
+namespace {
+// ---------------------------------------------------------------------------------------------- channel concat / broadcast
+// dst (N, sum C_i, HW) = the sources side by side along the channel axis; a source is addressed as
+//   value(n, c, hw) = p[(n % rows) * sb + (n / rows) * sg + c * sc + (bcast ? 0 : hw)]
+// which covers: a plain (N, C, HW) tensor (rows = N), a label / code broadcast over the plane (bcast; the reference's
+// .repeat(1, 1, H, W): model.py:109-110, 400, 632-633, 664), one tensor repeated for every object (rows = N / G, sg = 0:
+// c_code / the image in the object loops, model.py:395, 663) and the per-object slice label[:, idx] of a (B, G, C) tensor in the
+// object-major batch of the batched pathways (rows = B, sb = G C, sg = C; model.py:396, 664).
+struct CatSrcP { const float* p; long long sb, sg; int rows, C, bcast, c0; };
+struct CatP { CatSrcP s[MOGAN_CAT_MAX]; int nsrc, N, Ctot, HW; };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void concat_fwd_kernel(CatP P, float* __restrict__ dst, long long nvec) {
+    const int hwv = P.HW / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const int hw = (int)(i % hwv) * VEC;
+        const long long r = i / hwv;
+        const int c = (int)(r % P.Ctot), n = (int)(r / P.Ctot);
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < MOGAN_CAT_MAX; ++q) k += (q < P.nsrc && c >= P.s[q].c0) ? 1 : 0;
+        const CatSrcP S = P.s[k];
+        const float* src = S.p + (long long)(n % S.rows) * S.sb + (long long)(n / S.rows) * S.sg +
+                           (long long)(c - S.c0) * (S.bcast ? 1 : P.HW);
+        float* d = dst + (r * P.HW + hw);
+        if (VEC == 4) {
+            float4 v;
+            if (S.bcast) { const float t = src[0]; v = make_float4(t, t, t, t); }
+            else v = *(const float4*)(src + hw);
+            *(float4*)d = v;
+        } else {
+            d[0] = S.bcast ? src[0] : src[hw];
+        }
+    }
+}
+
+// the gradient: every source receives the sum of the destination gradient over everything that read it -- its channel slice
+// (plain), summed over the plane (bcast), summed over the G repeats (rows < N, sg = 0).  One launch: the first `ncopy` work
+// items are elements of the non-broadcast sources (one thread each), the rest are (row, channel) sums of the broadcast sources
+// (one wave each).  dsrc[i] = NULL: no gradient wanted.
+struct CatGradP { CatP c; float* d[MOGAN_CAT_MAX]; long long ebeg[MOGAN_CAT_MAX + 1]; long long rbeg[MOGAN_CAT_MAX + 1]; };
+
+__global__ __launch_bounds__(256) void concat_bwd_kernel(CatGradP G, const float* __restrict__ ddst, unsigned copy_blocks) {
+    const CatP& P = G.c;
+    if (blockIdx.x < copy_blocks) {
+        const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= G.ebeg[P.nsrc]) return;
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < MOGAN_CAT_MAX; ++q) k += (q < P.nsrc && i >= G.ebeg[q]) ? 1 : 0;
+        const CatSrcP S = P.s[k];
+        const long long e = i - G.ebeg[k];                      // element of the source's own (rows_total, C, HW) layout
+        const int hw = (int)(e % P.HW);
+        const long long rc = e / P.HW;
+        const int c = (int)(rc % S.C);
+        const long long row = rc / S.C;                         // row index in the source's storage order
+        // destination batch indices n that read this row: sg = 0 and rows < N: n = row, row + rows, ...; else exactly one
+        float t = 0.f;
+        if (S.sg == 0) {
+            for (int n = (int)row; n < P.N; n += S.rows) t += ddst[((long long)n * P.Ctot + S.c0 + c) * P.HW + hw];
+        } else {
+            // storage row = (n % rows) * (sb / sg) + n / rows  (object-major batch of a (rows, G, C) tensor)
+            const int Gn = (int)(S.sb / S.sg);
+            const int b = (int)(row / Gn), g = (int)(row % Gn);
+            const int n = g * S.rows + b;
+            t = ddst[((long long)n * P.Ctot + S.c0 + c) * P.HW + hw];
+        }
+        G.d[k][e] = t;
+        return;
+    }
+    const long long item = (long long)(blockIdx.x - copy_blocks) * 4 + (threadIdx.x >> 6);
+    if (item >= G.rbeg[P.nsrc]) return;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < MOGAN_CAT_MAX; ++q) k += (q < P.nsrc && item >= G.rbeg[q]) ? 1 : 0;
+    const CatSrcP S = P.s[k];
+    const long long e = item - G.rbeg[k];
+    const int c = (int)(e % S.C);
+    const long long row = e / S.C;
+    const int lane = threadIdx.x & 63;
+    float t = 0.f;
+    auto plane_sum = [&](int n) {
+        const float* q = ddst + ((long long)n * P.Ctot + S.c0 + c) * P.HW;
+        for (int hw = lane; hw < P.HW; hw += 64) t += q[hw];
+    };
+    if (S.sg == 0) {
+        for (int n = (int)row; n < P.N; n += S.rows) plane_sum(n);
+    } else {
+        const int Gn = (int)(S.sb / S.sg);
+        plane_sum((int)(row % Gn) * S.rows + (int)(row / Gn));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) G.d[k][e] = t;
+}
+
+static int cat_params(CatP& P, const void* const* src, const int* C, const int* rows, const long long* sb, const long long* sg,
+                      const int* bcast, int nsrc, int N, int HW) {
+    if (nsrc <= 0 || nsrc > MOGAN_CAT_MAX || N <= 0 || HW <= 0) return MOGAN_ERR_SHAPE;
+    P.nsrc = nsrc; P.N = N; P.HW = HW;
+    int c0 = 0;
+    for (int i = 0; i < MOGAN_CAT_MAX; ++i) {
+        CatSrcP& S = P.s[i];
+        if (i < nsrc) {
+            if (C[i] <= 0 || rows[i] <= 0 || N % rows[i] != 0) return MOGAN_ERR_SHAPE;
+            S.p = (const float*)src[i]; S.C = C[i]; S.rows = rows[i]; S.sb = sb[i]; S.sg = sg[i]; S.bcast = bcast[i] ? 1 : 0; S.c0 = c0;
+            c0 += C[i];
+        } else {
+            S.p = nullptr; S.C = 0; S.rows = 1; S.sb = 0; S.sg = 0; S.bcast = 0; S.c0 = 0x7fffffff;
+        }
+    }
+    P.Ctot = c0;
+    return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int mogan_abi_version(void) { return 1; }
@@ -570,6 +687,44 @@ int mogan_reparam_bwd(const float* logvar, const float* eps, const float* dc, fl
 int mogan_relu_bwd(const float* z, const float* dz, float* dx, long long n, int accumulate, hipStream_t stream) {
     if (n <= 0) return MOGAN_ERR_SHAPE;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, stream, z, dz, dx, n, accumulate);
+    return ok_launch();
+}
+
+int mogan_concat_fwd(const void* const* src, const int* C, const int* rows, const long long* sb, const long long* sg,
+                     const int* bcast, int nsrc, float* dst, int N, int HW, hipStream_t stream) {
+    CatP P;
+    const int rc = cat_params(P, src, C, rows, sb, sg, bcast, nsrc, N, HW);
+    if (rc) return rc;
+    bool v4 = (HW % 4) == 0 && (((uintptr_t)dst) & 15) == 0;
+    for (int i = 0; i < nsrc && v4; ++i)
+        if (!P.s[i].bcast && ((((uintptr_t)P.s[i].p) & 15) != 0 || (P.s[i].sb % 4) != 0 || (P.s[i].sg % 4) != 0)) v4 = false;
+    const long long n = (long long)N * P.Ctot * HW;
+    if (v4) hipLaunchKernelGGL((concat_fwd_kernel<4>), dim3(nblk(n / 4)), dim3(256), 0, stream, P, dst, n / 4);
+    else hipLaunchKernelGGL((concat_fwd_kernel<1>), dim3(nblk(n)), dim3(256), 0, stream, P, dst, n);
+    return ok_launch();
+}
+
+int mogan_concat_bwd(const float* ddst, void* const* dsrc, const int* C, const int* rows, const long long* sb, const long long* sg,
+                     const int* bcast, int nsrc, int N, int HW, hipStream_t stream) {
+    CatGradP G;
+    const int rc = cat_params(G.c, (const void* const*)dsrc, C, rows, sb, sg, bcast, nsrc, N, HW);
+    if (rc) return rc;
+    long long ne = 0, nr = 0;
+    for (int i = 0; i <= MOGAN_CAT_MAX; ++i) { G.ebeg[i] = 0; G.rbeg[i] = 0; }
+    for (int i = 0; i < MOGAN_CAT_MAX; ++i) {
+        G.d[i] = i < nsrc ? (float*)dsrc[i] : nullptr;
+        const CatSrcP& S = G.c.s[i];
+        // rows of the source's own storage: `rows` when it is repeated (sg = 0), N when every batch index has its own row
+        const long long own = i < nsrc && G.d[i] ? (S.sg == 0 ? S.rows : N) : 0;
+        G.ebeg[i] = ne; G.rbeg[i] = nr;
+        if (i < nsrc && G.d[i]) { if (S.bcast) nr += own * S.C; else ne += own * S.C * HW; }
+    }
+    for (int i = nsrc; i <= MOGAN_CAT_MAX; ++i) { G.ebeg[i] = ne; G.rbeg[i] = nr; }
+    // a source without gradient has an empty range: the `i >= beg[q]` search must skip it -> give it the next begin
+    if (ne + nr == 0) return 0;
+    if (ne >= (1ll << 40)) return MOGAN_ERR_SHAPE;
+    const unsigned cb = (unsigned)((ne + 255) / 256), rb = (unsigned)((nr + 3) / 4);
+    hipLaunchKernelGGL(concat_bwd_kernel, dim3(cb + rb), dim3(256), 0, stream, G, ddst, cb);
     return ok_launch();
 }
 

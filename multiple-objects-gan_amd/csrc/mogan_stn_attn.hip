@@ -56,6 +56,79 @@ __device__ __forceinline__ Taps stn_taps(const float* __restrict__ th, int oy, i
     return t;
 }
 
+// shared / constant sources (mogan_stn_*_ex): output sample b reads image b % xB; PLANE: x is (xB, C), constant over the plane
+template <bool PLANE>
+__global__ __launch_bounds__(256) void stn_fwd_ex_kernel(const float* __restrict__ x, const float* __restrict__ theta,
+                                                         float* __restrict__ y, int C, int Hin, int Win, int Hout,
+                                                         int Wout, int ac, int cchunk, int xB, int tG) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Hout * Wout) return;
+    const int b = blockIdx.z, bx = b % xB, c0 = blockIdx.y * cchunk, c1 = min(C, c0 + cchunk);
+    const int oy = pix / Wout, ox = pix - oy * Wout;
+    // tG > 0: theta is stored (B', tG, 2, 3) and sample b = g B' + b' (object-major batch) uses theta[b'][g]
+    const int nb = tG > 0 ? (int)gridDim.z / tG : 1;
+    const int tb = tG > 0 ? (b % nb) * tG + b / nb : b;
+    const Taps t = stn_taps(theta + tb * 6, oy, ox, Hin, Win, Hout, Wout, ac);
+    const float w00 = (1.f - t.wx1) * (1.f - t.wy1), w01 = t.wx1 * (1.f - t.wy1);
+    const float w10 = (1.f - t.wx1) * t.wy1, w11 = t.wx1 * t.wy1;
+    const bool v00 = t.vx0 && t.vy0, v01 = t.vx1 && t.vy0, v10 = t.vx0 && t.vy1, v11 = t.vx1 && t.vy1;
+    const int o00 = t.y0 * Win + t.x0;
+    for (int c = c0; c < c1; ++c) {
+        float acc = 0.f;
+        if (PLANE) {                       // the same four products in the same order as on the materialised plane
+            const float v = x[(size_t)bx * C + c];
+            if (v00) acc += v * w00;
+            if (v01) acc += v * w01;
+            if (v10) acc += v * w10;
+            if (v11) acc += v * w11;
+        } else {
+            const float* px = x + ((size_t)bx * C + c) * Hin * Win;
+            if (v00) acc += px[o00] * w00;
+            if (v01) acc += px[o00 + 1] * w01;
+            if (v10) acc += px[o00 + Win] * w10;
+            if (v11) acc += px[o00 + Win + 1] * w11;
+        }
+        y[((size_t)b * C + c) * Hout * Wout + pix] = acc;
+    }
+}
+
+template <bool PLANE>
+__global__ __launch_bounds__(256) void stn_bwd_ex_kernel(const float* __restrict__ dy, const float* __restrict__ theta,
+                                                         float* __restrict__ dx, int C, int Hin, int Win, int Hout,
+                                                         int Wout, int ac, int cchunk, int xB, int tG) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const bool in = pix < Hout * Wout;
+    const int b = blockIdx.z, bx = b % xB, c0 = blockIdx.y * cchunk, c1 = min(C, c0 + cchunk);
+    const int oy = in ? pix / Wout : 0, ox = in ? pix - oy * Wout : 0;
+    const int nb = tG > 0 ? (int)gridDim.z / tG : 1;
+    const int tb = tG > 0 ? (b % nb) * tG + b / nb : b;
+    const Taps t = stn_taps(theta + tb * 6, oy, ox, Hin, Win, Hout, Wout, ac);
+    const float w00 = (1.f - t.wx1) * (1.f - t.wy1), w01 = t.wx1 * (1.f - t.wy1);
+    const float w10 = (1.f - t.wx1) * t.wy1, w11 = t.wx1 * t.wy1;
+    const bool v00 = in && t.vx0 && t.vy0, v01 = in && t.vx1 && t.vy0, v10 = in && t.vx0 && t.vy1, v11 = in && t.vx1 && t.vy1;
+    const int o00 = t.y0 * Win + t.x0;
+    if (PLANE) {
+        // d x[b, c] = sum over the output pixels of dy * (sum of the in-range tap weights): per wave a butterfly, one atomic
+        const float wsum = (v00 ? w00 : 0.f) + (v01 ? w01 : 0.f) + (v10 ? w10 : 0.f) + (v11 ? w11 : 0.f);
+        for (int c = c0; c < c1; ++c) {
+            float g = in ? dy[((size_t)b * C + c) * Hout * Wout + pix] * wsum : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+            if ((threadIdx.x & 63) == 0 && g != 0.f) atomicAdd(dx + (size_t)bx * C + c, g);
+        }
+        return;
+    }
+    if (!(v00 || v01 || v10 || v11)) return;
+    for (int c = c0; c < c1; ++c) {
+        float* px = dx + ((size_t)bx * C + c) * Hin * Win;
+        const float g = dy[((size_t)b * C + c) * Hout * Wout + pix];
+        if (v00) atomicAdd(px + o00, g * w00);
+        if (v01) atomicAdd(px + o00 + 1, g * w01);
+        if (v10) atomicAdd(px + o00 + Win, g * w10);
+        if (v11) atomicAdd(px + o00 + Win + 1, g * w11);
+    }
+}
+
 __global__ __launch_bounds__(256) void stn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ theta,
                                                       float* __restrict__ y, int C, int Hin, int Win, int Hout,
                                                       int Wout, int ac, int cchunk) {
@@ -222,6 +295,37 @@ int mogan_stn_bwd(const float* dy, const float* theta, float* dx, int B, int C, 
     const int cchunk = (C + csplit - 1) / csplit; csplit = (C + cchunk - 1) / cchunk;
     hipLaunchKernelGGL(stn_bwd_kernel, dim3(pb, csplit, B), dim3(256), 0, stream, dy, theta, dx, C, Hin, Win, Hout, Wout,
                        align_corners, cchunk);
+    return ok_launch();
+}
+
+int mogan_stn_fwd_ex(const float* x, const float* theta, float* y, int B, int C, int Hin, int Win, int Hout, int Wout,
+                     int align_corners, int xB, int x_plane, int theta_G, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || B > 65535 || xB <= 0 || B % xB != 0 ||
+        theta_G < 0 || (theta_G > 0 && B % theta_G != 0))
+        return MOGAN_ERR_SHAPE;
+    const int pb = (Hout * Wout + 255) / 256;
+    int csplit = (1024 + pb * B - 1) / (pb * B); if (csplit > C) csplit = C; if (csplit < 1) csplit = 1;
+    const int cchunk = (C + csplit - 1) / csplit; csplit = (C + cchunk - 1) / cchunk;
+    if (x_plane) hipLaunchKernelGGL((stn_fwd_ex_kernel<true>), dim3(pb, csplit, B), dim3(256), 0, stream, x, theta, y, C, Hin, Win,
+                                    Hout, Wout, align_corners, cchunk, xB, theta_G);
+    else hipLaunchKernelGGL((stn_fwd_ex_kernel<false>), dim3(pb, csplit, B), dim3(256), 0, stream, x, theta, y, C, Hin, Win,
+                            Hout, Wout, align_corners, cchunk, xB, theta_G);
+    return ok_launch();
+}
+
+int mogan_stn_bwd_ex(const float* dy, const float* theta, float* dx, int B, int C, int Hin, int Win, int Hout, int Wout,
+                     int align_corners, int xB, int x_plane, int theta_G, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || B > 65535 || xB <= 0 || B % xB != 0 ||
+        theta_G < 0 || (theta_G > 0 && B % theta_G != 0))
+        return MOGAN_ERR_SHAPE;
+    zero_fill(dx, (size_t)xB * C * (x_plane ? 1 : (size_t)Hin * Win), stream);
+    const int pb = (Hout * Wout + 255) / 256;
+    int csplit = (1024 + pb * B - 1) / (pb * B); if (csplit > C) csplit = C; if (csplit < 1) csplit = 1;
+    const int cchunk = (C + csplit - 1) / csplit; csplit = (C + cchunk - 1) / cchunk;
+    if (x_plane) hipLaunchKernelGGL((stn_bwd_ex_kernel<true>), dim3(pb, csplit, B), dim3(256), 0, stream, dy, theta, dx, C, Hin, Win,
+                                    Hout, Wout, align_corners, cchunk, xB, theta_G);
+    else hipLaunchKernelGGL((stn_bwd_ex_kernel<false>), dim3(pb, csplit, B), dim3(256), 0, stream, dy, theta, dx, C, Hin, Win,
+                            Hout, Wout, align_corners, cchunk, xB, theta_G);
     return ok_launch();
 }
 

@@ -356,6 +356,264 @@ __global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__
     }
 }
 
+#if MOGAN_X6
+// ------------------------------------------------------------------------------------------ round 4: forward, third form
+// Same tiling (96 output channels x 32 tiles per block, wave w owns positions 2w, 2w+1, 2 x 3 accumulator tiles), new K loop:
+//  * a K-step is 16 input channels = the k-extent of ONE v_mfma_f32_32x32x16_bf16 group (lane (h, l31) holds channels
+//    8h .. 8h+7), so every step issues its 36 MFMAs -- the earlier form alternated a staging-only step with an MFMA step;
+//  * the transformed filters arrive PRE-SPLIT into their three bf16 pieces in lane order (wino3_weight_kernel), 18 16-byte
+//    loads per lane and step straight into the MFMA operand registers: no split arithmetic on the A side (it was 3/4 of
+//    the kernel's split VALU work), and the weights are split once per (co, ci, position), not once per tile;
+//  * one barrier per step; the MFMAs of step p run beside: halo X(p+2) registers -> LDS, halo loads of X(p+3), the input
+//    transform X(p+1) -> V(p+1), and the filter loads of step p+1 (position j's registers are reloaded as soon as its MFMAs
+//    have been issued).
+// U3[mb][wave][step][j][a][piece][lane] x 16 bytes.
+constexpr int CK2 = 16, XSZ2 = CK2 * XR * XCP, VSZ2 = 16 * CK2 * NT;
+
+__global__ __launch_bounds__(256) void wino3_weight_kernel(const float* __restrict__ w, uint4* __restrict__ U3, int Cout,
+                                                           int Cin, int flip, long long nfrag) {
+    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= nfrag) return;
+    const int Kin = flip ? Cout : Cin, Kout = flip ? Cin : Cout;
+    const int nstep = Kin / CK2;
+    const int lane = (int)(gidx & 63); long long rr = gidx >> 6;
+    const int a3 = (int)(rr % 3); rr /= 3;
+    const int j = (int)(rr & 1); rr >>= 1;
+    const int step = (int)(rr % nstep); rr /= nstep;
+    const int wv = (int)(rr & 7); const int mb = (int)(rr >> 3);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int xi = 2 * wv + j, r = xi >> 2, q = xi & 3;
+    const int kout = mb * BM + a3 * 32 + l31;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    float u8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kin = step * CK2 + 8 * h + e;
+        float u = 0.f;
+        if (kout < Kout) {
+            const int co = flip ? kin : kout, ci = flip ? kout : kin;
+            const float* g = w + ((size_t)co * Cin + ci) * 9;
+            float t[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float tt = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) tt += G[r][a] * (flip ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b]);
+                t[b] = tt;
+            }
+            u = G[q][0] * t[0] + G[q][1] * t[1] + G[q][2] * t[2];
+        }
+        u8[e] = u;
+    }
+    const X6Frag f = x6_split8(u8);
+    const size_t base = ((((size_t)(mb * 8 + wv) * nstep + step) * 2 + j) * 3 + a3) * 3 * 64 + lane;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) U3[base + (size_t)pc * 64] = __builtin_bit_cast(uint4, f.p[pc]);
+}
+
+__global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict__ X, const uint4* __restrict__ U3,
+                                                        float* __restrict__ Y, int Cin, int H, int W, int Cout, int OH, int OW,
+                                                        int pad, int tiles_x, int tiles_y, int ntile, int nimg,
+                                                        const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
+                                                        int ep_relu, unsigned x_bytes, unsigned u_bytes) {
+    constexpr int VT = 8 * BM * NT > 2 * VSZ2 ? 8 * BM * NT : 2 * VSZ2;
+    __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ2];
+    __shared__ __attribute__((aligned(16))) float VTs[VT];              // V of the K loop; the epilogue's exchange buffer
+    float* const Vs = VTs;
+    float* const Ts = VTs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int plane = H * W;
+    const int nstep = Cin / CK2;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U3, (short)0, (int)u_bytes, 0x00020000);
+
+    // halo staging role: position (row, column) sr of the 6 x 34 halo, channels 2i + sg of a step (i < 8)
+    const int sg = tid >> 8, sr = tid & 255;
+    const bool sact = sr < XR * XC;
+    const int shy = sr / XC, shx = sr - shy * XC;
+    // (the 2 x 52 idle lanes of this role store their zeros into the two pad columns of the rows, which nobody reads:
+    // unconditional stores keep the K loop one basic block)
+    const int xl0 = sact ? sg * (XR * XCP) + shy * XCP + shx : sg * (XR * XCP) + (sr % XR) * XCP + XC + ((sr / XR) & 1);
+    // transform role: rows 2th, 2th+1 of V = B^t d B for tile tt of channels tc and tc + 8
+    const int th = tid >> 8, tc = (tid >> 5) & 7, tt = tid & 31, tty = tt >> 4, ttx = tt & 15;
+    const int tx0 = tc * (XR * XCP) + (2 * tty + th) * XCP + 2 * ttx;
+    const int tv0 = ((2 * th) * 4 * CK2 + tc) * NT + tt;
+    const int bv0 = (wave * 2 * CK2 + 8 * h) * NT + l31;
+
+    // filter loads: per-lane offset (lane x 16 bytes) in the VGPR, everything else -- (mb, wave, step, fragment) -- is uniform
+    // and rides in the scalar offset of the buffer instruction (no vector address arithmetic in the K loop)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned ulane = (unsigned)lane * 16u;
+    unsigned xg, ubase; int m0, img, oy0, ox0;
+    auto plan = [&](int tile, unsigned& g, unsigned& ub, int& m0_, int& img_, int& oy_, int& ox_) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y; t /= tiles_y;
+        img_ = t % nimg; const int mb = t / nimg;
+        m0_ = mb * BM; oy_ = ty * 2 * TROWS; ox_ = tx * 2 * TCOLS;
+        const int iy = oy_ + shy - pad, ix = ox_ + shx - pad;
+        const bool ok = sact && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        g = ok ? (unsigned)(img_ * Cin + sg) * plane + (unsigned)(iy * W + ix) : 0x30000000u;     // reads 0
+        ub = (unsigned)((mb * 8 + wave_s) * nstep) * (18u * 1024u);
+    };
+    float rx[8], rx1[8];
+    auto load_x = [&](float (&r)[8], unsigned g, int c0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = ldgx(rX, g + (unsigned)(c0 + 2 * i) * plane, true);
+    };
+    auto store_x = [&](const float (&r)[8], float* Xd) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Xd[xl0 + 2 * i * (XR * XCP)] = r[i];
+    };
+    X6Frag fa[2][3];
+    auto load_a = [&](int j, unsigned ub, int step) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                fa[j][a].p[pc] = __builtin_bit_cast(mma_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    rU, ulane, ub + (unsigned)(((step * 2 + j) * 3 + a) * 3 + pc) * 1024u, 0));
+    };
+    auto transform = [&](const float* Xc, float* Vd, int c8) {          // channel tc + c8
+        float ra[4], rb[4], rc[4];
+        const float* px = &Xc[tx0 + c8 * (XR * XCP)];
+        {
+            const float2 a0 = *(const float2*)px, a1 = *(const float2*)(px + 2);
+            const float2 b0 = *(const float2*)(px + XCP), b1 = *(const float2*)(px + XCP + 2);
+            const float2 c0 = *(const float2*)(px + 2 * XCP), c1 = *(const float2*)(px + 2 * XCP + 2);
+            ra[0] = a0.x; ra[1] = a0.y; ra[2] = a1.x; ra[3] = a1.y;
+            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
+            rc[0] = c0.x; rc[1] = c0.y; rc[2] = c1.x; rc[3] = c1.y;
+        }
+        float u[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t1 = ra[j] - rc[j], t2 = rb[j] - ra[j], t3 = rb[j] + rc[j];
+            u[0][j] = th ? t2 : t1;
+            u[1][j] = th ? t1 : t3;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* pv = &Vd[tv0 + (i * 4 * CK2 + c8) * NT];
+            pv[0] = u[i][0] - u[i][2];
+            pv[CK2 * NT] = u[i][1] + u[i][2];
+            pv[2 * CK2 * NT] = u[i][2] - u[i][1];
+            pv[3 * CK2 * NT] = u[i][1] - u[i][3];
+        }
+    };
+
+    f32x16 acc[2][3];
+    auto mma_j = [&](int j, const float* Vc) {
+        float b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = Vc[bv0 + (j * CK2 + e) * NT];
+        const X6Frag fb = x6_split8(b8);
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[j][a] = x6_mfma(fa[j][a], fb, term, acc[j][a]);
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntile) {
+        plan(tile, xg, ubase, m0, img, oy0, ox0);
+        load_x(rx, xg, 0); load_x(rx1, xg, CK2); load_a(0, ubase, 0); load_a(1, ubase, 0);
+    }
+    for (; tile < ntile; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][a][r] = 0.f;
+        store_x(rx, Xs);
+        store_x(rx1, Xs + XSZ2);
+        load_x(rx, xg, 2 * CK2);
+        __syncthreads();                                    // (also: every thread is done with the previous tile's Ts)
+        transform(Xs, Vs, 0);
+        transform(Xs, Vs, 8);
+        __syncthreads();
+        for (int p = 0; p < nstep; ++p) {
+            const int cur = p & 1;
+            const float* Vc = Vs + cur * VSZ2;
+            float* Vn = Vs + (cur ^ 1) * VSZ2;
+            const float* Xn = Xs + (cur ^ 1) * XSZ2;
+            mma_j(0, Vc);
+            load_a(0, ubase, p + 1);
+            store_x(rx, Xs + cur * XSZ2);                   // X(p+2)
+            load_x(rx, xg, (p + 3) * CK2);
+            transform(Xn, Vn, 0);                           // X(p+1) -> V(p+1)
+            mma_j(1, Vc);
+            load_a(1, ubase, p + 1);
+            transform(Xn, Vn, 8);
+            __syncthreads();
+        }
+        const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
+        const bool more = tile + (int)gridDim.x < ntile;
+        if (more) {
+            plan(tile + gridDim.x, xg, ubase, m0, img, oy0, ox0);
+            load_x(rx, xg, 0); load_x(rx1, xg, CK2);
+        }
+        // ---- output transform (as in wino_fwd_kernel): row i = wave>>1 of M, T_i[b] = sum_j M[i][j] A[j][b] split over the
+        // wave pair; Y[a][b] = sum_i A^t[a][i] T_i[b] through Ts, one pass per output column parity b
+        float yreg[6][2][2];
+        const int wj = wave & 1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b) __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = wj == 0 ? (b == 0 ? acc[0][a][r] + acc[1][a][r] : acc[1][a][r])
+                                            : (b == 0 ? acc[0][a][r] : -acc[0][a][r] - acc[1][a][r]);
+                    Ts[(wave * BM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * NT + l31] = p;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int idx = tid + 512 * q;
+                float tq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tq[i] = Ts[(2 * i) * BM * NT + idx] + Ts[(2 * i + 1) * BM * NT + idx];
+                yreg[q][0][b] = tq[0] + tq[1] + tq[2];
+                yreg[q][1][b] = tq[1] - tq[2] - tq[3];
+            }
+        }
+        if (more) { load_a(0, ubase, 0); load_a(1, ubase, 0); }         // (the accumulators are free now)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int idx = tid + 512 * q;
+            const int m = idx >> 5, tl = idx & 31;
+            const int oy = coy0 + 2 * (tl >> 4), ox = cox0 + 2 * (tl & 15);
+            if (cm0 + m < Cout && oy < OH && ox < OW) {
+                float v[2][2] = {{yreg[q][0][0], yreg[q][0][1]}, {yreg[q][1][0], yreg[q][1][1]}};
+                if (ep_scale != nullptr) {
+                    const float sc = ep_scale[cm0 + m], sh = ep_shift[cm0 + m];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            v[a][b] = fmaf(v[a][b], sc, sh);
+                            if (ep_relu) v[a][b] = fmaxf(v[a][b], 0.f);
+                        }
+                }
+                float* o = Y + ((size_t)(cimg * Cout + cm0 + m) * OH + oy) * OW + ox;
+                const bool y1 = oy + 1 < OH;
+                if ((OW & 1) == 0) {
+                    *(float2*)o = make_float2(v[0][0], v[0][1]);
+                    if (y1) *(float2*)(o + OW) = make_float2(v[1][0], v[1][1]);
+                } else {
+                    const bool x1 = ox + 1 < OW;
+                    o[0] = v[0][0]; if (x1) o[1] = v[0][1];
+                    if (y1) { o[OW] = v[1][0]; if (x1) o[OW + 1] = v[1][1]; }
+                }
+            }
+        }
+    }
+}
+#endif  // MOGAN_X6
+
 // ------------------------------------------------------------------------------------------ weight gradient
 // dW = G^t [ sum over tiles (A dY A^t) .* (B^t d B) ] G: per position xi a GEMM dU_xi[co][ci] = sum_tiles Q_xi[co][tile]
 // V_xi[ci][tile] with the tiles on K.  A block owns 96 co x 32 ci for all 16 positions (wave w: xi = 2w, 2w+1; 2 x 3
@@ -665,11 +923,6 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
         (long long)B * Kout * oH * oW >= (1ll << 30) || ubytes >= (1ull << 31))
         return 0;
     if (!ws || ws_bytes < ubytes) return 0;
-    float* U = (float*)ws;
-    const long long n = (long long)Cout * Cin;
-    const long long ngroups = mbs * 8 * (Kin / CK) * 6 * 64;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad,
-                       ngroups);
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
@@ -680,6 +933,25 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     if (ntile >= (1ll << 30)) return 0;
     // persistent: one 8-wave block per CU walks the tiles
     dim3 grid((unsigned)std::min<long long>(ntile, ncu));
+#if MOGAN_X6
+    // round 4: pre-split filter planes + one 16-channel K-step per barrier (MOGAN_WINO_V=2: the round-2 kernel, A/B)
+    static const int wino_v = getenv("MOGAN_WINO_V") ? atoi(getenv("MOGAN_WINO_V")) : 3;
+    // (+ one step of padding: the K loop's last iteration prefetches step nstep, whose scalar offset must stay inside the buffer)
+    const size_t u3bytes = (size_t)mbs * 8 * (Kin / CK2) * 18 * 1024 + 18 * 1024;
+    if (wino_v == 3 && u3bytes <= ws_bytes && u3bytes < (1ull << 31)) {
+        const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
+        hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, Cout, Cin,
+                           dgrad, nfrag);
+        hipLaunchKernelGGL(wino3_fwd_kernel, grid, dim3(512), 0, st, in, (const uint4*)ws, out, Kin, iH, iW, Kout, oH, oW, pad,
+                           tiles_x, tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu, (unsigned)(4ull * B * Kin * iH * iW),
+                           (unsigned)u3bytes);
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+    }
+#endif
+    float* U = (float*)ws;
+    const long long ngroups = mbs * 8 * (Kin / CK) * 6 * 64;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad,
+                       ngroups);
     hipLaunchKernelGGL(wino_fwd_kernel, grid, dim3(512), 0, st, in, (const float*)U, out, Kin, iH, iW, Kout, oH, oW, pad,
                        tiles_x, tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu, (unsigned)(4ull * B * Kin * iH * iW),
                        (unsigned)ubytes);

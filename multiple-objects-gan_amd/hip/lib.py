@@ -77,6 +77,10 @@ SIGNATURES = {
     "mogan_softmax_bwd": [P, P, P, P, L, I, L, F, P],
     "mogan_stn_fwd": [P, P, P, I, I, I, I, I, I, I, P],
     "mogan_stn_bwd": [P, P, P, I, I, I, I, I, I, I, P],
+    "mogan_stn_fwd_ex": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "mogan_stn_bwd_ex": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "mogan_concat_fwd": [P, P, P, P, P, P, I, P, I, I, P],
+    "mogan_concat_bwd": [P, P, P, P, P, P, P, I, I, I, P],
     "mogan_bbox_to_theta": [P, P, P, I, P],
     "mogan_attn_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "mogan_attn_bwd": [P, P, P, P, P, P, I, I, I, I, P],

@@ -944,6 +944,118 @@ def stn(x, theta, size, align_corners=False):
     return STNFn.apply(x, theta, int(size[2]), int(size[3]), 1 if align_corners else 0)
 
 
+class STNSharedFn(torch.autograd.Function):
+    """stn() whose source is shared between the objects or constant over the plane, without the materialised copies
+    (include/mogan_hip.h: mogan_stn_*_ex): x (xB, C, Hin, Win) read by sample b as image b % xB, or -- plane -- x (xB, C), the
+    label vector the reference repeats over Hin x Win first (model.py:109-111, 663-665).  theta (B', G, 2, 3) in the loader's
+    order when theta_G = G (samples are object-major), else (N, 2, 3)."""
+
+    @staticmethod
+    def forward(ctx, x, theta, N, Hin, Win, Hout, Wout, align_corners, plane, theta_G):
+        x, theta = _c(x), _c(theta)
+        xB, C = x.shape[0], x.shape[1]
+        y = torch.empty((N, C, Hout, Wout), dtype=torch.float32, device=x.device)
+        call("mogan_stn_fwd_ex", ptr(x), ptr(theta), ptr(y), N, C, Hin, Win, Hout, Wout, align_corners, xB, plane, theta_G,
+             stream_ptr())
+        ctx.save_for_backward(theta)
+        ctx.cfg = (N, C, Hin, Win, Hout, Wout, align_corners, xB, plane, theta_G, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (theta,) = ctx.saved_tensors
+        N, C, Hin, Win, Hout, Wout, ac, xB, plane, theta_G, xshape = ctx.cfg
+        dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+        call("mogan_stn_bwd_ex", ptr(_c(dy)), ptr(theta), ptr(dx), N, C, Hin, Win, Hout, Wout, ac, xB, plane, theta_G,
+             stream_ptr())
+        return (dx,) + (None,) * 9
+
+
+def stn_shared(x, theta, N, in_hw, out_hw, align_corners=False, plane=False, theta_G=0):
+    return STNSharedFn.apply(x, theta, int(N), int(in_hw[0]), int(in_hw[1]), int(out_hw[0]), int(out_hw[1]),
+                             1 if align_corners else 0, 1 if plane else 0, int(theta_G))
+
+
+# ------------------------------------------------------------------------------- channel concat with broadcast sources
+class CatFn(torch.autograd.Function):
+    """torch.cat(parts, 1) where a part may be a code repeated over the plane, one tensor repeated for every object, or the
+    per-object slices of a (B, G, C) tensor in the object-major batch -- one launch each way (mogan_concat_fwd / _bwd; model.py:
+    400-401, 418, 457, 633-634, 666, 703).  meta[i] = (C, rows, sb, sg, bcast) of part i."""
+
+    @staticmethod
+    def forward(ctx, meta, N, spatial, *parts):
+        import ctypes
+        parts = [_c(t) for t in parts]
+        n = len(parts)
+        HW = 1
+        for d in spatial:
+            HW *= d
+        Ctot = sum(m[0] for m in meta)
+        dst = torch.empty((N, Ctot) + tuple(spatial), dtype=torch.float32, device=parts[0].device)
+        arrs = _cat_arrays(meta, [t.data_ptr() for t in parts])
+        call("mogan_concat_fwd", *arrs, n, ptr(dst), N, HW, stream_ptr())
+        ctx.cfg = (meta, N, HW, [tuple(t.shape) for t in parts])
+        return dst
+
+    @staticmethod
+    def backward(ctx, ddst):
+        meta, N, HW, shapes = ctx.cfg
+        ddst = _c(ddst)
+        grads = [torch.empty(shp, dtype=torch.float32, device=ddst.device) if ctx.needs_input_grad[3 + i] else None
+                 for i, shp in enumerate(shapes)]
+        if any(g is not None for g in grads):
+            arrs = _cat_arrays(meta, [g.data_ptr() if g is not None else None for g in grads])
+            call("mogan_concat_bwd", ptr(ddst), *arrs, len(shapes), N, HW, stream_ptr())
+        return (None, None, None) + tuple(grads)
+
+
+def _cat_arrays(meta, pointers):
+    import ctypes
+    n = len(meta)
+    pp = (ctypes.c_void_p * n)(*pointers)
+    cc = (ctypes.c_int * n)(*[m[0] for m in meta])
+    rr = (ctypes.c_int * n)(*[m[1] for m in meta])
+    sb = (ctypes.c_longlong * n)(*[m[2] for m in meta])
+    sg = (ctypes.c_longlong * n)(*[m[3] for m in meta])
+    bc = (ctypes.c_int * n)(*[m[4] for m in meta])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    return cast(pp), cast(cc), cast(rr), cast(sb), cast(sg), cast(bc)
+
+
+def cat_channels(parts, N, spatial=()):
+    """parts: list of (tensor, mode); mode = "full" (N, C, *spatial) | "plane" (N, C) | ("rep", G) (N/G, C, *spatial) repeated for
+    G objects | ("rep_plane", G) (N/G, C) | ("obj", G) (B, G, C, *spatial), batch n = g B + b | ("obj_plane", G) (B, G, C).
+    Returns the (N, sum C, *spatial) concatenation."""
+    HW = 1
+    for d in spatial:
+        HW *= int(d)
+    meta, ts = [], []
+    for t, mode in parts:
+        kind, G = (mode, 1) if isinstance(mode, str) else mode
+        if kind == "full":
+            C = t.shape[1]; m = (C, N, C * HW, 0, 0)
+        elif kind == "plane":
+            C = t.shape[1]; m = (C, N, C, 0, 1)
+        elif kind == "rep":
+            C = t.shape[1]; m = (C, N // G, C * HW, 0, 0)
+        elif kind == "rep_plane":
+            C = t.shape[1]; m = (C, N // G, C, 0, 1)
+        elif kind == "obj":
+            C = t.shape[2]; m = (C, N // G, G * C * HW, C * HW, 0)
+        elif kind == "obj_plane":
+            C = t.shape[2]; m = (C, N // G, G * C, C, 1)
+        else:
+            raise ValueError(mode)
+        want = {"full": N, "plane": N, "rep": N // G, "rep_plane": N // G, "obj": N // G, "obj_plane": N // G}[kind]
+        if t.shape[0] != want or (kind.startswith("obj") and t.shape[1] != G):
+            raise lib.MoganHipError("cat_channels: part of shape %r does not fit mode %r at N = %d" % (tuple(t.shape), mode, N))
+        meta.append(m)
+        ts.append(t)
+    if len(ts) > 4:
+        raise lib.MoganHipError("cat_channels: at most 4 parts")
+    return CatFn.apply(tuple(meta), int(N), tuple(int(d) for d in spatial), *ts)
+
+
 def bbox_to_theta(bbox):
     bbox = _c(bbox).view(-1, 4)
     n = bbox.shape[0]

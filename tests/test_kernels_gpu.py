@@ -347,6 +347,86 @@ def test_stn(ac):
         assert float(y[1].detach().abs().max()) == 0.0 or theta is rot    # absent object -> exactly 0
 
 
+@pytest.mark.parametrize("ac", [False, True])
+def test_stn_shared_and_constant_sources(ac):
+    """mogan_stn_*_ex: the object pathways' transformers without their materialised inputs (model.py:109-111, 402-404, 663-671)
+    -- one image batch read by every object (x index b % xB, gradients of all objects collected in the one dx), a label vector
+    constant over the plane (dx = (B, C)), theta in the loader's (image, object) layout for an object-major batch -- against the
+    plain transformer on the materialised tensors, forward and backward, in fp64."""
+    Bp, G, C = 4, 3, 5
+    bbox = torch.rand(Bp * G, 4, generator=torch.Generator().manual_seed(5)) * 0.5 + 0.05
+    bbox[4] = -1.0                                                       # an absent object
+    th, thi = (t.view(Bp, G, 2, 3) for t in __import__("mogan_amd.attngan.synthetic", fromlist=["x"]).bbox_to_theta(bbox))
+    objmajor = lambda t: t.transpose(0, 1).reshape(G * Bp, 2, 3)         # sample n = g * Bp + b
+    # (a) shared image, crop to 16 x 16
+    x = T("stnsh.x", (Bp, C, 20, 24)).requires_grad_(True)
+    ref = O.stn(x.double().repeat(G, 1, 1, 1), objmajor(th).double(), (G * Bp, C, 16, 16), align_corners=ac)
+    g = T("stnsh.g", ref.shape)
+    ref.backward(g.double())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.stn_shared(xd, th.to(DEV), G * Bp, (20, 24), (16, 16), ac, theta_G=G)
+    y.backward(g.to(DEV))
+    _check(y, ref, 1e-5, "shared y"); _check(xd.grad, x.grad, 1e-5, "shared dx")
+    # (b) one map per (object, image), theta looked up object-major
+    x = T("stnsh.x2", (G * Bp, C, 15, 15)).requires_grad_(True)
+    ref = O.stn(x.double(), objmajor(thi).double(), (G * Bp, C, 16, 16), align_corners=ac)
+    ref.backward(g.double())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.stn_shared(xd, thi.to(DEV), G * Bp, (15, 15), (16, 16), ac, theta_G=G)
+    y.backward(g.to(DEV))
+    _check(y, ref, 1e-5, "per-object y"); _check(xd.grad, x.grad, 1e-5, "per-object dx")
+    # (c) constant source: a (G*Bp, C) label vector standing for its 16 x 16 repetition
+    v = T("stnsh.v", (G * Bp, C)).requires_grad_(True)
+    ref = O.stn(v.double().view(G * Bp, C, 1, 1).repeat(1, 1, 16, 16), objmajor(thi).double(), (G * Bp, C, 16, 16),
+                align_corners=ac)
+    ref.backward(g.double())
+    vd = v.detach().to(DEV).requires_grad_(True)
+    y = ops.stn_shared(vd, thi.to(DEV), G * Bp, (16, 16), (16, 16), ac, plane=True, theta_G=G)
+    y.backward(g.to(DEV))
+    _check(y, ref, 1e-5, "plane y"); _check(vd.grad, v.grad, 1e-5, "plane dx")
+    assert float(y[1 * Bp + 1].detach().abs().max()) == 0.0             # bbox 4 = (image 1, object 1): absent -> exactly 0
+
+
+@pytest.mark.parametrize("spatial", [(), (4, 4), (16, 16), (5, 3)])
+def test_cat_channels(spatial):
+    """mogan_concat_fwd / _bwd: torch.cat(..., 1) whose parts are plain tensors, codes repeated over the plane, one tensor
+    repeated for every object and per-object slices of a (B, G, C) tensor (model.py:400-401, 418, 457, 633-634, 666, 703) --
+    forward bit-exact (it only moves values), gradients against autograd of the torch expression in fp64."""
+    B, G = 4, 3
+    N = G * B
+    full = T("cat.full%s" % (spatial,), (N, 6) + spatial)
+    plane = T("cat.plane", (N, 5))
+    rep = T("cat.rep%s" % (spatial,), (B, 3) + spatial)
+    objp = T("cat.objp", (B, G, 7))
+    ones = (1,) * len(spatial)
+    def torch_expr(full, plane, rep, objp):
+        a = plane.view(N, 5, *ones).expand(N, 5, *spatial)
+        b = rep.repeat(G, *([1] * (1 + len(spatial))))
+        c = objp.transpose(0, 1).reshape(N, 7, *ones).expand(N, 7, *spatial)
+        return torch.cat((full, a, b, c), 1)
+    leaves = [t.clone().double().requires_grad_(True) for t in (full, plane, rep, objp)]
+    ref = torch_expr(*leaves)
+    g = T("cat.g%s" % (spatial,), ref.shape)
+    ref.backward(g.double())
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (full, plane, rep, objp)]
+    y = ops.cat_channels([(dl[0], "full"), (dl[1], "plane"), (dl[2], ("rep", G)), (dl[3], ("obj_plane", G))], N, spatial)
+    assert torch.equal(y.detach().cpu(), ref.detach().float())
+    y.backward(g.to(DEV))
+    for got, want, what in zip(dl, leaves, ("full", "plane", "rep", "obj_plane")):
+        _check(got.grad, want.grad, 2e-6, "cat d" + what)
+    # per-object slices of a (B, G, C, *spatial) tensor, and a part without gradient
+    obj = T("cat.obj%s" % (spatial,), (B, G, 2) + spatial)
+    lo = obj.clone().double().requires_grad_(True)
+    ref = torch.cat((lo.transpose(0, 1).reshape((N, 2) + spatial), full.double()), 1)
+    g = T("cat.g2%s" % (spatial,), ref.shape)
+    ref.backward(g.double())
+    do = obj.clone().to(DEV).requires_grad_(True)
+    y = ops.cat_channels([(do, ("obj", G)), (full.to(DEV), "full")], N, spatial)
+    assert torch.equal(y.detach().cpu(), ref.detach().float())
+    y.backward(g.to(DEV))
+    _check(do.grad, lo.grad, 2e-6, "cat dobj")
+
+
 @pytest.mark.parametrize("B,idf,Q,T_", [(3, 6, 16, 5), (4, 48, 4096, 12), (2, 96, 300, 20)])
 def test_attention(B, idf, Q, T_):
     h = T("ath%d" % B, (B, idf, Q)).requires_grad_(True)

@@ -147,8 +147,12 @@ __global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) {
 #pragma unroll
             for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < 3; ++pl) {
+#ifdef PK_LAB_A2          // lab: two thirds of the weight bytes (the third piece is not loaded; results are wrong)
+                    if (pl == 2) { ra[s2][ta][2] = ra[s2][ta][1]; continue; }
+#endif
                     ra[s2][ta][pl] = ldg16(rA, abase[ta] + (unsigned)((t * 2 + s2) * 3 + pl) * 1024u, aok[ta] & live);
+                }
     };
     auto load_b = [&](int t) {
         const bool live = t < t_end;

@@ -411,6 +411,9 @@ __global__ __launch_bounds__(256) void wino3_weight_kernel(const float* __restri
     for (int pc = 0; pc < 3; ++pc) U3[base + (size_t)pc * 64] = __builtin_bit_cast(uint4, f.p[pc]);
 }
 
+// DBG (lab only, MOGAN_WINO_DBG): 1 = no filter loads inside the K loop, 2 = no output transform / stores, 4 = no halo loads /
+// input transform inside the K loop -- what each part costs; results are wrong
+template <int DBG>
 __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict__ X, const uint4* __restrict__ U3,
                                                         float* __restrict__ Y, int Cin, int H, int W, int Cout, int OH, int OW,
                                                         int pad, int tiles_x, int tiles_y, int ntile, int nimg,
@@ -539,13 +542,29 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
             float* Vn = Vs + (cur ^ 1) * VSZ2;
             const float* Xn = Xs + (cur ^ 1) * XSZ2;
             mma_j(0, Vc);
-            load_a(0, ubase, p + 1);
-            store_x(rx, Xs + cur * XSZ2);                   // X(p+2)
-            load_x(rx, xg, (p + 3) * CK2);
-            transform(Xn, Vn, 0);                           // X(p+1) -> V(p+1)
+            if (!(DBG & 1)) load_a(0, ubase, p + 1);
+            if (!(DBG & 4)) {
+                store_x(rx, Xs + cur * XSZ2);               // X(p+2)
+                load_x(rx, xg, (p + 3) * CK2);
+                transform(Xn, Vn, 0);                       // X(p+1) -> V(p+1)
+            }
             mma_j(1, Vc);
-            load_a(1, ubase, p + 1);
-            transform(Xn, Vn, 8);
+            if (!(DBG & 1)) load_a(1, ubase, p + 1);
+            if (!(DBG & 4)) transform(Xn, Vn, 8);
+#if defined(W3_SCHED) && W3_SCHED
+            // issue-order template (lab): the first group's operands (8 LDS reads, the split), then per MFMA a few of the
+            // step's other instructions
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 36, 0);
+#pragma unroll
+            for (int g = 0; g < 36; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, W3_SCHED, 0);
+                if (g < 26) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (g < 20) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (g >= 6 && g < 30) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+#endif
             __syncthreads();
         }
         const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
@@ -556,8 +575,20 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
         }
         // ---- output transform (as in wino_fwd_kernel): row i = wave>>1 of M, T_i[b] = sum_j M[i][j] A[j][b] split over the
         // wave pair; Y[a][b] = sum_i A^t[a][i] T_i[b] through Ts, one pass per output column parity b
-        float yreg[6][2][2];
         const int wj = wave & 1;
+        if (DBG & 2) {
+            float t = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[0][a][r] + acc[1][a][r];
+            if (t == 123.456f) Y[tid] = t;
+            if (more) { load_a(0, ubase, 0); load_a(1, ubase, 0); }
+            continue;
+        }
+        // item = (output channel m, pair of horizontally adjacent tiles): 96 x 16 = 1536 items, three per thread; the thread
+        // ends up with a 2 x 4 output patch per item and stores it as two 16-byte rows
+        float yreg[3][2][2][2];                             // [item][output row a][output column b][tile of the pair]
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             if (b) __syncthreads();
@@ -571,43 +602,50 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
                 }
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int idx = tid + 512 * q;
-                float tq[4];
+            for (int q = 0; q < 3; ++q) {
+                const int idx = 2 * (tid + 512 * q);        // = m * 32 + first tile of the pair
+                float2 tq[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tq[i] = Ts[(2 * i) * BM * NT + idx] + Ts[(2 * i + 1) * BM * NT + idx];
-                yreg[q][0][b] = tq[0] + tq[1] + tq[2];
-                yreg[q][1][b] = tq[1] - tq[2] - tq[3];
+                for (int i = 0; i < 4; ++i) {
+                    const float2 u0 = *(const float2*)&Ts[(2 * i) * BM * NT + idx];
+                    const float2 u1 = *(const float2*)&Ts[(2 * i + 1) * BM * NT + idx];
+                    tq[i] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                }
+                yreg[q][0][b][0] = tq[0].x + tq[1].x + tq[2].x; yreg[q][0][b][1] = tq[0].y + tq[1].y + tq[2].y;
+                yreg[q][1][b][0] = tq[1].x - tq[2].x - tq[3].x; yreg[q][1][b][1] = tq[1].y - tq[2].y - tq[3].y;
             }
         }
         if (more) { load_a(0, ubase, 0); load_a(1, ubase, 0); }         // (the accumulators are free now)
+        const bool fast = (OW & 3) == 0 && coy0 + 2 * TROWS <= OH && cox0 + 2 * TCOLS <= OW && cm0 + BM <= Cout &&
+                          ep_scale == nullptr && (((uintptr_t)Y) & 15) == 0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int idx = tid + 512 * q;
-            const int m = idx >> 5, tl = idx & 31;
-            const int oy = coy0 + 2 * (tl >> 4), ox = cox0 + 2 * (tl & 15);
-            if (cm0 + m < Cout && oy < OH && ox < OW) {
-                float v[2][2] = {{yreg[q][0][0], yreg[q][0][1]}, {yreg[q][1][0], yreg[q][1][1]}};
-                if (ep_scale != nullptr) {
-                    const float sc = ep_scale[cm0 + m], sh = ep_shift[cm0 + m];
+        for (int q = 0; q < 3; ++q) {
+            const int it = tid + 512 * q;
+            const int m = it >> 4, tp = it & 15;
+            const int oy = coy0 + 2 * (tp >> 3), ox = cox0 + 4 * (tp & 7);
+            if (fast) {
+                float* o = Y + ((size_t)(cimg * Cout + cm0 + m) * OH + oy) * OW + ox;
+                *(float4*)o = make_float4(yreg[q][0][0][0], yreg[q][0][1][0], yreg[q][0][0][1], yreg[q][0][1][1]);
+                *(float4*)(o + OW) = make_float4(yreg[q][1][0][0], yreg[q][1][1][0], yreg[q][1][0][1], yreg[q][1][1][1]);
+            } else if (cm0 + m < Cout) {
+                float sc = 1.f, sh = 0.f;
+                if (ep_scale != nullptr) { sc = ep_scale[cm0 + m]; sh = ep_shift[cm0 + m]; }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
-                            v[a][b] = fmaf(v[a][b], sc, sh);
-                            if (ep_relu) v[a][b] = fmaxf(v[a][b], 0.f);
+                            const int y = oy + a, x = ox + 2 * t + b;
+                            if (y < OH && x < OW) {
+                                float v = yreg[q][a][b][t];
+                                if (ep_scale != nullptr) {
+                                    v = fmaf(v, sc, sh);
+                                    if (ep_relu) v = fmaxf(v, 0.f);
+                                }
+                                Y[((size_t)(cimg * Cout + cm0 + m) * OH + y) * OW + x] = v;
+                            }
                         }
-                }
-                float* o = Y + ((size_t)(cimg * Cout + cm0 + m) * OH + oy) * OW + ox;
-                const bool y1 = oy + 1 < OH;
-                if ((OW & 1) == 0) {
-                    *(float2*)o = make_float2(v[0][0], v[0][1]);
-                    if (y1) *(float2*)(o + OW) = make_float2(v[1][0], v[1][1]);
-                } else {
-                    const bool x1 = ox + 1 < OW;
-                    o[0] = v[0][0]; if (x1) o[1] = v[0][1];
-                    if (y1) { o[OW] = v[1][0]; if (x1) o[OW + 1] = v[1][1]; }
-                }
             }
         }
     }
@@ -897,9 +935,25 @@ __global__ __launch_bounds__(64) void wino_wgrad_finish(const float* __restrict_
 // weights change every step, the transform is one thread per (co, ci).
 static int g_wino = -1;
 
+static int wino_run(const float* in, const float* w, const void* u3_prepared, float* out, int B, int Cin, int H, int W, int Cout,
+                    int KH, int KW, int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift,
+                    int ep_relu, void* ws, size_t ws_bytes, hipStream_t st, size_t* u3_bytes_out);
+
 int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                    int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift, int ep_relu,
                    void* ws, size_t ws_bytes, hipStream_t st) {
+    return wino_run(in, w, nullptr, out, B, Cin, H, W, Cout, KH, KW, stride, ph, pw, up, dgrad, ep_scale, ep_shift, ep_relu, ws,
+                    ws_bytes, st, nullptr);
+}
+
+// u3_bytes_out != nullptr: plan only -- *u3_bytes_out = size of the pre-split filter planes this geometry would use (0: the
+// call would not take the round-4 kernel), nothing is launched.  u3_prepared != nullptr: the planes were built by
+// mogan_wino_prep for this weight version; the per-call weight kernel is skipped.
+static int wino_run(const float* in, const float* w, const void* u3_prepared, float* out, int B, int Cin, int H, int W, int Cout,
+                    int KH, int KW, int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift,
+                    int ep_relu, void* ws, size_t ws_bytes, hipStream_t st, size_t* u3_bytes_out) {
+    const bool plan_only = u3_bytes_out != nullptr;
+    if (plan_only) *u3_bytes_out = 0;
     if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
     // MOGAN_WINO_FWD / MOGAN_WINO_DGRAD = 0: forward / data gradient on the direct kernels, the weight gradient stays here
     static const int fwd_on = getenv("MOGAN_WINO_FWD") ? atoi(getenv("MOGAN_WINO_FWD")) : 1;
@@ -911,7 +965,7 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     const int cH = H + 2 * ph - 2, cW = W + 2 * pw - 2;
     const int iH = dgrad ? cH : H, iW = dgrad ? cW : W, oH = dgrad ? H : cH, oW = dgrad ? W : cW, pad = dgrad ? 2 - ph : ph;
     if (cH < 2 || cW < 2 || (Kin % (2 * CK)) || Kin < 32 || Kout < 64) return 0;
-    if (((oW & 1) == 0) && (((uintptr_t)out) & 7) != 0) return 0;
+    if (!plan_only && ((oW & 1) == 0) && (((uintptr_t)out) & 7) != 0) return 0;
     const int tiles_x = (oW + 2 * TCOLS - 1) / (2 * TCOLS), tiles_y = (oH + 2 * TROWS - 1) / (2 * TROWS);
     // ragged grids waste part of every 4 x 32 tile: below 70 % filling the direct kernels win
     if ((double)oW * oH < 0.7 * (double)tiles_x * 2 * TCOLS * tiles_y * 2 * TROWS) return 0;
@@ -922,7 +976,7 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     if ((long long)B * Kin * iH * iW >= (1ll << 29) || (long long)Kin * iH * iW >= (1ll << 26) ||
         (long long)B * Kout * oH * oW >= (1ll << 30) || ubytes >= (1ull << 31))
         return 0;
-    if (!ws || ws_bytes < ubytes) return 0;
+    if (!plan_only && !u3_prepared && (!ws || ws_bytes < ubytes)) return 0;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
@@ -938,16 +992,35 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     static const int wino_v = getenv("MOGAN_WINO_V") ? atoi(getenv("MOGAN_WINO_V")) : 3;
     // (+ one step of padding: the K loop's last iteration prefetches step nstep, whose scalar offset must stay inside the buffer)
     const size_t u3bytes = (size_t)mbs * 8 * (Kin / CK2) * 18 * 1024 + 18 * 1024;
-    if (wino_v == 3 && u3bytes <= ws_bytes && u3bytes < (1ull << 31)) {
-        const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
-        hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, Cout, Cin,
-                           dgrad, nfrag);
-        hipLaunchKernelGGL(wino3_fwd_kernel, grid, dim3(512), 0, st, in, (const uint4*)ws, out, Kin, iH, iW, Kout, oH, oW, pad,
-                           tiles_x, tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu, (unsigned)(4ull * B * Kin * iH * iW),
-                           (unsigned)u3bytes);
+    if (plan_only) {
+        if (wino_v == 3 && u3bytes < (1ull << 31) && (((uintptr_t)out) & 15) == 0) *u3_bytes_out = u3bytes;
+        return 0;
+    }
+    if (wino_v == 3 && (u3_prepared || u3bytes <= ws_bytes) && u3bytes < (1ull << 31)) {
+        if (!u3_prepared) {
+            const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
+            hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, Cout,
+                               Cin, dgrad, nfrag);
+        }
+        const uint4* const u3 = u3_prepared ? (const uint4*)u3_prepared : (const uint4*)ws;
+        static const int dbg = getenv("MOGAN_WINO_DBG") ? atoi(getenv("MOGAN_WINO_DBG")) : 0;
+#define W3_LAUNCH(D) hipLaunchKernelGGL(wino3_fwd_kernel<D>, grid, dim3(512), 0, st, in, u3, out, Kin, iH, iW, Kout, \
+                                       oH, oW, pad, tiles_x, tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu,                 \
+                                       (unsigned)(4ull * B * Kin * iH * iW), (unsigned)u3bytes)
+        switch (dbg) {
+            case 1: W3_LAUNCH(1); break;
+            case 2: W3_LAUNCH(2); break;
+            case 3: W3_LAUNCH(3); break;
+            case 4: W3_LAUNCH(4); break;
+            case 5: W3_LAUNCH(5); break;
+            case 7: W3_LAUNCH(7); break;
+            default: W3_LAUNCH(0); break;
+        }
+#undef W3_LAUNCH
         return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
     }
 #endif
+    if (u3_prepared) return 0;          // (prepared planes belong to the round-4 kernel only)
     float* U = (float*)ws;
     const long long ngroups = mbs * 8 * (Kin / CK) * 6 * 64;
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad,
@@ -993,3 +1066,57 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
                        Cin, nsplit, accumulate);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }
+
+// ---- C ABI: the filter planes of a weight version prepared ONCE (behind the optimizer step) instead of per call ------------
+extern "C" {
+
+size_t mogan_wino_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up,
+                             int dgrad) {
+#if MOGAN_X6
+    size_t n = 0;
+    // (a 16-byte aligned dummy output pointer: alignment of the real one is the allocator's)
+    wino_run(nullptr, nullptr, nullptr, (float*)16, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, dgrad, nullptr, nullptr, 0, nullptr,
+             0, nullptr, &n);
+    return n;
+#else
+    return 0;
+#endif
+}
+
+int mogan_wino_prep(const float* w, void* u3, int Cout, int Cin, int dgrad, hipStream_t stream) {
+#if MOGAN_X6
+    if (!w || !u3 || Cout <= 0 || Cin <= 0) return MOGAN_ERR_SHAPE;
+    const int Kin = dgrad ? Cout : Cin, Kout = dgrad ? Cin : Cout;
+    if (Kin % CK2) return MOGAN_ERR_SHAPE;
+    const long long mbs = (Kout + BM - 1) / BM;
+    const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
+    hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, stream, w, (uint4*)u3, Cout, Cin,
+                       dgrad, nfrag);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+#else
+    return MOGAN_ERR_SHAPE;
+#endif
+}
+
+int mogan_conv2d_fwd_wp(const float* x, const void* u3, float* y, int B, int Cin, int Hs, int Ws, int Cout, int ph, int pw,
+                        hipStream_t stream) {
+    if (!u3) return MOGAN_ERR_SHAPE;
+    const int OH = Hs + 2 * ph - 2, OW = Ws + 2 * pw - 2;
+    mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * OH * OW * Cin * 9, Cout, B * OH * OW, Cin * 9, stream);
+    const int rc = wino_run(x, nullptr, u3, y, B, Cin, Hs, Ws, Cout, 3, 3, 1, ph, pw, 0, 0, nullptr, nullptr, 0, nullptr, 0, stream,
+                            nullptr);
+    mogan_prof_end(rc == 1, stream);
+    return rc == 1 ? 0 : (rc < 0 ? rc : MOGAN_ERR_SHAPE);
+}
+
+int mogan_conv2d_dgrad_wp(const float* dy, const void* u3, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int ph, int pw,
+                          hipStream_t stream) {
+    if (!u3) return MOGAN_ERR_SHAPE;
+    mogan_prof_begin(5, 1, (4.0 / 9.0) * 2.0 * Cin * (double)B * Hs * Ws * Cout * 9, Cin, B * Hs * Ws, Cout * 9, stream);
+    const int rc = wino_run(dy, nullptr, u3, dx, B, Cin, Hs, Ws, Cout, 3, 3, 1, ph, pw, 0, 1, nullptr, nullptr, 0, nullptr, 0, stream,
+                            nullptr);
+    mogan_prof_end(rc == 1, stream);
+    return rc == 1 ? 0 : (rc < 0 ? rc : MOGAN_ERR_SHAPE);
+}
+
+}  // extern "C"

@@ -77,6 +77,10 @@ SIGNATURES = {
     "mogan_softmax_bwd": [P, P, P, P, L, I, L, F, P],
     "mogan_stn_fwd": [P, P, P, I, I, I, I, I, I, I, P],
     "mogan_stn_bwd": [P, P, P, I, I, I, I, I, I, I, P],
+    "mogan_wino_prep_bytes": [I] * 12,
+    "mogan_wino_prep": [P, P, I, I, I, P],
+    "mogan_conv2d_fwd_wp": [P, P, P, I, I, I, I, I, I, I, P],
+    "mogan_conv2d_dgrad_wp": [P, P, P, I, I, I, I, I, I, I, P],
     "mogan_stn_fwd_ex": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "mogan_stn_bwd_ex": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "mogan_concat_fwd": [P, P, P, P, P, P, I, P, I, I, P],
@@ -133,7 +137,7 @@ class ConvDgradArgs(ctypes.Structure):          # MoganConvDgradArgs
                 ("accumulate", I)] + [(k, I) for k in ("B", "Cin", "Hs", "Ws", "Cout", "KH", "KW", "stride", "ph", "pw")]
 
 
-_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z}
+_RESTYPE = {"mogan_wino_prep_bytes": Z, "mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
 _lib = None

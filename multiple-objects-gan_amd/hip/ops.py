@@ -105,10 +105,21 @@ def _wgrad_accumulate(dy, x, w, geom, g):
         return
     pdy, px, _, pgeom, _ = prev
     if pgeom == geom and pdy.shape[1:] == dy.shape[1:] and px.shape[1:] == x.shape[1:]:
-        _wgrad_launch(torch.cat([pdy, dy]), torch.cat([px, x]), w.shape, geom, g)
+        _wgrad_launch(_cat_batch(pdy, dy), _cat_batch(px, x), w.shape, geom, g)
     else:
         _wgrad_launch(pdy, px, w.shape, pgeom, g)
         _wgrad_launch(dy, x, w.shape, geom, g)
+
+
+def _cat_batch(a, b):
+    """torch.cat([a, b]) along the batch axis of two dense tensors as one mogan_concat_fwd launch (the images of a tensor are the
+    "channels" of a one-row concat)."""
+    a, b = _c(a), _c(b)
+    per = a[0].numel()
+    out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
+    arrs = _cat_arrays([(a.shape[0], 1, 0, 0, 0), (b.shape[0], 1, 0, 0, 0)], [a.data_ptr(), b.data_ptr()])
+    call("mogan_concat_fwd", *arrs, 2, ptr(out), 1, per, stream_ptr())
+    return out
 
 
 def _wgrad_flush():
@@ -218,9 +229,12 @@ class WeightPacks:
 
     def _pack(self, dgrad, slot):
         Cout, Cin, KH, KW = self.w.shape
-        stride, ph, pw = slot[3]
         st = stream_ptr()
-        call("mogan_pk_weight_pack", ptr(self.w), slot[0].data_ptr(), Cout, Cin, KH, KW, stride, ph, pw, dgrad, st)
+        if isinstance(dgrad, tuple):                      # ("wino", dgrad): the Winograd kernel's pre-split filter planes
+            call("mogan_wino_prep", ptr(self.w), slot[0].data_ptr(), Cout, Cin, dgrad[1], st)
+        else:
+            stride, ph, pw = slot[3]
+            call("mogan_pk_weight_pack", ptr(self.w), slot[0].data_ptr(), Cout, Cin, KH, KW, stride, ph, pw, dgrad, st)
         slot[1], slot[2] = self.cell[0], _PK_GLOBAL[0]
         ev = torch.cuda.Event()
         ev.record()
@@ -242,9 +256,39 @@ class WeightPacks:
             for slot in (s0, s1):
                 slot[1], slot[2], slot[4], slot[5], slot[6] = self.cell[0], _PK_GLOBAL[0], ev, st, cap
             PK_STATS["packs"] += 1
+            for key, slot in self.slots.items():
+                if isinstance(key, tuple):
+                    self._pack(key, slot)
             return
         for dgrad, slot in self.slots.items():
             self._pack(dgrad, slot)
+
+    def _fresh(self, key, slot):
+        """make the copy in `slot` current for a use on the current stream"""
+        if slot[1] != self.cell[0] or slot[2] != _PK_GLOBAL[0]:
+            self._pack(key, slot)
+        elif slot[5] != stream_ptr() and (slot[6] or not lib._capturing()):
+            # packed on another stream: order behind that pack (a capturing stream must not wait for an event recorded
+            # outside its capture -- and need not: the device is synchronised before a capture begins)
+            torch.cuda.current_stream().wait_event(slot[4])
+        return slot[0].data_ptr()
+
+    def pointer_wino(self, dgrad, B, Hs, Ws, ph, pw):
+        """device pointer of the Winograd filter planes of this weight for a 3x3 stride-1 call of this geometry (built once
+        per weight version, csrc/mogan_wino.hip), or None: the call takes mogan_conv2d_fwd / _dgrad"""
+        Cout, Cin, KH, KW = self.w.shape
+        gk = ("wino", dgrad, B, Hs, Ws, ph, pw)
+        nbytes = self.elig.get(gk)
+        if nbytes is None:
+            nbytes = self.elig[gk] = int(lib.load().mogan_wino_prep_bytes(B, Cin, Hs, Ws, Cout, KH, KW, 1, ph, pw, 0, dgrad))
+        if not nbytes:
+            return None
+        key = ("wino", dgrad)
+        slot = self.slots.get(key)
+        if slot is None:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.w.device)
+            slot = self.slots[key] = [buf, -1, -1, None, None, None, False]
+        return self._fresh(key, slot)
 
     def pointer(self, dgrad, B, Hs, Ws, stride, ph, pw):
         """device pointer of the packed copy for this call's geometry, or None: take the unpacked kernels"""
@@ -262,13 +306,7 @@ class WeightPacks:
             slot = self.slots[dgrad] = [buf, -1, -1, (stride, ph, pw), None, None, False]
         elif slot[3] != (stride, ph, pw):
             return None                                   # one weight, two convolution geometries: not a case of the step
-        if slot[1] != self.cell[0] or slot[2] != _PK_GLOBAL[0]:
-            self._pack(dgrad, slot)
-        elif slot[5] != stream_ptr() and (slot[6] or not lib._capturing()):
-            # packed on another stream: order behind that pack (a capturing stream must not wait for an event recorded
-            # outside its capture -- and need not: the device is synchronised before a capture begins)
-            torch.cuda.current_stream().wait_event(slot[4])
-        return slot[0].data_ptr()
+        return self._fresh(dgrad, slot)
 
 
 def attach_packs(w, version_cell=None):
@@ -292,9 +330,30 @@ def _packed(w, dgrad, B, Hs, Ws, stride, ph, pw, up):
     return pk.pointer(dgrad, B, Hs, Ws, stride, ph, pw)
 
 
+WINO_PREP = os.environ.get("MOGAN_WINO_PREP", "0") != "0"     # 1: the Winograd filter planes built once per weight version behind
+# the optimizer step instead of per call.  Measured in the step (same box, two interleaved pairs): 402.4 / 401.8 img/s with the
+# planes prepared behind Adam vs 404.6 / 404.9 rebuilt per call -- the per-call transform leaves the planes hot in L2 right in
+# front of their only consumer, and the generator uses every weight version exactly once per direction; off by default
+
+
+def _wino_planes(w, dgrad, B, Hs, Ws, stride, ph, pw, up):
+    if up or stride != 1 or not WINO_PREP or w.shape[2] != 3 or w.shape[3] != 3:
+        return None
+    pk = getattr(w, "_mogan_pk", None)
+    if pk is None:
+        return None
+    return pk.pointer_wino(dgrad, B, Hs, Ws, ph, pw)
+
+
 def conv2d_forward(x, w, stride, ph, pw, up):
     B, Cin, Hs, Ws = x.shape
     Cout, _, KH, KW = w.shape
+    u3 = _wino_planes(w, 0, B, Hs, Ws, stride, ph, pw, up)
+    if u3 is not None:
+        y = torch.empty((B, Cout, Hs + 2 * ph - 2, Ws + 2 * pw - 2), dtype=torch.float32, device=x.device)
+        call("mogan_conv2d_fwd_wp", ptr(x), u3, ptr(y), B, Cin, Hs, Ws, Cout, ph, pw, stream_ptr())
+        PK_STATS["wino"] = PK_STATS.get("wino", 0) + 1
+        return y
     wp = _packed(w, 0, B, Hs, Ws, stride, ph, pw, up)
     if wp is not None:
         OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, 0)
@@ -319,6 +378,12 @@ def conv2d_forward(x, w, stride, ph, pw, up):
 def conv2d_dgrad(dy, w, x_shape, stride, ph, pw, up):
     B, Cin, Hs, Ws = x_shape
     Cout, _, KH, KW = w.shape
+    u3 = _wino_planes(w, 1, B, Hs, Ws, stride, ph, pw, up)
+    if u3 is not None:
+        dx = torch.empty((B, Cin, Hs, Ws), dtype=torch.float32, device=dy.device)
+        call("mogan_conv2d_dgrad_wp", ptr(dy), u3, ptr(dx), B, Cin, Hs, Ws, Cout, ph, pw, stream_ptr())
+        PK_STATS["wino"] = PK_STATS.get("wino", 0) + 1
+        return dx
     wsp, wsn = workspace(dy.device)
     wp = _packed(w, 1, B, Hs, Ws, stride, ph, pw, up)
     if wp is not None:

@@ -347,6 +347,36 @@ def test_stn(ac):
         assert float(y[1].detach().abs().max()) == 0.0 or theta is rot    # absent object -> exactly 0
 
 
+def test_winograd_prepared_filter_planes_follow_the_weight_version():
+    """mogan_wino_prep / mogan_conv2d_fwd_wp / _dgrad_wp: the pre-split filter planes of a ResBlock convolution (model.py:67-81)
+    built once per weight version by the weight's owner instead of per call -- same results as the per-call path, bit for
+    bit (the same kernel on the same planes), rebuilt when the owner bumps the version, and not used for geometries the
+    Winograd kernel does not take."""
+    B, Cin, H, W, Cout = 2, 96, 32, 64, 192
+    x, dy = T("wp.x", (B, Cin, H, W)).to(DEV), T("wp.dy", (B, Cout, H, W)).to(DEV)
+    w = (T("wp.w", (Cout, Cin, 3, 3)) * 0.1).to(DEV)
+    y0, dx0 = ops.conv2d_forward(x, w, 1, 1, 1, 0), ops.conv2d_dgrad(dy, w, x.shape, 1, 1, 1, 0)
+    cell = [0]
+    w2 = w.clone()
+    pk = ops.attach_packs(w2, cell)
+    n0 = ops.PK_STATS.get("wino", 0)
+    y1, dx1 = ops.conv2d_forward(x, w2, 1, 1, 1, 0), ops.conv2d_dgrad(dy, w2, x.shape, 1, 1, 1, 0)
+    assert ops.PK_STATS.get("wino", 0) == n0 + 2 and sorted(k for k in pk.slots if isinstance(k, tuple)) == [("wino", 0), ("wino", 1)]
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    _check(y1, F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1), 2e-6, "prepared fwd")
+    # the owner changes the weight: stale planes until the version moves, fresh ones after
+    w2.mul_(2.0)
+    assert torch.equal(ops.conv2d_forward(x, w2, 1, 1, 1, 0), y1)
+    cell[0] += 1
+    pk.repack()
+    _check(ops.conv2d_forward(x, w2, 1, 1, 1, 0), 2.0 * y1.double().cpu(), 2e-6, "after repack")
+    # a stride-2 / tiny-map use of a 3x3 weight does not go through the planes
+    n1 = ops.PK_STATS.get("wino", 0)
+    xs = T("wp.xs", (B, Cin, 4, 4)).to(DEV)
+    _check(ops.conv2d_forward(xs, w2, 1, 1, 1, 0), F.conv2d(xs.double().cpu(), w2.double().cpu(), None, 1, 1), 2e-6, "4x4 map")
+    assert ops.PK_STATS.get("wino", 0) == n1
+
+
 @pytest.mark.parametrize("ac", [False, True])
 def test_stn_shared_and_constant_sources(ac):
     """mogan_stn_*_ex: the object pathways' transformers without their materialised inputs (model.py:109-111, 402-404, 663-671)

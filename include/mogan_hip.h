@@ -113,6 +113,20 @@ int mogan_prof_dump(const char* path);
 int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, int pw, int up, int* OH, int* OW);
 int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                      int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
+/* The discriminators' logits head in one launch each way: p (B,Cout) = sigmoid(<x[b], w[co]> + bias[co]) over K = Cin*KH*KW --
+ * nn.Conv2d(8 ndf, 1, kernel_size=4, stride=4) (with bias) on a 4x4 map followed by nn.Sigmoid (model.py:626-627, 640-641);
+ * x (B,K) and w (Cout,K) dense, K % 4 == 0, Cout <= 4.  Backward from dp and p: dx (B,K) (NULL = not wanted), dw (Cout,K) and
+ * db (Cout) written or accumulated (NULL = not wanted; the images are summed in order). */
+int mogan_logits_head_fwd(const float* x, const float* w, const float* bias, float* p, int B, int K, int Cout,
+                          hipStream_t stream);
+int mogan_logits_head_bwd(const float* dp, const float* p, const float* x, const float* w, float* dx, float* dw, float* db,
+                          int B, int K, int Cout, int accumulate, hipStream_t stream);
+/* z = LeakyReLU_slope(conv2d(x, w)) in one launch: the first layer of every discriminator -- nn.Conv2d(3, ndf, 4, 2, 1)
+ * followed by nn.LeakyReLU(0.2) with no BatchNorm in between (model.py:597-598, 660-661).  Returns 0 = done, 1 = not a geometry
+ * for this kernel (run mogan_conv2d_fwd + mogan_act_fwd), < 0 = error.  Backward: mogan_act_bwd with z in place of the
+ * pre-activation (same sign), then the convolution's gradients. */
+int mogan_conv2d_lrelu_fwd(const float* x, const float* w, float* z, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                           int stride, int ph, int pw, float slope, void* ws, size_t ws_bytes, hipStream_t stream);
 /* conv (no upsample) with y = relu?(scale[co]*conv + shift[co]) applied in the kernel epilogue: BasicConv2d of the frozen,
  * eval-mode Inception trunk (conv -> BN on running statistics -> ReLU; model.py:258-299) in one pass over the output */
 int mogan_conv2d_affine_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,

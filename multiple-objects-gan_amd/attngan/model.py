@@ -442,7 +442,7 @@ class D_NET64(_D_BASE):
         return self._trunk(image, _sum_objects(h, G))
 
     def _trunk(self, image, h_code_locals):
-        h = ops.act(self.conv1(image), ops.ACT_LRELU, 0.2)
+        h = ops.conv2d_lrelu(image, self.conv1.weight, self.conv1.stride[0], self.conv1.padding, 0.2)
         h = self.bn2.fused(self.conv2(h), ops.ACT_LRELU, 0.2)
         h = ops.cat_channels([(h, "full"), (h_code_locals, "full")], h.shape[0], tuple(h.shape[2:]))
         h = self.bn3.fused(self.conv3(h), ops.ACT_LRELU, 0.2)

@@ -164,6 +164,19 @@ class FusedSeq(nn.Sequential):
                 if deep is not None:
                     x, i = deep
                     continue
+                if (isinstance(m, HipConv2d) and not up and groups == 1 and i + 1 < n and isinstance(mods[i + 1], nn.Sigmoid)
+                        and ops.logits_head_ok(x, m)):
+                    # the logits head: full-map convolution + bias + sigmoid in one launch (model.py:626-627, 640-641)
+                    x = ops.logits_head(x, m.weight, m.bias)
+                    i += 2
+                    continue
+                if (isinstance(m, HipConv2d) and not up and m.bias is None and groups == 1 and i + 1 < n
+                        and _act_of(mods[i + 1])[0] == ops.ACT_LRELU and x.dim() == 4 and x.shape[1] <= 16):
+                    # conv -> LeakyReLU with no BatchNorm in between (the first layer of a discriminator, model.py:597-598):
+                    # the activation rides in the convolution's epilogue
+                    x = ops.conv2d_lrelu(x, m.weight, m.stride[0], m.padding, _act_of(mods[i + 1])[1])
+                    i += 2
+                    continue
                 x = m(x, up=up)
                 up, i = False, i + 1
                 if i < n and isinstance(mods[i], _HipBNMixin):

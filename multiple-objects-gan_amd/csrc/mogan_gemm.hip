@@ -78,6 +78,7 @@ struct GemmP {
     int accumulate;         // direct (nsplit==1) store adds to C
     // optional fused epilogue of CONV_FWD (frozen eval-mode BN + ReLU of the Inception trunk): y = act(scale[m]*y + shift[m])
     const float* ep_scale; const float* ep_shift; int ep_relu;
+    float ep_slope;         // > 0 with ep_scale == nullptr: y = LeakyReLU_slope(conv) in the epilogue (mogan_conv2d_lrelu_fwd)
     // conv geometry: H,W = conv-input dims (after the optional fused upsample), Hs,Ws = stored dims
     int Bn, Cin, Cout, H, W, Hs, Ws, OH, OW, KH, KW, s, ph, pw, up;
     FastDiv fd_ohw, fd_ow, fd_khw, fd_kw, fd_nk, fd_nkw;
@@ -597,6 +598,8 @@ __device__ __forceinline__ void gemm_block(const GemmP& p, const unsigned bx, co
                         if (p.ep_scale != nullptr) {
                             v = fmaf(v, p.ep_scale[m], p.ep_shift[m]);
                             if (p.ep_relu) v = fmaxf(v, 0.f);
+                        } else if (p.ep_slope > 0.f) {
+                            v = v > 0.f ? v : v * p.ep_slope;
                         }
                     }
                     *dst = v;
@@ -661,6 +664,7 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GroupArgs g) {
 struct ReduceP {
     long long n, slab, Mcms, cms, ybs, ybs2, mbs;
     int nsplit, acc, msplit, ep_relu;
+    float ep_slope;
     const float* ep_scale; const float* ep_shift; const float* mask; float* out2;
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
@@ -692,6 +696,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (q.ep_scale != nullptr) {
         s = fmaf(s, q.ep_scale[m], q.ep_shift[m]);
         if (q.ep_relu) s = fmaxf(s, 0.f);
+    } else if (q.ep_slope > 0.f) {
+        s = s > 0.f ? s : s * q.ep_slope;
     }
     *dst = s;
 }
@@ -867,7 +873,7 @@ static int run_gemm(int mode, GemmP& p, int nz, long long c_numel, void* ws, siz
             q.cms = mode == CONV_FWD ? (long long)p.OH * p.OW : (long long)p.H * p.W;
             q.Mcms = (long long)p.M * q.cms; q.ybs = p.ybs; q.msplit = p.msplit; q.out2 = p.C2; q.ybs2 = p.ybs2;
             q.mask = p.mask; q.mbs = p.mbs;
-            if (mode == CONV_FWD) { q.ep_scale = p.ep_scale; q.ep_shift = p.ep_shift; q.ep_relu = p.ep_relu; }
+            if (mode == CONV_FWD) { q.ep_scale = p.ep_scale; q.ep_shift = p.ep_shift; q.ep_relu = p.ep_relu; q.ep_slope = p.ep_slope; }
         }
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)ws, p.C, q);
     }
@@ -1088,6 +1094,24 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
     p.A = w; p.B = x; p.C = y; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    dense_io(p, CONV_FWD);
+    return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
+}
+
+// conv + LeakyReLU in the epilogue of the implicit-GEMM kernel (or of its split-K reduction): the first layer of every
+// discriminator (nn.Conv2d(3, ndf, 4, 2, 1) -> nn.LeakyReLU(0.2), model.py:597-598, 660-661) has no BatchNorm to carry the
+// activation, and its output is the largest map of the network.  Returns 1 when the geometry is not one for this kernel (the
+// caller then runs mogan_conv2d_fwd + mogan_act_fwd).
+int mogan_conv2d_lrelu_fwd(const float* x, const float* w, float* z, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
+                           int stride, int ph, int pw, float slope, void* ws, size_t ws_bytes, hipStream_t stream) {
+    GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0); if (rc) return rc;
+    if (!(slope > 0.f)) return MOGAN_ERR_SHAPE;
+    // only layers the dispatch of mogan_conv2d_fwd would hand to the implicit-GEMM kernel anyway: few input channels
+    if (Cin > 16 || Cout <= 4) return 1;
+    p.A = w; p.B = x; p.C = z; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
+    p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
+    p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    p.ep_slope = slope;
     dense_io(p, CONV_FWD);
     return run_gemm(CONV_FWD, p, 1, (long long)B * Cout * p.OH * p.OW, ws, ws_bytes, stream);
 }

@@ -352,6 +352,68 @@ __global__ __launch_bounds__(256) void sc_dot_wgrad(const float* __restrict__ dy
     for (int b = 0; b < B; ++b) acc = fmaf(dy[b * Cout + co], x[(size_t)b * K + k], acc);
     dw[i] = accumulate ? dw[i] + acc : acc;
 }
+// ---- the whole logits head in one launch each way (round 4): p[b][co] = sigmoid(<x[b], w[co]> + bias[co]) -- Conv2d(8 ndf, 1,
+// kernel_size=4, stride=4) + bias + nn.Sigmoid on a 4x4 map (model.py:626-627, 640-641) were three launches forward (dot,
+// bias_add, sigmoid) and four backward on 16-element results, 21 times per step.  K % 4 == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(256) void logits_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ p, int K,
+                                                              int Cout) {
+    const int b = blockIdx.x / Cout, co = blockIdx.x % Cout;
+    const float4* xb = (const float4*)(x + (size_t)b * K); const float4* wc = (const float4*)(w + (size_t)co * K);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = threadIdx.x; k < K / 4; k += 256) {       // fixed order per thread; four independent chains
+        const float4 u = xb[k], v = wc[k];
+        a0 = fmaf(u.x, v.x, a0); a1 = fmaf(u.y, v.y, a1); a2 = fmaf(u.z, v.z, a2); a3 = fmaf(u.w, v.w, a3);
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float z = (part[0] + part[1]) + (part[2] + part[3]) + (bias ? bias[co] : 0.f);
+        p[blockIdx.x] = 1.f / (1.f + __expf(-z));
+    }
+}
+// backward: dz[b][co] = dp * p * (1 - p) on the fly.  Blocks [0, nbx): dx[b][k] = sum_co dz[b][co] w[co][k] (when dx != NULL);
+// the rest: dw[co][k] (+)= sum_b dz[b][co] x[b][k] (images in order), and the block's thread 0 of the first of them: db[co].
+__global__ __launch_bounds__(256) void logits_head_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p,
+                                                              const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ dx, float* __restrict__ dw,
+                                                              float* __restrict__ db, int B, int K, int Cout, int accumulate,
+                                                              unsigned nbx) {
+    if (blockIdx.x < nbx) {
+        const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= (long long)B * K) return;
+        const int b = (int)(i / K), k = (int)(i - (long long)b * K);
+        float acc = 0.f;
+        for (int co = 0; co < Cout; ++co) {
+            const float q = p[b * Cout + co];
+            acc = fmaf(dp[b * Cout + co] * q * (1.f - q), w[(size_t)co * K + k], acc);
+        }
+        dx[i] = acc;
+        return;
+    }
+    if (dw == nullptr) return;
+    const int i = (blockIdx.x - nbx) * 256 + threadIdx.x;
+    if (i < Cout * K) {
+        const int co = i / K, k = i - co * K;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float q = p[b * Cout + co];
+            acc = fmaf(dp[b * Cout + co] * q * (1.f - q), x[(size_t)b * K + k], acc);
+        }
+        dw[i] = accumulate ? dw[i] + acc : acc;
+    }
+    if (db != nullptr && blockIdx.x == nbx && threadIdx.x < Cout) {
+        const int co = threadIdx.x;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) { const float q = p[b * Cout + co]; acc += dp[b * Cout + co] * q * (1.f - q); }
+        db[co] = accumulate ? db[co] + acc : acc;
+    }
+}
+
 static inline bool is_full_map(int Hs, int Ws, int Cout, int KH, int KW, int ph, int pw, int up) {
     return up == 0 && ph == 0 && pw == 0 && KH == Hs && KW == Ws && Cout >= 1 && Cout <= 4;
 }
@@ -458,3 +520,26 @@ int mogan_smallc_wgrad_try(const float* dy, const float* x, float* dw, int B, in
                        accumulate);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }
+
+// ---- C ABI: the discriminators' logits head ---------------------------------------------------------------------------------
+extern "C" {
+
+int mogan_logits_head_fwd(const float* x, const float* w, const float* bias, float* p, int B, int K, int Cout,
+                          hipStream_t stream) {
+    if (B <= 0 || K <= 0 || (K & 3) || Cout < 1 || Cout > 4 || ((((uintptr_t)x) | ((uintptr_t)w)) & 15)) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(logits_head_fwd_kernel, dim3((unsigned)(B * Cout)), dim3(256), 0, stream, x, w, bias, p, K, Cout);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+int mogan_logits_head_bwd(const float* dp, const float* p, const float* x, const float* w, float* dx, float* dw, float* db,
+                          int B, int K, int Cout, int accumulate, hipStream_t stream) {
+    if (B <= 0 || K <= 0 || Cout < 1 || Cout > 4 || (long long)B * K >= (1ll << 31)) return MOGAN_ERR_SHAPE;
+    const unsigned nbx = dx ? (unsigned)(((long long)B * K + 255) / 256) : 0u;
+    const unsigned nbw = dw ? (unsigned)((Cout * K + 255) / 256) : 0u;
+    if (nbx + nbw == 0) return 0;
+    hipLaunchKernelGGL(logits_head_bwd_kernel, dim3(nbx + nbw), dim3(256), 0, stream, dp, p, x, w, dx, dw, db, B, K, Cout,
+                       accumulate, nbx);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+}  // extern "C"

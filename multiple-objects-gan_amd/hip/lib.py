@@ -32,6 +32,9 @@ SIGNATURES = {
     "mogan_prof_dump": [ctypes.c_char_p],
     "mogan_conv2d_out_dims": [I, I, I, I, I, I, I, I, P, P],
     "mogan_conv2d_fwd": [P, P, P] + [I] * 11 + [P, Z, P],
+    "mogan_logits_head_fwd": [P, P, P, P, I, I, I, P],
+    "mogan_logits_head_bwd": [P, P, P, P, P, P, P, I, I, I, I, P],
+    "mogan_conv2d_lrelu_fwd": [P, P, P] + [I] * 10 + [F, P, Z, P],
     "mogan_conv2d_affine_fwd": [P, P, P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_affine_relu_bwd_out": [P, P, P, P, I, I, I, P],
     "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],

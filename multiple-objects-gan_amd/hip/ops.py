@@ -501,6 +501,107 @@ class ConvAffineReluFn(torch.autograd.Function):
         return dx, dw, None, None, None, None, None
 
 
+class ConvLReLUFn(torch.autograd.Function):
+    """z = LeakyReLU(conv2d(x, w)) with the activation in the convolution's epilogue (mogan_conv2d_lrelu_fwd): the first layer
+    of every discriminator (model.py:597-598, 660-661).  Saves x, w and the OUTPUT z; backward: g = dz * (z > 0 ? 1 : slope)
+    (z has the pre-activation's sign), then the ordinary data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, ph, pw, slope):
+        x, w = _c(x), _c(w)
+        B, Cin, Hs, Ws = x.shape
+        Cout, _, KH, KW = w.shape
+        OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, 0)
+        z = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        wsp, wsn = workspace(x.device)
+        rc = lib.load().mogan_conv2d_lrelu_fwd(ptr(x), ptr(w), ptr(z), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, slope,
+                                               wsp, wsn, stream_ptr())
+        if rc == 1:                                        # not a geometry for the fused epilogue
+            z = conv2d_forward(x, w, stride, ph, pw, 0)
+            call("mogan_act_fwd", ptr(z), ptr(z), B, Cout, OH * OW, ACT_LRELU, slope, stream_ptr())
+        elif rc != 0:
+            raise lib.MoganHipError("mogan_conv2d_lrelu_fwd failed: %s" % lib._ERRORS.get(rc, rc))
+        if ACT_TRACE is not None:
+            ACT_TRACE.append((ACT_LRELU, z))
+        ctx.save_for_backward(x, w, z)
+        ctx.cfg = (stride, ph, pw, slope)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, z = ctx.saved_tensors
+        stride, ph, pw, slope = ctx.cfg
+        g = torch.empty_like(z)
+        call("mogan_act_bwd", ptr(z), ptr(_c(dz)), ptr(g), z.shape[0], z.shape[1], z.shape[2] * z.shape[3], ACT_LRELU, slope,
+             stream_ptr())
+        dx = conv2d_dgrad(g, w, x.shape, stride, ph, pw, 0) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            gb = _grad_buf(w)
+            if gb is not None:
+                _wgrad_accumulate(g, x, w, (stride, ph, pw, 0), gb)
+            else:
+                dw = conv2d_wgrad(g, x, w.shape, stride, ph, pw, 0)
+        return dx, dw, None, None, None, None
+
+
+class LogitsHeadFn(torch.autograd.Function):
+    """p = sigmoid(conv(x, w) + bias).view(-1) for a convolution whose filter covers the whole map (D_GET_LOGITS.outlogits,
+    model.py:626-627, 640-641): one launch forward, one backward (mogan_logits_head_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w = _c(x), _c(w)
+        B, Cout, K = x.shape[0], w.shape[0], w[0].numel()
+        p = torch.empty((B, Cout, 1, 1), dtype=torch.float32, device=x.device)
+        call("mogan_logits_head_fwd", ptr(x), ptr(w), ptr(_c(bias)) if bias is not None else None, ptr(p), B, K, Cout,
+             stream_ptr())
+        ctx.save_for_backward(x, w, p)
+        ctx.bias_ref = bias
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, w, p = ctx.saved_tensors
+        bias = ctx.bias_ref
+        B, Cout, K = x.shape[0], w.shape[0], w[0].numel()
+        dp = _c(dp)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        want_w = ctx.needs_input_grad[1]
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        gw = _grad_buf(w) if want_w else None
+        gb = _grad_buf(bias) if want_b else None
+        # one accumulate flag for both: direct only when every wanted gradient has its buffer
+        direct = want_w and gw is not None and (not want_b or gb is not None)
+        dw = gw if direct else (torch.empty_like(w) if want_w else None)
+        db = (gb if direct else torch.empty_like(bias)) if want_b else None
+        call("mogan_logits_head_bwd", ptr(dp), ptr(p), ptr(x), ptr(w), ptr(dx), ptr(dw), ptr(db), B, K, Cout,
+             1 if direct else 0, stream_ptr())
+        if direct:
+            _grad_hit(gw)
+            if gb is not None:
+                _grad_hit(gb)
+            dw = db = None
+        return dx, dw, db
+
+
+def logits_head(x, w, bias):
+    return LogitsHeadFn.apply(x, w, bias)
+
+
+def logits_head_ok(x, conv):
+    """conv + Sigmoid as the fused head: the filter covers the whole (unpadded) map, <= 4 logits, K a multiple of 4"""
+    w = conv.weight
+    ph, pw = conv.padding if isinstance(conv.padding, tuple) else (conv.padding, conv.padding)
+    return (x.dim() == 4 and ph == 0 and pw == 0 and w.shape[2] == x.shape[2] and w.shape[3] == x.shape[3] and w.shape[0] <= 4
+            and w[0].numel() % 4 == 0 and x.shape[1] == w.shape[1])
+
+
+def conv2d_lrelu(x, w, stride, padding, slope=0.2):
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    return ConvLReLUFn.apply(x, w, int(stride), int(ph), int(pw), float(slope))
+
+
 def conv2d_affine_relu(x, w, scale, shift, stride=1, padding=0):
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
     return ConvAffineReluFn.apply(x, w, scale, shift, int(stride), int(ph), int(pw))

@@ -347,6 +347,38 @@ def test_stn(ac):
         assert float(y[1].detach().abs().max()) == 0.0 or theta is rot    # absent object -> exactly 0
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(16, 768, 1), (15, 32, 1), (5, 70, 3)])
+def test_logits_head_and_conv_lrelu(B, Cin, Cout):
+    """mogan_logits_head_fwd / _bwd (full-map Conv2d + bias + Sigmoid, model.py:626-627, 640-641) and mogan_conv2d_lrelu_fwd
+    (first discriminator layer: Conv2d(3, ndf, 4, 2, 1) + LeakyReLU(0.2), model.py:597-598) against torch in fp64: value,
+    input gradient, weight / bias gradients -- returned and accumulated into existing .grad buffers."""
+    x = T("lh.x%d" % Cin, (B, Cin, 4, 4)).requires_grad_(True)
+    w = T("lh.w%d" % Cin, (Cout, Cin, 4, 4), 0.05).requires_grad_(True)
+    b = T("lh.b%d" % Cin, (Cout,), 0.1).requires_grad_(True)
+    ref = torch.sigmoid(F.conv2d(x.double(), w.double(), b.double(), 4))
+    g = T("lh.g%d" % Cin, ref.shape)
+    ref.backward(g.double())
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    p = ops.logits_head(xd, wd, bd)
+    p.backward(g.to(DEV))
+    _check(p, ref, 2e-6, "head p"); _check(xd.grad, x.grad, 5e-6, "head dx")
+    _check(wd.grad, w.grad, 5e-6, "head dw"); _check(bd.grad, b.grad, 5e-6, "head db")
+    # a second backward accumulates straight into the existing dense .grad buffers (the trainer's flat buckets)
+    p2 = ops.logits_head(xd.detach(), wd, bd)
+    p2.backward(g.to(DEV))
+    _check(wd.grad, 2 * w.grad, 5e-6, "head dw x2"); _check(bd.grad, 2 * b.grad, 5e-6, "head db x2")
+    # conv + LeakyReLU in the epilogue
+    xi = T("cl.x%d" % B, (min(B, 4), 3, 32, 32)).requires_grad_(True)
+    wi = T("cl.w%d" % B, (24, 3, 4, 4), 0.2).requires_grad_(True)
+    ref = F.leaky_relu(F.conv2d(xi.double(), wi.double(), None, 2, 1), 0.2)
+    g = T("cl.g%d" % B, ref.shape)
+    ref.backward(g.double())
+    xid, wid = (t.detach().to(DEV).requires_grad_(True) for t in (xi, wi))
+    z = ops.conv2d_lrelu(xid, wid, 2, 1, 0.2)
+    z.backward(g.to(DEV))
+    _check(z, ref, 2e-6, "conv+lrelu"); _check(xid.grad, xi.grad, 5e-6, "conv+lrelu dx"); _check(wid.grad, wi.grad, 5e-6, "conv+lrelu dw")
+
+
 def test_winograd_prepared_filter_planes_follow_the_weight_version():
     """mogan_wino_prep / mogan_conv2d_fwd_wp / _dgrad_wp: the pre-split filter planes of a ResBlock convolution (model.py:67-81)
     built once per weight version by the weight's owner instead of per call -- same results as the per-call path, bit for
@@ -548,6 +580,31 @@ def test_pooling_and_resize():
         y = fn(xd)
         y.backward(g.to(DEV))
         _check(y, ref, 5e-6, name); _check(xd.grad, x.grad, 5e-6, name + " dx")
+
+
+@pytest.mark.parametrize("shape,out", [((2, 3, 64, 64), (75, 75)), ((1, 2, 256, 256), (299, 299)), ((2, 2, 40, 24), (13, 9)),
+                                       ((1, 1, 30, 30), (7, 200)), ((1, 2, 17, 17), (17, 17))])
+def test_bilinear_resize_backward_gather(shape, out):
+    """mogan_bilinear_bwd in gather form (one thread per input element, no atomics): up-scaling (the 256 -> 299 resize in front
+    of the Inception trunk, model.py:256), down-scaling past the register path's candidate count, and identity, against
+    autograd of F.interpolate in fp64."""
+    x = T("bilg%s%s" % (shape, out), shape).requires_grad_(True)
+    ref = F.interpolate(x.double(), size=out, mode="bilinear", align_corners=False)
+    g = T("bilgg%s%s" % (shape, out), ref.shape)
+    ref.backward(g.double())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.bilinear_resize(xd, out[0], out[1])
+    y.backward(g.to(DEV))
+    # (the source coordinate (o + 0.5) * scale - 0.5 is fp32 arithmetic here as in torch's own float kernels; the reference of
+    # this test is fp64: 2e-5 covers the weight rounding at 256 -> 299)
+    _check(y, ref, 2e-5, "resize"); _check(xd.grad, x.grad, 2e-5, "resize dx")
+    y2 = ops.bilinear_resize(xd, out[0], out[1])
+    xd.grad = None
+    y2.backward(g.to(DEV))
+    g1 = xd.grad.clone()
+    xd.grad = None
+    ops.bilinear_resize(xd, out[0], out[1]).backward(g.to(DEV))
+    assert torch.equal(g1, xd.grad)                                      # deterministic (the scatter form was not)
 
 
 @pytest.mark.parametrize("eps_mode", [0, 1])

@@ -77,10 +77,21 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[t] = 0.f;
         int c = 0;
+        // (round 4: the loads of the NEXT eight channels are in flight while the current eight are multiplied -- with five waves
+        // per CU nothing else hides the L2 round trip, and the loop was one exposed latency per eight channels)
+        float xn[8];
+        if (C >= 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xn[u] = cb[(size_t)u * S + s];
+        }
         for (; c + 8 <= C; c += 8) {
             float xs[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xs[u] = cb[(size_t)(c + u) * S + s];
+            for (int u = 0; u < 8; ++u) xs[u] = xn[u];
+            if (c + 16 <= C) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xn[u] = cb[(size_t)(c + 8 + u) * S + s];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float* wr = L.w + (c + u) * T;
@@ -130,12 +141,32 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
     // wave keeps the sums of word t).
     float dot = 0.f, nwc = 0.f, nw = 0.f;
     constexpr int NW = NT / 64;
+    constexpr int SI = 5;                                    // s-iterations of a wave held in registers (S <= 320)
     for (int c0 = wave; c0 < C; c0 += 2 * NW) {
         const int c1 = c0 + NW;
         const bool two = c1 < C;
         float p[TT], q[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) { p[t] = 0.f; q[t] = 0.f; }
+        if (S <= 64 * SI) {
+            // (round 4) all loads of the channel pair first, then the multiplies: the loop used to wait for one L2 round trip per
+            // 64 regions, 130 times per wave
+            float xv[SI], yv[SI];
+#pragma unroll
+            for (int k = 0; k < SI; ++k) {
+                const int s = lane + 64 * k;
+                xv[k] = s < S ? cb[(size_t)c0 * S + s] : 0.f;
+                yv[k] = (two && s < S) ? cb[(size_t)c1 * S + s] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < SI; ++k) {
+                const int s = lane + 64 * k;
+                if (s < S) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) if (t < Ti) { const float a = L.a[t * SP + s]; p[t] = fmaf(xv[k], a, p[t]); q[t] = fmaf(yv[k], a, q[t]); }
+                }
+            }
+        } else
         for (int s = lane; s < S; s += 64) {
             const float x = cb[(size_t)c0 * S + s], y = two ? cb[(size_t)c1 * S + s] : 0.f;
 #pragma unroll
@@ -242,10 +273,19 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
         for (int t = 0; t < TT; ++t) { da[j][t] = 0.f; av[j][t] = 0.f; }
         if (s < S) {
             int c = 0;
+            float xn[8];                                     // (the next eight channels' loads in flight, as in the forward)
+            if (C >= 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xn[u] = cb[(size_t)u * S + s];
+            }
             for (; c + 8 <= C; c += 8) {
                 float xs[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xs[u] = cb[(size_t)(c + u) * S + s];
+                for (int u = 0; u < 8; ++u) xs[u] = xn[u];
+                if (c + 16 <= C) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xn[u] = cb[(size_t)(c + 8 + u) * S + s];
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const float* wr = L.w + (c + u) * T;

@@ -111,8 +111,8 @@ class D_GET_LOGITS(nn.Module):
 
     def forward(self, h_code, c_code=None):
         if self.bcondition and c_code is not None:
-            c = c_code.reshape(-1, self.cond_dim, 1, 1).expand(-1, self.cond_dim, 4, 4)
-            h_code = torch.cat((h_code, c), 1)
+            h_code = ops.cat_channels([(h_code, "full"), (c_code.reshape(-1, self.cond_dim), "plane")], h_code.shape[0],
+                                      tuple(h_code.shape[2:]))
         return self.outlogits(h_code).view(-1)
 
 
@@ -130,6 +130,22 @@ def _objects_first(t, K):
 def _repeat_batch(t, K):
     """(B, ...) -> (K*B, ...): the same B samples once per object"""
     return t.unsqueeze(0).expand((K,) + tuple(t.shape)).reshape((K * t.shape[0],) + tuple(t.shape[1:]))
+
+
+def _stn_objects(x, theta, K, out_hw, align, plane=False):
+    """the per-object transformer calls of a loop as one object-major batch of K*B samples without materialised inputs
+    (hip/ops.stn_shared; see attngan/model.py:_stn_objects): x is (K*B, C, H, W), (B, C, H, W) -- one image batch shared by the
+    objects -- or, plane, (K*B, C): a label vector standing for its repetition over the plane; theta (B, >= K, 2, 3)"""
+    Bp = theta.shape[0]
+    if theta.shape[1] != K:
+        theta = theta[:, :K].contiguous()
+    in_hw = out_hw if plane else tuple(x.shape[2:])
+    return ops.stn_shared(x, theta, K * Bp, in_hw, out_hw, align, plane=plane, theta_G=K)
+
+
+def _obj(t, K):
+    """(B, >= K, ...) per-object tensor as a part of ops.cat_channels"""
+    return t if t.shape[1] == K else t[:, :K].contiguous()
 
 
 def _tile(vec, size):
@@ -156,8 +172,7 @@ class BBOX_NET(nn.Module):
     def forward(self, labels, transf_matr_inv, max_objects):
         B, K = labels.shape[0], max_objects
         if BATCH_OBJECTS:
-            lab = ops.stn(_tile(_objects_first(labels, K), 16), _objects_first(transf_matr_inv, K), (K * B, self.in_dim, 16, 16),
-                          bool(self.cfg.STN_ALIGN_CORNERS))
+            lab = _stn_objects(_objects_first(labels, K), transf_matr_inv, K, (16, 16), bool(self.cfg.STN_ALIGN_CORNERS), plane=True)
             return self.encode(ops.group_sum(lab, K)).view(B, -1)
         layout = None
         for idx in range(max_objects):
@@ -207,11 +222,13 @@ class STAGE1_G(nn.Module):
         """-> (fake_img, local_labels (B,K,ef))"""
         v, B, K = self.variant, noise.shape[0], max_objects
         if BATCH_OBJECTS:
-            lab = _objects_first(label_one_hot, K)
-            if v.label_net:
-                lab = self.label(lab if c_code is None else torch.cat((_repeat_batch(c_code, K), lab), 1), groups=K)
-            h = self.local2(self.local1(_tile(lab, 4), groups=K), groups=K)
-            h = ops.stn(h, _objects_first(transf_matrices_inv, K), tuple(h.shape), self._align())
+            oh = [(_obj(label_one_hot, K), ("obj", K))]
+            if v.label_net:                                  # (c_code repeated for the K objects) | one-hot, object-major
+                lab = self.label(ops.cat_channels(oh if c_code is None else [(c_code, ("rep", K))] + oh, K * B), groups=K)
+            else:
+                lab = ops.cat_channels(oh, K * B)            # the one-hot labels themselves, object-major
+            h = self.local2(self.local1(ops.cat_channels([(lab, "plane")], K * B, (4, 4)), groups=K), groups=K)
+            h = _stn_objects(h, transf_matrices_inv, K, tuple(h.shape[2:]), self._align())
             canvas = ops.group_sum(h, K)
             local_labels = lab.view(K, B, -1).transpose(0, 1)
         else:
@@ -230,10 +247,10 @@ class STAGE1_G(nn.Module):
         parts = [noise] + ([c_code] if c_code is not None else [])
         if self.cfg.USE_BBOX_LAYOUT:
             parts.append(self.bbox_net(local_labels, transf_matrices_inv, max_objects))
-        z_c_code = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+        z_c_code = parts[0] if len(parts) == 1 else ops.cat_channels([(t, "full") for t in parts], B)
         h_code = self.fc(z_c_code).view(-1, self.gf_dim, 4, 4)
         h_code = self.upsample2(self.upsample1(h_code))
-        h_code = torch.cat((h_code, canvas), 1)
+        h_code = ops.cat_channels([(h_code, "full"), (canvas, "full")], B, tuple(h_code.shape[2:]))
         h_code = self.upsample4(self.upsample3(h_code))
         return self.img(h_code), local_labels
 
@@ -268,9 +285,9 @@ class STAGE1_D(nn.Module):
     def _encode_img(self, image, label, transf_matrices, transf_matrices_inv, max_objects):
         B, v, ndf = image.shape[0], self.variant, self.df_dim
         canvas = self._object_canvas(image, label, transf_matrices, transf_matrices_inv, max_objects, 16)
-        h = ops.act(self.conv1(image), ops.ACT_LRELU, 0.2)
+        h = ops.conv2d_lrelu(image, self.conv1.weight, self.conv1.stride[0], self.conv1.padding, 0.2)
         h = self.bn2.fused(self.conv2(h), ops.ACT_LRELU, 0.2)
-        h = torch.cat((h, canvas), 1)
+        h = ops.cat_channels([(h, "full"), (canvas, "full")], B, tuple(h.shape[2:]))
         h = self.bn3.fused(self.conv3(h), ops.ACT_LRELU, 0.2)
         return self.bn4.fused(self.conv4(h), ops.ACT_LRELU, 0.2)
 
@@ -278,10 +295,11 @@ class STAGE1_D(nn.Module):
         """per object: STN crop + tiled label -> self.local -> STN paste; summed over the objects"""
         B, ndf = image.shape[0], self.df_dim
         if BATCH_OBJECTS:
-            crop = ops.stn(_repeat_batch(image, K), _objects_first(transf_matrices, K), (K * B, image.shape[1], size, size),
-                           self._align())
-            h = self.local(torch.cat((crop, _tile(_objects_first(label, K), size)), 1), groups=K)
-            h = ops.stn(h, _objects_first(transf_matrices_inv, K), (K * B, ndf * 2, size, size), self._align())
+            # every object's crop reads the one image batch; the label rides into the concat as a code repeated over the plane,
+            # straight from the loader's (B, K, label_dim) layout
+            crop = _stn_objects(image, transf_matrices, K, (size, size), self._align())
+            h = self.local(ops.cat_channels([(crop, "full"), (_obj(label, K), ("obj_plane", K))], K * B, (size, size)), groups=K)
+            h = _stn_objects(h, transf_matrices_inv, K, (size, size), self._align())
             return ops.group_sum(h, K)
         canvas = None
         for idx in range(K):
@@ -376,19 +394,18 @@ class STAGE2_G(nn.Module):
                          transf_matrices_inv_s2, label_one_hot, K):
         """the two object loops of S/model.py:380-420 as batches of K*B samples (see BATCH_OBJECTS)"""
         B, ef = c_code.shape[0], self.ef_dim
-        lab = self.label(torch.cat((_repeat_batch(c_code, K), _objects_first(label_one_hot, K)), 1), groups=K)      # (K*B, ef)
-        parts = [encoded_img, _tile(c_code, 16)]
+        lab = self.label(ops.cat_channels([(c_code, ("rep", K)), (_obj(label_one_hot, K), ("obj", K))], K * B), groups=K)   # (K*B, ef)
+        parts = [(encoded_img, "full"), (c_code, "plane")]
         if self.cfg.USE_BBOX_LAYOUT:
-            lay = ops.stn(_tile(lab, 16), _objects_first(transf_matrices_inv, K), (K * B, ef, 16, 16), self._align())
-            parts.append(ops.group_sum(lay, K))
-        h_code = self.residual(self.hr_joint(torch.cat(parts, 1)))
-        patch = ops.stn(_repeat_batch(h_code, K), _objects_first(transf_matrices_s2, K), (K * B, h_code.shape[1], 16, 16),
-                        self._align())
-        h = self.local2(self.local1(torch.cat((patch, _tile(lab, 16)), 1), groups=K), groups=K)
-        h = ops.stn(h, _objects_first(transf_matrices_inv_s2, K), (K * B, self.gf_dim, 64, 64), self._align())
+            lay = _stn_objects(lab, transf_matrices_inv, K, (16, 16), self._align(), plane=True)
+            parts.append((ops.group_sum(lay, K), "full"))
+        h_code = self.residual(self.hr_joint(ops.cat_channels(parts, B, (16, 16))))
+        patch = _stn_objects(h_code, transf_matrices_s2, K, (16, 16), self._align())
+        h = self.local2(self.local1(ops.cat_channels([(patch, "full"), (lab, "plane")], K * B, (16, 16)), groups=K), groups=K)
+        h = _stn_objects(h, transf_matrices_inv_s2, K, (64, 64), self._align())
         canvas = ops.group_sum(h, K)
         h_code = self.upsample2(self.upsample1(h_code))
-        h_code = torch.cat((h_code, canvas), 1)
+        h_code = ops.cat_channels([(h_code, "full"), (canvas, "full")], B, tuple(h_code.shape[2:]))
         h_code = self.upsample4(self.upsample3(h_code))
         return stage1_img, self.img(h_code), mu, logvar, lab.view(K, B, ef).transpose(0, 1)
 
@@ -426,10 +443,10 @@ class STAGE2_D(nn.Module):
     def _encode_img(self, image, label, transf_matrices, transf_matrices_inv, max_objects):
         B, ndf = image.shape[0], self.df_dim
         canvas = STAGE1_D._object_canvas(self, image, label, transf_matrices, transf_matrices_inv, max_objects, 32)
-        h = ops.act(self.conv1(image), ops.ACT_LRELU, 0.2)
+        h = ops.conv2d_lrelu(image, self.conv1.weight, self.conv1.stride[0], self.conv1.padding, 0.2)
         h = self.bn2.fused(self.conv2(h), ops.ACT_LRELU, 0.2)
         h = self.bn3.fused(self.conv3(h), ops.ACT_LRELU, 0.2)
-        h = torch.cat((h, canvas), 1)
+        h = ops.cat_channels([(h, "full"), (canvas, "full")], B, tuple(h.shape[2:]))
         for i in range(4, 9):
             h = getattr(self, "bn%d" % i).fused(getattr(self, "conv%d" % i)(h), ops.ACT_LRELU, 0.2)
         return h

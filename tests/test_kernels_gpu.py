@@ -379,11 +379,12 @@ def test_logits_head_and_conv_lrelu(B, Cin, Cout):
     _check(z, ref, 2e-6, "conv+lrelu"); _check(xid.grad, xi.grad, 5e-6, "conv+lrelu dx"); _check(wid.grad, wi.grad, 5e-6, "conv+lrelu dw")
 
 
-def test_winograd_prepared_filter_planes_follow_the_weight_version():
+def test_winograd_prepared_filter_planes_follow_the_weight_version(monkeypatch):
     """mogan_wino_prep / mogan_conv2d_fwd_wp / _dgrad_wp: the pre-split filter planes of a ResBlock convolution (model.py:67-81)
     built once per weight version by the weight's owner instead of per call -- same results as the per-call path, bit for
     bit (the same kernel on the same planes), rebuilt when the owner bumps the version, and not used for geometries the
-    Winograd kernel does not take."""
+    Winograd kernel does not take.  (Off by default, MOGAN_WINO_PREP: measured slightly slower in the step, hip/ops.py.)"""
+    monkeypatch.setattr(ops, "WINO_PREP", True)
     B, Cin, H, W, Cout = 2, 96, 32, 64, 192
     x, dy = T("wp.x", (B, Cin, H, W)).to(DEV), T("wp.dy", (B, Cout, H, W)).to(DEV)
     w = (T("wp.w", (Cout, Cin, 3, 3)) * 0.1).to(DEV)

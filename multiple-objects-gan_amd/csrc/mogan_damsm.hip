@@ -46,29 +46,6 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Sums of NV per-lane values over the 64 lanes of a wave as a reduce-scatter butterfly (round 4): at every step a lane keeps one
-// half of its values and trades the other half with its partner, so NV - 1 (+ the leftover lane bits) shuffles do what NV
-// separate 6-step butterflies (6 NV shuffles) did.  Returns the total of value j = lane >> (6 - log2 NV); the lanes that share a
-// j all hold it.
-template <int NV>
-__device__ __forceinline__ float wave_reduce_scatter(float (&w)[NV], int lane) {
-    static_assert(NV == 16 || NV == 32 || NV == 64, "NV");
-    constexpr int LG = NV == 16 ? 4 : NV == 32 ? 5 : 6;
-#pragma unroll
-    for (int k = 0; k < LG; ++k) {
-        const int m = 32 >> k, half = NV >> (k + 1);
-        const bool upper = (lane & m) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float send = upper ? w[i] : w[i + half], keep = upper ? w[i + half] : w[i];
-            w[i] = keep + __shfl_xor(send, m, 64);
-        }
-    }
-#pragma unroll
-    for (int m = 32 >> LG; m >= 1; m >>= 1) w[0] += __shfl_xor(w[0], m, 64);
-    return w[0];
-}
-
 // dynamic LDS layout (floats): ws[C*T] word embeddings (or d wc in the backward), a[T*SP] attention image, red[...]
 struct Lds {
     float* w; float* a; float* red;
@@ -86,6 +63,12 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
     Lds L(smem, C, T, SP);
     const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ti = min(T, max(0, lens[i]));
+    // The multiply-add loops run over ALL TT word slots without the `t < Ti` test (round 4): a uniform branch per slot cut the
+    // unrolled loops into hundreds of two-instruction blocks with nothing in flight between them (300 us for 0.2 GFLOP).  Slots
+    // past the caption's length multiply values nobody reads; slots past T re-read slot T - 1 (tcl) so that every address is valid.
+    int tcl[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) tcl[t] = min(t, T - 1);
     const float* cb = ctx + (size_t)b * C * S;
     const float* wi = words + (size_t)i * C * T;
     for (int e = tid; e < C * T; e += NT) {
@@ -119,14 +102,14 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
             for (int u = 0; u < 8; ++u) {
                 const float* wr = L.w + (c + u) * T;
 #pragma unroll
-                for (int t = 0; t < TT; ++t) if (t < Ti) acc[t] = fmaf(xs[u], wr[t], acc[t]);
+                for (int t = 0; t < TT; ++t) acc[t] = fmaf(xs[u], wr[tcl[t]], acc[t]);
             }
         }
         for (; c < C; ++c) {
             const float x = cb[(size_t)c * S + s];
             const float* wr = L.w + c * T;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) if (t < Ti) acc[t] = fmaf(x, wr[t], acc[t]);
+            for (int t = 0; t < TT; ++t) acc[t] = fmaf(x, wr[tcl[t]], acc[t]);
         }
         float m = -INFINITY;
 #pragma unroll
@@ -186,44 +169,36 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
                 const int s = lane + 64 * k;
                 if (s < S) {
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) if (t < Ti) { const float a = L.a[t * SP + s]; p[t] = fmaf(xv[k], a, p[t]); q[t] = fmaf(yv[k], a, q[t]); }
+                    for (int t = 0; t < TT; ++t) { const float a = L.a[tcl[t] * SP + s]; p[t] = fmaf(xv[k], a, p[t]); q[t] = fmaf(yv[k], a, q[t]); }
                 }
             }
         } else
         for (int s = lane; s < S; s += 64) {
             const float x = cb[(size_t)c0 * S + s], y = two ? cb[(size_t)c1 * S + s] : 0.f;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) if (t < Ti) { const float a = L.a[t * SP + s]; p[t] = fmaf(x, a, p[t]); q[t] = fmaf(y, a, q[t]); }
+            for (int t = 0; t < TT; ++t) { const float a = L.a[tcl[t] * SP + s]; p[t] = fmaf(x, a, p[t]); q[t] = fmaf(y, a, q[t]); }
         }
-        // all 2 * TT sums of the pair in one reduce-scatter: value t = channel c0 / word t, value TTP + t = channel c1 / word t;
-        // afterwards the lane group j = lane >> SH holds value j (its first lane acts on it)
-        constexpr int TTP = TT <= 8 ? 8 : TT <= 16 ? 16 : 32, NV = 2 * TTP, SH = NV == 16 ? 2 : NV == 32 ? 1 : 0;
-        float wv_[NV];
+        float mine = 0.f, mine2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) wv_[k] = 0.f;
-#pragma unroll
-        for (int t = 0; t < TT; ++t) { wv_[t] = p[t]; wv_[TTP + t] = q[t]; }
-        const float tot = wave_reduce_scatter<NV>(wv_, lane);
-        {
-            const int j = lane >> SH, ch = j / TTP, t = j - ch * TTP;
-            const bool lead = (lane & ((1 << SH) - 1)) == 0;
-            if (lead && t < T && (ch == 0 || two)) {
-                const int c = ch ? c1 : c0;
-                const float v = t < Ti ? tot : 0.f;
-                wco[(((size_t)b * C + c) * Bc + i) * T + t] = v;           // [b][c][i][t]
-                const float wv = L.w[c * T + t];
-                dot = fmaf(v, wv, dot); nwc = fmaf(v, v, nwc); nw = fmaf(wv, wv, nw);
+        for (int t = 0; t < TT; ++t) {                       // (all TT slots, no `t < Ti` branch: see tcl)
+            const float v = wave_sum(p[t]), v2 = wave_sum(q[t]);
+            if (lane == t) { mine = v; mine2 = v2; }
+        }
+        if (lane < T) {
+            const float v = lane < Ti ? mine : 0.f;
+            wco[(((size_t)b * C + c0) * Bc + i) * T + lane] = v;        // [b][c][i][t]
+            const float wv = L.w[c0 * T + lane];
+            dot = fmaf(v, wv, dot); nwc = fmaf(v, v, nwc); nw = fmaf(wv, wv, nw);
+            if (two) {
+                const float v2 = lane < Ti ? mine2 : 0.f;
+                wco[(((size_t)b * C + c1) * Bc + i) * T + lane] = v2;
+                const float wv2 = L.w[c1 * T + lane];
+                dot = fmaf(v2, wv2, dot); nwc = fmaf(v2, v2, nwc); nw = fmaf(wv2, wv2, nw);
             }
         }
     }
-    {   // the two lanes of word t (channel slot 0 / 1 of the pairs) sit 32 lanes apart
-        constexpr int TTP = TT <= 8 ? 8 : TT <= 16 ? 16 : 32, SH = TTP == 8 ? 2 : TTP == 16 ? 1 : 0;
-        dot += __shfl_xor(dot, 32, 64); nwc += __shfl_xor(nwc, 32, 64); nw += __shfl_xor(nw, 32, 64);
-        const int t = lane >> SH;
-        if (lane < 32 && (lane & ((1 << SH) - 1)) == 0 && t < T) {
-            L.red[(wave * 3 + 0) * TMAX + t] = dot; L.red[(wave * 3 + 1) * TMAX + t] = nwc; L.red[(wave * 3 + 2) * TMAX + t] = nw;
-        }
-    }
+    if (lane < T) { L.red[(wave * 3 + 0) * TMAX + lane] = dot; L.red[(wave * 3 + 1) * TMAX + lane] = nwc;
+                    L.red[(wave * 3 + 2) * TMAX + lane] = nw; }
     __syncthreads();
     if (wave == 0) {
         float e = 0.f;
@@ -252,6 +227,9 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     Lds L(smem, C, T, SP);
     const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ti = min(T, max(0, lens[i]));
+    int tcl[TT];                                             // (see the forward kernel)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) tcl[t] = min(t, T - 1);
     const float* cb = ctx + (size_t)b * C * S;
     const float* wi = words + (size_t)i * C * T;
     const float g = dsim[(size_t)b * Bc + i];
@@ -321,14 +299,14 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
                 for (int u = 0; u < 8; ++u) {
                     const float* wr = L.w + (c + u) * T;
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) if (t < Ti) da[j][t] = fmaf(xs[u], wr[t], da[j][t]);
+                    for (int t = 0; t < TT; ++t) da[j][t] = fmaf(xs[u], wr[tcl[t]], da[j][t]);
                 }
             }
             for (; c < C; ++c) {
                 const float x = cb[(size_t)c * S + s];
                 const float* wr = L.w + c * T;
 #pragma unroll
-                for (int t = 0; t < TT; ++t) if (t < Ti) da[j][t] = fmaf(x, wr[t], da[j][t]);
+                for (int t = 0; t < TT; ++t) da[j][t] = fmaf(x, wr[tcl[t]], da[j][t]);
             }
 #pragma unroll
             for (int t = 0; t < TT; ++t) if (t < Ti) {

@@ -192,14 +192,21 @@ __global__ void bbox_to_theta_kernel(const float* __restrict__ bbox, float* __re
 }
 
 // ------------------------------------------------------------------------------------ attention
+// Round 4: the word projections sit in LDS zero-padded to TMAX slots per channel and every multiply-add loop runs over all
+// TMAX slots -- the `t < T` tests of the earlier form were uniform branches inside the unrolled loops, which left one global
+// load and a dozen FMAs per basic block with nothing in flight between them (61 us per launch against a 20 us HBM bound); the
+// channel loops now issue eight loads before their multiplies.
 template <int TMAX>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ h, const float* __restrict__ src,
                                                        const uint8_t* __restrict__ mask, float* __restrict__ wc,
                                                        float* __restrict__ attn, int B, int idf, int Q, int T,
                                                        int mask_mode) {
-    extern __shared__ __attribute__((aligned(16))) float s_src[];     // [idf][T]
+    extern __shared__ __attribute__((aligned(16))) float s_src[];     // [idf][TMAX], slots >= T are zero
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < idf * T; i += 256) s_src[i] = src[(size_t)b * idf * T + i];
+    for (int i = threadIdx.x; i < idf * TMAX; i += 256) {
+        const int c = i / TMAX, t = i - c * TMAX;
+        s_src[i] = t < T ? src[((size_t)b * idf + c) * T + t] : 0.f;
+    }
     __syncthreads();
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) return;
@@ -207,29 +214,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
     const float* ph = h + (size_t)b * idf * Q + q;
-    for (int c = 0; c < idf; ++c) {
+    int c = 0;
+    for (; c + 8 <= idf; c += 8) {
+        float hv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hv[u] = ph[(size_t)(c + u) * Q];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) s[t] = fmaf(hv[u], s_src[(c + u) * TMAX + t], s[t]);
+    }
+    for (; c < idf; ++c) {
         const float hv = ph[(size_t)c * Q];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < T) s[t] = fmaf(hv, s_src[c * T + t], s[t]);
+        for (int t = 0; t < TMAX; ++t) s[t] = fmaf(hv, s_src[c * TMAX + t], s[t]);
     }
     // reference: mask.repeat(queryL,1) laid over rows b*Q+q  ->  row r uses mask[r % B]  
     const uint8_t* pm = nullptr;
     if (mask) pm = mask + (size_t)(mask_mode == 0 ? (int)(((long long)b * Q + q) % B) : b) * T;
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) if (t < T) { if (pm && pm[t]) s[t] = -INFINITY; m = fmaxf(m, s[t]); }
+    for (int t = 0; t < TMAX; ++t) {
+        bool off = t >= T;
+        if (t < T && pm != nullptr && pm[t] != 0) off = true;
+        if (off) s[t] = -INFINITY;
+        m = fmaxf(m, s[t]);
+    }
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) if (t < T) { s[t] = __expf(s[t] - m); sum += s[t]; }
+    for (int t = 0; t < TMAX; ++t) { s[t] = __expf(s[t] - m); sum += s[t]; }     // (slots >= T: exp(-inf) = 0)
     const float inv = 1.f / sum;
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) if (t < T) { s[t] *= inv; attn[((size_t)b * T + t) * Q + q] = s[t]; }
+    for (int t = 0; t < TMAX; ++t) { s[t] *= inv; if (t < T) attn[((size_t)b * T + t) * Q + q] = s[t]; }
     float* pw = wc + (size_t)b * idf * Q + q;
-    for (int c = 0; c < idf; ++c) {
+    for (int c2 = 0; c2 < idf; ++c2) {
         float a = 0.f;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < T) a = fmaf(s_src[c * T + t], s[t], a);
-        pw[(size_t)c * Q] = a;
+        for (int t = 0; t < TMAX; ++t) a = fmaf(s_src[c2 * TMAX + t], s[t], a);
+        pw[(size_t)c2 * Q] = a;
     }
 }
 
@@ -239,9 +261,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dwc, const float* __restrict__ dattn,
                                                        float* __restrict__ dh, float* __restrict__ dscore, int idf,
                                                        int Q, int T) {
-    extern __shared__ __attribute__((aligned(16))) float s_src[];
+    extern __shared__ __attribute__((aligned(16))) float s_src[];     // [idf][TMAX], slots >= T are zero
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < idf * T; i += 256) s_src[i] = src[(size_t)b * idf * T + i];
+    for (int i = threadIdx.x; i < idf * TMAX; i += 256) {
+        const int c = i / TMAX, t = i - c * TMAX;
+        s_src[i] = t < T ? src[((size_t)b * idf + c) * T + t] : 0.f;
+    }
     __syncthreads();
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) return;
@@ -252,22 +277,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         dp[t] = (t < T && dattn) ? dattn[((size_t)b * T + t) * Q + q] : 0.f;
     }
     const float* pd = dwc + (size_t)b * idf * Q + q;
-    for (int c = 0; c < idf; ++c) {
+    int c = 0;
+    for (; c + 8 <= idf; c += 8) {
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gv[u] = pd[(size_t)(c + u) * Q];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) dp[t] = fmaf(gv[u], s_src[(c + u) * TMAX + t], dp[t]);
+    }
+    for (; c < idf; ++c) {
         const float g = pd[(size_t)c * Q];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < T) dp[t] = fmaf(g, s_src[c * T + t], dp[t]);
+        for (int t = 0; t < TMAX; ++t) dp[t] = fmaf(g, s_src[c * TMAX + t], dp[t]);
     }
     float dot = 0.f;
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) dot = fmaf(p[t], dp[t], dot);
+    for (int t = 0; t < TMAX; ++t) dot = fmaf(p[t], dp[t], dot);           // (p = 0 in the slots >= T)
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) if (t < T) { dp[t] = p[t] * (dp[t] - dot); dscore[((size_t)b * T + t) * Q + q] = dp[t]; }
+    for (int t = 0; t < TMAX; ++t) { dp[t] = p[t] * (dp[t] - dot); if (t < T) dscore[((size_t)b * T + t) * Q + q] = dp[t]; }
     float* po = dh + (size_t)b * idf * Q + q;
-    for (int c = 0; c < idf; ++c) {
+    for (int c2 = 0; c2 < idf; ++c2) {
         float a = 0.f;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < T) a = fmaf(dp[t], s_src[c * T + t], a);
-        po[(size_t)c * Q] = a;
+        for (int t = 0; t < TMAX; ++t) a = fmaf(dp[t], s_src[c2 * TMAX + t], a);
+        po[(size_t)c2 * Q] = a;
     }
 }
 
@@ -339,7 +374,7 @@ int mogan_attn_fwd(const float* h, const float* src, const uint8_t* mask, float*
                    int Q, int T, int mask_mode, hipStream_t stream) {
     if (B <= 0 || idf <= 0 || idf > 128 || Q <= 0 || T <= 0 || T > 32 || B > 65535) return MOGAN_ERR_SHAPE;
     dim3 grid((Q + 255) / 256, B);
-    const size_t sh = (size_t)idf * T * sizeof(float);
+    const size_t sh = (size_t)idf * (T <= 8 ? 8 : T <= 16 ? 16 : 32) * sizeof(float);
     if (T <= 8) hipLaunchKernelGGL((attn_fwd_kernel<8>), grid, dim3(256), sh, stream, h, src, mask, wc, attn, B, idf, Q, T, mask_mode);
     else if (T <= 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(256), sh, stream, h, src, mask, wc, attn, B, idf, Q, T, mask_mode);
     else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(256), sh, stream, h, src, mask, wc, attn, B, idf, Q, T, mask_mode);
@@ -350,7 +385,7 @@ int mogan_attn_bwd(const float* src, const float* attn, const float* dwc, const 
                    float* dscore, int B, int idf, int Q, int T, hipStream_t stream) {
     if (B <= 0 || idf <= 0 || idf > 128 || Q <= 0 || T <= 0 || T > 32 || B > 65535) return MOGAN_ERR_SHAPE;
     dim3 grid((Q + 255) / 256, B);
-    const size_t sh = (size_t)idf * T * sizeof(float);
+    const size_t sh = (size_t)idf * (T <= 8 ? 8 : T <= 16 ? 16 : 32) * sizeof(float);
     if (T <= 8) hipLaunchKernelGGL((attn_bwd_kernel<8>), grid, dim3(256), sh, stream, src, attn, dwc, dattn, dh, dscore, idf, Q, T);
     else if (T <= 16) hipLaunchKernelGGL((attn_bwd_kernel<16>), grid, dim3(256), sh, stream, src, attn, dwc, dattn, dh, dscore, idf, Q, T);
     else hipLaunchKernelGGL((attn_bwd_kernel<32>), grid, dim3(256), sh, stream, src, attn, dwc, dattn, dh, dscore, idf, Q, T);

@@ -242,6 +242,42 @@ int mogan_deep_conv_bn_act_bwd(const float* dz, const float* y, const float* sta
                                int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act, float slope,
                                void* ws, size_t ws_bytes, hipStream_t stream);
 
+/* ---- Frozen CNN_ENCODER trunk on pixel panels (code/coco/attngan/model.py:258-299: Mixed_5b .. Mixed_7c of the frozen, eval-mode
+ * Inception-v3; trainer.py:329-333 sends only the image gradient through it).  With frozen weights every filter is packed ONCE
+ * (mogan_pk_weight_pack of the, where needed zero-padded, filters); activations and gradients travel between the layers as pixel
+ * panels (channels-last bf16 pieces, 192 bytes per pixel and group of 32 channels; a tensor's channel slices start at multiples
+ * of 32), so a convolution is the packed-operand GEMM alone and everything around it -- K-split sum, eval-mode BatchNorm affine,
+ * ReLU / ReLU mask, the 3x3 average pool of the pool branch (moved behind the 1x1 convolution: both are linear), accumulation of a
+ * gradient with several contributors, the fp32 copy and the next layer's panel -- is ONE tail launch per dependency level.
+ *   mogan_pk_group          n <= 8 independent GEMMs in one launch: forward (dgrad = 0: rows = Cout, K = KH*KW*Cp, tap-major) or
+ *                           stride-1 data gradient (dgrad = 1: rows = Cin, K = KH*KW*Cp over the dY panel).  raw receives
+ *                           nsplit slabs of (B, M, outH, outW) fp32; nsplit is in/out (asked for / written).
+ *   mogan_panel_tail_group  n <= 8 slices: v = sum of the sources' slabs; [box: 3x3 mean, zero padding, divisor 9];
+ *                           [v = v * scale[c] + shift[c]]; [relu]; [v += add]; [v = 0 where mask <= 0]; -> dst (fp32, nullable)
+ *                           and the panel slice (nullable; channels n .. roundup32(n) are written as zeros). */
+typedef struct MoganPkArgs {
+    const void* wpk; const void* panel; float* raw;
+    int B, M;                 /* images, rows of the result */
+    int Cp, CGp, cg0;         /* channels of the K range per tap (multiple of 32); channel groups per pixel of the panel; first group */
+    int PH, PW, outH, outW;   /* image dims of the panel / of the result */
+    int KH, KW, stride, ph, pw, dgrad;
+    int nsplit;
+} MoganPkArgs;
+#define MOGAN_TAIL_MAXSRC 3
+typedef struct MoganTailArgs {
+    const float* src[MOGAN_TAIL_MAXSRC]; long long src_bs[MOGAN_TAIL_MAXSRC]; long long src_slab[MOGAN_TAIL_MAXSRC];
+    int src_nsplit[MOGAN_TAIL_MAXSRC]; int nsrc;
+    const float* add; long long add_bs;
+    const float* mask; long long mask_bs;
+    const float* scale; const float* shift;
+    int relu, box;
+    float* dst; long long dst_bs;
+    void* panel; int CGp, cg0;
+    int B, n, H, W;           /* images, channels of the slice, map */
+} MoganTailArgs;
+int mogan_pk_group(int n, MoganPkArgs* args, hipStream_t stream);
+int mogan_panel_tail_group(int n, const MoganTailArgs* args, hipStream_t stream);
+
 /* nn.Upsample(scale_factor=2, mode='nearest') + conv3x3(padding 1, no bias) -- every upBlock of the reference
  * (code/coco/attngan/model.py:48-55, code/coco/stackgan/model.py:16-22) -- evaluated as the TRANSPOSED 4x4
  * stride-2 pad-1 convolution with kernel K = T w T^t, T = [[0,0,1],[0,1,1],[1,1,0],[1,0,0]]: each phase of the

@@ -571,9 +571,10 @@ class FrozenTrunk:
         tp.plan_backward([[bp, a, da], [b, db], [d2], [pool, g1]])    # a/b both add into dT[:, :384], da/db into dU
         return O
 
-    def forward(self, x299):
-        """x299: (B,3,299,299) dense.  -> tape, features (B,768,17,17) = Mixed_6e output, Mixed_7c output (B,2048,8,8)"""
+    def run_stem(self, x299):
+        """Conv2d_1a .. the second max-pool -> (tape, (B,192,35,35) slice)"""
         tp = _Tape(x299.shape[0], x299.device)
+        tp.x299 = x299
         st = self.stem
         cur = _Slice(x299)
         plan = (("Conv2d_1a_3x3", False, True), ("Conv2d_2a_3x3", True, False), ("Conv2d_2b_3x3", True, False), "pool",
@@ -595,12 +596,482 @@ class FrozenTrunk:
                 op.plain = False
             tp.plan_backward([[op]])
             cur = y
+        return tp, cur
+
+    def forward(self, x299):
+        """x299: (B,3,299,299) dense.  -> tape, features (B,768,17,17) = Mixed_6e output, Mixed_7c output (B,2048,8,8)"""
+        tp, cur = self.run_stem(x299)
         feats = None
         for name, kind, fcs in self.blocks:
             cur = _Slice(self._block(tp, kind, fcs, cur))
             if name == "Mixed_6e":
                 feats = cur.t
+        tp.outs = (feats, cur.t)
         return tp, feats, cur.t
+
+    @staticmethod
+    def backward(tp, gfeat, glast):
+        """gradients of the two outputs (None = zero) -> gradient of x299"""
+        feats, last = tp.outs
+        tp.seed(last, glast if glast is not None else torch.zeros_like(last))
+        if gfeat is not None:
+            tp.seed(feats, gfeat)
+        tp.backward()
+        return tp.grad_of(tp.x299)[0]
+
+
+# ======================================================================================================================
+# Panel trunk: the Mixed blocks on the packed-operand GEMM (hip: mogan_pk_group + mogan_panel_tail_group).
+#
+# FrozenTrunk above still splits both operands of every product into bf16 pieces inside the GEMM kernel, launch after launch,
+# although the weights never change and every activation is read by several K-tiles of several convolutions.  Here
+#   * every filter is packed ONCE at load, in both directions (forward: rows = Cout; data gradient: rows = Cin, eval-mode BN scale
+#     folded), zero-padded where a channel slice is not a multiple of 32;
+#   * activations and gradients travel as pixel panels (channels-last bf16 pieces); a tensor's channel slices start at multiples of
+#     32, so concatenation is addressing (cg0) and a convolution reads its slice in place;
+#   * one dependency level of a Mixed block = ONE grouped GEMM launch + ONE tail launch (K-split sum, BN affine + ReLU or ReLU
+#     mask, gradient accumulation, fp32 copy, next panel);
+#   * the pool branch avg_pool(3,1,1) -> 1x1 conv is evaluated as 1x1 conv -> avg_pool (both linear, they commute): the 1x1 joins
+#     the block's first GEMM (one more row range) and the pool runs on 192 instead of 768 channels inside the tail; backward the
+#     same way round (box filter of the slice's gradient, then the shared data-gradient GEMM);
+#   * the four stride-2 convolutions run forward on the packed kernel; their data gradients (odd maps, 3x3 stride 2) and the two
+#     max-pools keep the kernels FrozenTrunk uses, on the fp32 copies.
+# Same arithmetic as FrozenTrunk up to fp32 reassociation (pool/conv order, K-split order); checked against it and the CPU
+# restatement in tests/.
+PANEL_TRUNK = os.environ.get("MOGAN_INCEPTION_PANELS", "1") != "0"
+PANEL_TARGET = int(os.environ.get("MOGAN_PT_TARGET", "512"))          # blocks a grouped GEMM launch aims at (K-split)
+
+
+def _up32(n):
+    return (n + 31) // 32 * 32
+
+
+class _PT:
+    """(B, Cp, H, W): channel slices `sizes` laid out at multiples of 32; fp32 NCHW copy and / or pixel panel"""
+
+    def __init__(self, B, dev, sizes, H, W, f32=True, panel=True):
+        self.sizes, self.H, self.W, self.B = list(sizes), H, W, B
+        self.off, c = [], 0
+        for n in self.sizes:
+            self.off.append(c)
+            c += _up32(n)
+        self.Cp = c
+        self.f32 = torch.empty((B, c, H, W), dtype=torch.float32, device=dev) if f32 is True else (None if f32 is False else f32)
+        self.panel = torch.empty(B * H * W * c * 6, dtype=torch.uint8, device=dev) if panel else None
+        self.written = False                                  # gradient tensors: the fp32 copy holds a contribution already
+
+    def sl(self, i):
+        return _PS(self, self.off[i], self.sizes[i])
+
+    def whole(self):
+        return _PS(self, 0, self.Cp)
+
+
+class _PS:
+    """channels [c0, c0 + n) of a _PT"""
+    __slots__ = ("t", "c0", "n")
+
+    def __init__(self, t, c0, n):
+        self.t, self.c0, self.n = t, c0, n
+
+    @property
+    def f32ptr(self):
+        return self.t.f32.data_ptr() + 4 * self.c0 * self.t.H * self.t.W
+
+    @property
+    def bs(self):
+        return self.t.Cp * self.t.H * self.t.W
+
+
+class _PConv:
+    """one convolution of the panel trunk (or a group of same-input 1x1 ones: rows concatenated): packed filters, folded BN"""
+
+    def __init__(self, mods, dgrad=True):
+        from ..hip.lib import call, load, stream_ptr
+        mods = list(mods)
+        m0 = mods[0].conv
+        self.k, self.stride, self.pad = m0.kernel_size, m0.stride[0], m0.padding
+        for m in mods[1:]:
+            assert m.conv.kernel_size == self.k and m.conv.stride[0] == self.stride and m.conv.padding == self.pad
+        self.couts = [m.conv.weight.shape[0] for m in mods]
+        self.cin = m0.weight.shape[1]
+        self.M, self.cin_p = sum(self.couts), _up32(self.cin)
+        L = load()
+        with torch.no_grad():
+            w = torch.cat([m.conv.weight for m in mods], 0)
+            folded = [m.folded() for m in mods]
+            self.scale = torch.cat([f[0] for f in folded]).contiguous()
+            self.shift = torch.cat([f[1] for f in folded]).contiguous()
+            wf = torch.zeros((self.M, self.cin_p) + tuple(self.k), dtype=torch.float32, device=w.device)
+            wf[:, :self.cin] = w
+            self.wf = torch.empty(L.mogan_pk_weight_bytes(self.M, self.cin_p, self.k[0], self.k[1], 1, 0), dtype=torch.uint8,
+                                  device=w.device)
+            call("mogan_pk_weight_pack", wf.data_ptr(), self.wf.data_ptr(), self.M, self.cin_p, self.k[0], self.k[1], 1,
+                 self.pad[0], self.pad[1], 0, stream_ptr())
+            self.wb = (w * self.scale.view(-1, 1, 1, 1)).contiguous()                 # backward: BN scale folded
+            self.wd, self.Mp = None, sum(_up32(c) for c in self.couts)
+            if dgrad and self.stride == 1:
+                wp = torch.zeros((self.Mp, self.cin) + tuple(self.k), dtype=torch.float32, device=w.device)
+                r, rp = 0, 0
+                for c in self.couts:
+                    wp[rp:rp + c] = self.wb[r:r + c]
+                    r, rp = r + c, rp + _up32(c)
+                self.wd = torch.empty(L.mogan_pk_weight_bytes(self.Mp, self.cin, self.k[0], self.k[1], 1, 1), dtype=torch.uint8,
+                                      device=w.device)
+                call("mogan_pk_weight_pack", wp.data_ptr(), self.wd.data_ptr(), self.Mp, self.cin, self.k[0], self.k[1], 1,
+                     self.pad[0], self.pad[1], 1, stream_ptr())
+                self.wb = None
+            torch.cuda.current_stream().synchronize()                                  # wf / wp die here
+        self.device = w.device
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad[0] - self.k[0]) // self.stride + 1, (W + 2 * self.pad[1] - self.k[1]) // self.stride + 1)
+
+    def rows(self, i):
+        """(first row, rows) of member i of a grouped convolution"""
+        return sum(self.couts[:i]), self.couts[i]
+
+
+class _Raw:
+    """result of one GEMM of a grouped launch: nsplit slabs of (B, M, H, W) fp32"""
+    __slots__ = ("t", "M", "H", "W", "B", "nsplit")
+
+    def __init__(self, B, M, H, W, nsplit, dev):
+        self.t = torch.empty((nsplit, B, M, H, W), dtype=torch.float32, device=dev)
+        self.M, self.H, self.W, self.B, self.nsplit = M, H, W, B, nsplit
+
+    def rows(self, r0=0, n=None):
+        return (self.t.data_ptr() + 4 * r0 * self.H * self.W, self.M * self.H * self.W, self.B * self.M * self.H * self.W, self.nsplit)
+
+
+class _PTape:
+    """launch helpers + the tensors the backward pass needs"""
+
+    def __init__(self, B, dev):
+        self.B, self.dev, self.blocks = B, dev, []
+        self.g = {}
+
+    def new(self, sizes, H, W, f32=True, panel=True):
+        return _PT(self.B, self.dev, sizes, H, W, f32, panel)
+
+    def grad(self, t, f32=True, panel=True):
+        """gradient tensor of forward tensor t (same slices)"""
+        g = self.g.get(id(t))
+        if g is None:
+            g = self.g[id(t)] = _PT(self.B, self.dev, t.sizes, t.H, t.W, f32, panel)
+        return g
+
+    # ---- grouped GEMM: members = [(conv, dgrad, K-range slice, (outH, outW))] -> [_Raw]
+    def gemm(self, members):
+        import ctypes
+        from ..hip.lib import PkArgs, call, stream_ptr
+        tiles, geo = 0, []
+        for fc, dgrad, x, (oh, ow) in members:
+            M = fc.cin if dgrad else fc.M
+            Cp = _up32(x.n)
+            assert x.c0 % 32 == 0 and Cp == (fc.Mp if dgrad else fc.cin_p), (x.c0, x.n, fc.Mp, fc.cin_p, dgrad)
+            tiles += -(-M // 128) * -(-(self.B * oh * ow) // 64)
+            geo.append((M, Cp, fc.k[0] * fc.k[1] * Cp // 32))
+        want = max(1, -(-PANEL_TARGET // tiles)) if tiles < PANEL_TARGET else 1
+        arr = (PkArgs * len(members))()
+        raws = []
+        for i, ((fc, dgrad, x, (oh, ow)), (M, Cp, ntile)) in enumerate(zip(members, geo)):
+            ns = max(1, min(want, ntile // 6))
+            kt_per = -(-(-(-ntile // ns)) // 6) * 6
+            ns = -(-ntile // kt_per)
+            raw = _Raw(self.B, M, oh, ow, ns, self.dev)
+            raws.append(raw)
+            a = arr[i]
+            a.wpk, a.panel, a.raw = (fc.wd if dgrad else fc.wf).data_ptr(), x.t.panel.data_ptr(), raw.t.data_ptr()
+            a.B, a.M, a.Cp, a.CGp, a.cg0 = self.B, M, Cp, x.t.Cp // 32, x.c0 // 32
+            a.PH, a.PW, a.outH, a.outW = x.t.H, x.t.W, oh, ow
+            a.KH, a.KW, a.stride, a.ph, a.pw, a.dgrad, a.nsplit = fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1], 1 if dgrad else 0, ns
+        call("mogan_pk_group", len(members), ctypes.cast(arr, ctypes.c_void_p), stream_ptr())
+        for i, raw in enumerate(raws):
+            assert 1 <= arr[i].nsplit <= raw.nsplit, (arr[i].nsplit, raw.nsplit)
+            raw.nsplit = arr[i].nsplit                                                 # slabs actually written
+        return raws
+
+    # ---- tail: members = dicts(n, H, W, srcs=[(ptr, bs, slab, nsplit)], dst=_PS|None (fp32), panel=_PS|None, ...)
+    def tail(self, members):
+        import ctypes
+        from ..hip.lib import TailArgs, call, stream_ptr
+        for i0 in range(0, len(members), 8):
+            part = members[i0:i0 + 8]
+            arr = (TailArgs * len(part))()
+            for a, m in zip(arr, part):
+                for j, (ptr, bs, slab, ns) in enumerate(m["srcs"]):
+                    a.src[j], a.src_bs[j], a.src_slab[j], a.src_nsplit[j] = ptr, bs, slab, ns
+                a.nsrc = len(m["srcs"])
+                out = m["out"]
+                a.B, a.n, a.H, a.W = self.B, out.n if "n" not in m else m["n"], out.t.H, out.t.W
+                if m.get("add") is not None:
+                    a.add, a.add_bs = m["add"].f32ptr, m["add"].bs
+                if m.get("mask") is not None:
+                    a.mask, a.mask_bs = m["mask"].f32ptr, m["mask"].bs
+                if m.get("scale") is not None:
+                    a.scale, a.shift = m["scale"], m["shift"]
+                a.relu, a.box = int(m.get("relu", 0)), int(m.get("box", 0))
+                if m.get("f32", True) and out.t.f32 is not None:
+                    a.dst, a.dst_bs = out.f32ptr, out.bs
+                if m.get("panel", True) and out.t.panel is not None:
+                    a.panel, a.CGp, a.cg0 = out.t.panel.data_ptr(), out.t.Cp // 32, out.c0 // 32
+            call("mogan_panel_tail_group", len(part), ctypes.cast(arr, ctypes.c_void_p), stream_ptr())
+
+
+def _f32src(s):
+    """a fp32 slice as a tail source"""
+    return (s.f32ptr, s.bs, 0, 1)
+
+
+class PanelTrunk(FrozenTrunk):
+    """Stem as FrozenTrunk (wide maps, few channels: the streaming / Winograd kernels); Mixed_5b .. 7c on pixel panels."""
+
+    def __init__(self, enc):
+        self.stem = {n: _FrozenConv([getattr(enc, n)]) for n in ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3",
+                                                               "Conv2d_3b_1x1", "Conv2d_4a_3x3")}
+        self.blocks = []
+        for name, _ in TRUNK[5:]:
+            blk = getattr(enc, name)
+            g = lambda *names, **kw: _PConv([getattr(blk, n) for n in names], **kw)
+            if isinstance(blk, InceptionA):
+                fcs = dict(g1=g("branch1x1", "branch5x5_1", "branch3x3dbl_1", "branch_pool"), b5=g("branch5x5_2"),
+                           d2=g("branch3x3dbl_2"), d3=g("branch3x3dbl_3"))
+            elif isinstance(blk, InceptionB):
+                fcs = dict(b3=g("branch3x3"), d1=g("branch3x3dbl_1"), d2=g("branch3x3dbl_2"), d3=g("branch3x3dbl_3"))
+            elif isinstance(blk, InceptionC):
+                fcs = dict(g1=g("branch1x1", "branch7x7_1", "branch7x7dbl_1", "branch_pool"), s2=g("branch7x7_2"),
+                           s3=g("branch7x7_3"), d2=g("branch7x7dbl_2"), d3=g("branch7x7dbl_3"), d4=g("branch7x7dbl_4"),
+                           d5=g("branch7x7dbl_5"))
+            elif isinstance(blk, InceptionD):
+                fcs = dict(g1=g("branch3x3_1", "branch7x7x3_1"), b2=g("branch3x3_2"), s2=g("branch7x7x3_2"),
+                           s3=g("branch7x7x3_3"), s4=g("branch7x7x3_4"))
+            else:
+                fcs = dict(g1=g("branch1x1", "branch3x3_1", "branch3x3dbl_1", "branch_pool"), a=g("branch3x3_2a"),
+                           b=g("branch3x3_2b"), d2=g("branch3x3dbl_2"), da=g("branch3x3dbl_3a"), db=g("branch3x3dbl_3b"))
+            self.blocks.append((name, type(blk).__name__, fcs))
+
+    # ---- tail members -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _fwd(raw, fc, i, out, box=0):
+        """rows of member i of (grouped) convolution fc -> BN affine + ReLU -> out (fp32 + panel)"""
+        r0, n = fc.rows(i)
+        return dict(srcs=[raw.rows(r0)], out=out, n=n, scale=fc.scale.data_ptr() + 4 * r0, shift=fc.shift.data_ptr() + 4 * r0, relu=1,
+                    box=box)
+
+    @staticmethod
+    def _bwd(raws, out, mask, add=None, f32=False, panel=True):
+        """sum of data-gradient GEMM results (+ what the fp32 gradient holds already) -> ReLU mask of the input -> out"""
+        return dict(srcs=[r.rows(0) for r in raws], out=out, mask=mask, add=add, f32=f32, panel=panel)
+
+    @staticmethod
+    def _final(raws, dX, xin):
+        """the last contribution to a block input's gradient: + what the fp32 copy holds (seed, max-pool, stride-2 data gradients),
+        ReLU mask of the input -> fp32 + panel"""
+        m = dict(srcs=[r.rows(0) for r in raws], out=dX.whole(), mask=xin, add=dX.whole() if dX.written else None, f32=True)
+        dX.written = True
+        return m
+
+    # ---- blocks: forward runs at once and returns (O, backward closure) --------------------------------------------------
+    def _block(self, tp, kind, f, X):
+        B, H, W = tp.B, X.H, X.W
+        hw = (H, W)
+        xin = X.whole()
+        if kind in ("InceptionA", "InceptionC", "InceptionE"):
+            g1 = f["g1"]
+            n1, npool = g1.couts[0], g1.couts[3]
+            G = tp.new(g1.couts[1:3], H, W)
+            if kind == "InceptionA":
+                O = tp.new([n1, 64, 96, npool], H, W)
+                ipool = 3
+            elif kind == "InceptionC":
+                O = tp.new([192, 192, 192, 192], H, W)
+                ipool = 3
+            else:
+                O = tp.new([320, 384, 384, 384, 384, 192], H, W)
+                ipool = 5
+            (r,) = tp.gemm([(g1, 0, xin, hw)])
+            tp.tail([self._fwd(r, g1, 0, O.sl(0)), self._fwd(r, g1, 1, G.sl(0)), self._fwd(r, g1, 2, G.sl(1)),
+                     self._fwd(r, g1, 3, O.sl(ipool), box=1)])
+            if kind == "InceptionA":
+                U = tp.new([96], H, W)
+                ra, rb = tp.gemm([(f["b5"], 0, G.sl(0), hw), (f["d2"], 0, G.sl(1), hw)])
+                tp.tail([self._fwd(ra, f["b5"], 0, O.sl(1)), self._fwd(rb, f["d2"], 0, U.sl(0))])
+                (rc,) = tp.gemm([(f["d3"], 0, U.sl(0), hw)])
+                tp.tail([self._fwd(rc, f["d3"], 0, O.sl(2))])
+
+                def backward(dO, dX):
+                    DG = tp.new(g1.couts, H, W, f32=False)
+                    dU = tp.new([96], H, W, f32=False)
+                    ra, rc = tp.gemm([(f["b5"], 1, dO.sl(1), hw), (f["d3"], 1, dO.sl(2), hw)])
+                    tp.tail([self._bwd([ra], DG.sl(1), G.sl(0)), self._bwd([rc], dU.sl(0), U.sl(0)),
+                             dict(srcs=[_f32src(dO.sl(0))], out=DG.sl(0)), dict(srcs=[_f32src(dO.sl(3))], out=DG.sl(3), box=1)])
+                    (rb,) = tp.gemm([(f["d2"], 1, dU.sl(0), hw)])
+                    tp.tail([self._bwd([rb], DG.sl(2), G.sl(1))])
+                    (rg,) = tp.gemm([(g1, 1, DG.whole(), hw)])
+                    tp.tail([self._final([rg], dX, xin)])
+            elif kind == "InceptionC":
+                c7 = g1.couts[1]
+                V, W1, W2, W3 = (tp.new([c7], H, W) for _ in range(4))
+                ra, rb = tp.gemm([(f["s2"], 0, G.sl(0), hw), (f["d2"], 0, G.sl(1), hw)])
+                tp.tail([self._fwd(ra, f["s2"], 0, V.sl(0)), self._fwd(rb, f["d2"], 0, W1.sl(0))])
+                ra, rb = tp.gemm([(f["s3"], 0, V.sl(0), hw), (f["d3"], 0, W1.sl(0), hw)])
+                tp.tail([self._fwd(ra, f["s3"], 0, O.sl(1)), self._fwd(rb, f["d3"], 0, W2.sl(0))])
+                (rb,) = tp.gemm([(f["d4"], 0, W2.sl(0), hw)])
+                tp.tail([self._fwd(rb, f["d4"], 0, W3.sl(0))])
+                (rb,) = tp.gemm([(f["d5"], 0, W3.sl(0), hw)])
+                tp.tail([self._fwd(rb, f["d5"], 0, O.sl(2))])
+
+                def backward(dO, dX):
+                    DG = tp.new(g1.couts, H, W, f32=False)
+                    dV, dW1, dW2, dW3 = (tp.new([c7], H, W, f32=False) for _ in range(4))
+                    ra, rb = tp.gemm([(f["s3"], 1, dO.sl(1), hw), (f["d5"], 1, dO.sl(2), hw)])
+                    tp.tail([self._bwd([ra], dV.sl(0), V.sl(0)), self._bwd([rb], dW3.sl(0), W3.sl(0)),
+                             dict(srcs=[_f32src(dO.sl(0))], out=DG.sl(0)), dict(srcs=[_f32src(dO.sl(3))], out=DG.sl(3), box=1)])
+                    ra, rb = tp.gemm([(f["s2"], 1, dV.sl(0), hw), (f["d4"], 1, dW3.sl(0), hw)])
+                    tp.tail([self._bwd([ra], DG.sl(1), G.sl(0)), self._bwd([rb], dW2.sl(0), W2.sl(0))])
+                    (rb,) = tp.gemm([(f["d3"], 1, dW2.sl(0), hw)])
+                    tp.tail([self._bwd([rb], dW1.sl(0), W1.sl(0))])
+                    (rb,) = tp.gemm([(f["d2"], 1, dW1.sl(0), hw)])
+                    tp.tail([self._bwd([rb], DG.sl(2), G.sl(1))])
+                    (rg,) = tp.gemm([(g1, 1, DG.whole(), hw)])
+                    tp.tail([self._final([rg], dX, xin)])
+            else:
+                U = tp.new([384], H, W)
+                ra, rb, rc = tp.gemm([(f["a"], 0, G.sl(0), hw), (f["b"], 0, G.sl(0), hw), (f["d2"], 0, G.sl(1), hw)])
+                tp.tail([self._fwd(ra, f["a"], 0, O.sl(1)), self._fwd(rb, f["b"], 0, O.sl(2)), self._fwd(rc, f["d2"], 0, U.sl(0))])
+                ra, rb = tp.gemm([(f["da"], 0, U.sl(0), hw), (f["db"], 0, U.sl(0), hw)])
+                tp.tail([self._fwd(ra, f["da"], 0, O.sl(3)), self._fwd(rb, f["db"], 0, O.sl(4))])
+
+                def backward(dO, dX):
+                    DG = tp.new(g1.couts, H, W, f32=False)
+                    dU = tp.new([384], H, W, f32=False)
+                    ra, rb, rc, rd = tp.gemm([(f["a"], 1, dO.sl(1), hw), (f["b"], 1, dO.sl(2), hw), (f["da"], 1, dO.sl(3), hw),
+                                              (f["db"], 1, dO.sl(4), hw)])
+                    tp.tail([self._bwd([ra, rb], DG.sl(1), G.sl(0)), self._bwd([rc, rd], dU.sl(0), U.sl(0)),
+                             dict(srcs=[_f32src(dO.sl(0))], out=DG.sl(0)), dict(srcs=[_f32src(dO.sl(5))], out=DG.sl(3), box=1)])
+                    (rb,) = tp.gemm([(f["d2"], 1, dU.sl(0), hw)])
+                    tp.tail([self._bwd([rb], DG.sl(2), G.sl(1))])
+                    (rg,) = tp.gemm([(g1, 1, DG.whole(), hw)])
+                    tp.tail([self._final([rg], dX, xin)])
+            return O, backward
+        import ctypes
+        from ..hip.lib import ConvDgradArgs, call, stream_ptr, workspace
+
+        def old_dgrads(items):
+            """stride-2 data gradients on the fp32 copies: items = [(conv, dy slice, dx slice, ReLU-mask slice, accumulate)]"""
+            arr = (ConvDgradArgs * len(items))(*[
+                ConvDgradArgs(dy.f32ptr, dy.bs, fc.wb.data_ptr(), dx.f32ptr, dx.bs, mk.f32ptr, mk.bs, 1 if acc else 0, B, fc.cin,
+                              mk.t.H, mk.t.W, fc.M, fc.k[0], fc.k[1], fc.stride, fc.pad[0], fc.pad[1])
+                for fc, dy, dx, mk, acc in items])
+            wsp, wsn = workspace(tp.dev)
+            call("mogan_conv2d_dgrad_group", len(items), ctypes.cast(arr, ctypes.c_void_p), wsp, wsn, stream_ptr())
+
+        def maxpool_fwd(dst):
+            idx = torch.empty((B, X.Cp, dst.t.H, dst.t.W), dtype=torch.uint8, device=tp.dev)
+            call("mogan_maxpool_fwd_ex", X.f32.data_ptr(), dst.f32ptr, dst.bs, idx.data_ptr(), B, X.Cp, H, W, 3, 2, stream_ptr())
+            return idx
+
+        def maxpool_bwd(idx, dy, dX):
+            call("mogan_maxpool_bwd_ex", idx.data_ptr(), dy.f32ptr, dy.bs, dX.f32.data_ptr(), X.f32.data_ptr(), 1 if dX.written else 0,
+                 B, X.Cp, H, W, 3, 2, stream_ptr())
+            dX.written = True
+
+        if kind == "InceptionB":
+            ohw = f["b3"].out_hw(H, W)
+            O = tp.new([384, 96, X.Cp], *ohw)
+            T, U = tp.new([64], H, W), tp.new([96], H, W)
+            idx = maxpool_fwd(O.sl(2))
+            ra, rb = tp.gemm([(f["b3"], 0, xin, ohw), (f["d1"], 0, xin, hw)])
+            tp.tail([self._fwd(ra, f["b3"], 0, O.sl(0)), self._fwd(rb, f["d1"], 0, T.sl(0)),
+                     dict(srcs=[_f32src(O.sl(2))], out=O.sl(2), f32=False)])
+            (rb,) = tp.gemm([(f["d2"], 0, T.sl(0), hw)])
+            tp.tail([self._fwd(rb, f["d2"], 0, U.sl(0))])
+            (rb,) = tp.gemm([(f["d3"], 0, U.sl(0), ohw)])
+            tp.tail([self._fwd(rb, f["d3"], 0, O.sl(1))])
+
+            def backward(dO, dX):
+                dU, dT = tp.new([96], H, W), tp.new([64], H, W, f32=False)
+                maxpool_bwd(idx, dO.sl(2), dX)
+                old_dgrads([(f["b3"], dO.sl(0), dX.whole(), xin, True), (f["d3"], dO.sl(1), dU.sl(0), U.sl(0), False)])
+                tp.tail([dict(srcs=[_f32src(dU.sl(0))], out=dU.sl(0), f32=False)])
+                (rb,) = tp.gemm([(f["d2"], 1, dU.sl(0), hw)])
+                tp.tail([self._bwd([rb], dT.sl(0), T.sl(0))])
+                (rb,) = tp.gemm([(f["d1"], 1, dT.sl(0), hw)])
+                tp.tail([self._final([rb], dX, xin)])
+            return O, backward
+        # InceptionD
+        g1 = f["g1"]
+        ohw = f["b2"].out_hw(H, W)
+        O = tp.new([320, 192, X.Cp], *ohw)
+        G, V1, V2 = tp.new([192, 192], H, W), tp.new([192], H, W), tp.new([192], H, W)
+        idx = maxpool_fwd(O.sl(2))
+        (r,) = tp.gemm([(g1, 0, xin, hw)])
+        tp.tail([self._fwd(r, g1, 0, G.sl(0)), self._fwd(r, g1, 1, G.sl(1)), dict(srcs=[_f32src(O.sl(2))], out=O.sl(2), f32=False)])
+        ra, rb = tp.gemm([(f["b2"], 0, G.sl(0), ohw), (f["s2"], 0, G.sl(1), hw)])
+        tp.tail([self._fwd(ra, f["b2"], 0, O.sl(0)), self._fwd(rb, f["s2"], 0, V1.sl(0))])
+        (rb,) = tp.gemm([(f["s3"], 0, V1.sl(0), hw)])
+        tp.tail([self._fwd(rb, f["s3"], 0, V2.sl(0))])
+        (rb,) = tp.gemm([(f["s4"], 0, V2.sl(0), ohw)])
+        tp.tail([self._fwd(rb, f["s4"], 0, O.sl(1))])
+
+        def backward(dO, dX):
+            DG, dV2, dV1 = tp.new([192, 192], H, W), tp.new([192], H, W), tp.new([192], H, W, f32=False)
+            maxpool_bwd(idx, dO.sl(2), dX)
+            old_dgrads([(f["b2"], dO.sl(0), DG.sl(0), G.sl(0), False), (f["s4"], dO.sl(1), dV2.sl(0), V2.sl(0), False)])
+            tp.tail([dict(srcs=[_f32src(DG.sl(0))], out=DG.sl(0), f32=False), dict(srcs=[_f32src(dV2.sl(0))], out=dV2.sl(0), f32=False)])
+            (rb,) = tp.gemm([(f["s3"], 1, dV2.sl(0), hw)])
+            tp.tail([self._bwd([rb], dV1.sl(0), V1.sl(0))])
+            (rb,) = tp.gemm([(f["s2"], 1, dV1.sl(0), hw)])
+            tp.tail([self._bwd([rb], DG.sl(1), G.sl(1))])
+            (rg,) = tp.gemm([(g1, 1, DG.whole(), hw)])
+            tp.tail([self._final([rg], dX, xin)])
+        return O, backward
+
+    def forward(self, x299):
+        """x299: (B,3,299,299) dense.  -> (stem tape, panel tape), features (B,768,17,17) = Mixed_6e output, Mixed_7c output"""
+        tp, cur = self.run_stem(x299)
+        pt = _PTape(x299.shape[0], x299.device)
+        X = _PT(pt.B, pt.dev, [cur.C], cur.H, cur.W, f32=cur.t)
+        pt.tail([dict(srcs=[_f32src(X.sl(0))], out=X.sl(0), f32=False)])
+        pt.stem_out, pt.chain = cur.t, []
+        feats = None
+        for name, kind, fcs in self.blocks:
+            O, bwd = self._block(pt, kind, fcs, X)
+            pt.chain.append((X, O, bwd))
+            X = O
+            if name == "Mixed_6e":
+                feats = O
+        pt.feats, pt.last = feats, X
+        return (tp, pt), feats.f32, X.f32
+
+    @staticmethod
+    def backward(tapes, gfeat, glast):
+        """gradients of the two outputs (None = zero) -> gradient of x299"""
+        tp, pt = tapes
+        for out, g in ((pt.last, glast), (pt.feats, gfeat)):
+            d = pt.grad(out)
+            if g is None:
+                d.f32.zero_()
+                if out is pt.last:
+                    d.panel.zero_()
+            else:
+                g = g.contiguous()
+                gs = (g.data_ptr(), g.stride(0), 0, 1)
+                # the seed is the gradient's first contribution: ReLU mask of the output; Mixed_7c's has no other one -> panel too
+                pt.tail([dict(srcs=[gs], out=d.whole(), mask=out.whole(), panel=out is pt.last)])
+            d.written = True
+        for X, O, bwd in reversed(pt.chain):
+            dO = pt.grad(O)
+            if X.f32 is pt.stem_out:                         # the first block: its input gradient goes on into the stem's tape
+                g, written = tp.grad_of(pt.stem_out)
+                written.add((0, X.Cp))
+                dX = _PT(pt.B, pt.dev, X.sizes, X.H, X.W, f32=g, panel=False)
+            else:
+                dX = pt.grad(X)
+            bwd(dO, dX)
+        tp.backward()
+        return tp.grad_of(tp.x299)[0]
 
 
 class _FrozenTrunkFn(torch.autograd.Function):
@@ -608,18 +1079,12 @@ class _FrozenTrunkFn(torch.autograd.Function):
     def forward(ctx, x299, trunk):
         xc = x299.contiguous()
         tp, feats, last = trunk.forward(xc)
-        ctx.tape, ctx.x, ctx.outs = tp, xc, (feats, last)
+        ctx.tape, ctx.trunk = tp, trunk
         return feats, last
 
     @staticmethod
     def backward(ctx, gfeat, glast):
-        tp = ctx.tape
-        feats, last = ctx.outs
-        tp.seed(last, glast if glast is not None else torch.zeros_like(last))
-        if gfeat is not None:
-            tp.seed(feats, gfeat)
-        tp.backward()
-        g, _ = tp.grad_of(ctx.x)
+        g = ctx.trunk.backward(ctx.tape, gfeat, glast)
         ctx.tape = None
         return g, None
 
@@ -628,7 +1093,9 @@ def frozen_trunk(enc, x299):
     """(features 768x17x17, Mixed_7c output 2048x8x8) of the frozen eval-mode trunk of `enc` (a CNN_ENCODER)."""
     ft = getattr(enc, "_frozen_trunk", None)
     key = _versions(*[t for t in list(enc.parameters()) + list(enc.buffers()) if t.is_floating_point()])
-    if ft is None or getattr(enc, "_frozen_trunk_key", None) != key or ft.stem["Conv2d_1a_3x3"].w.device != x299.device:
-        ft = enc._frozen_trunk = FrozenTrunk(enc)
+    cls = PanelTrunk if PANEL_TRUNK else FrozenTrunk
+    if ft is None or type(ft) is not cls or getattr(enc, "_frozen_trunk_key", None) != key \
+            or ft.stem["Conv2d_1a_3x3"].w.device != x299.device:
+        ft = enc._frozen_trunk = cls(enc)
         enc._frozen_trunk_key = key
     return _FrozenTrunkFn.apply(x299, ft)

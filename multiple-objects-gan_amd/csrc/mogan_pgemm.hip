@@ -54,7 +54,8 @@ struct PkP {
     long long slab;
     int accumulate;
     int dgrad, ncls;
-    int Cc, CG;                  // channels of the pixel panel, Cc / 32
+    int Cc, CG;                  // channels of the K range (one tap), Cc / 32
+    int CGp, cg0;                // channel groups of a pixel in the panel, first group of the K range's slice
     int PH, PW;                  // image dims of the pixel panel
     int RH, RW;                  // rows n -> (img, r, c) with r < RH, c < RW
     int s, ph, pw, nkw;          // nkw: taps per class along x (tap = ta * nkw + tb)
@@ -71,8 +72,8 @@ __device__ __forceinline__ uint4 ldg16(__amdgpu_buffer_rsrc_t r, unsigned off, b
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : 0xFFFFFFF0u, 0, 0));
 }
 
-template <int TM, int TN, int OCC>
-__global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) {
+template <int TM, int TN>
+__device__ __forceinline__ void pgemm_body(const PkP& p, unsigned V, const unsigned nblk) {
     constexpr int BM = 4 * TM * 32, BN = TN * 32, RS = 208;
     constexpr int NCH = BN * 12 / 256;                 // 16-byte chunks of the pixel panel tile per thread and K-tile
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * RS];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // block -> (n-tile, class, m-tile, K-split); n fastest, then the class: the blocks that stream the same weight rows
     // (the n-tiles; for a strided data gradient the classes read interleaved taps of the same filters) sit on one XCD
-    unsigned V = xcd_order(blockIdx.x, gridDim.x);
+    V = xcd_order(V, nblk);
     const unsigned bx = V % p.gx; V /= p.gx;
     const unsigned cls = V % p.ncls; V /= p.ncls;
     const unsigned by = V % p.gy;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) {
         ldso[i] = row * RS + ch * 16;
         cho[i] = ch * 16;                                  // the same offset inside the pixel's 192-byte group
     }
-    const unsigned pixb = (unsigned)p.Cc * 6u;          // bytes per pixel in the panel
+    const unsigned pixb = (unsigned)p.CGp * 192u;       // bytes per pixel in the panel
     const int sgn = p.dgrad ? -1 : 1;
 
     // weight stream of this wave: m-tile mt -> byte offset of its k-step 0, plus this lane's 16 bytes
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) {
         const int tap = t / p.CG, cg = t - tap * p.CG;           // uniform
         const int ta = tap / p.nkw, tb = tap - ta * p.nkw;
         const int dy = sgn * ta, dx = sgn * tb;
-        const unsigned goff = (unsigned)cg * 192u;
+        const unsigned goff = (unsigned)(p.cg0 + cg) * 192u;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int iy = ry[i] + dy, ix = rx[i] + dx;
@@ -271,6 +272,24 @@ __global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) {
             }
         }
     }
+}
+
+template <int TM, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) { pgemm_body<TM, TN>(p, blockIdx.x, gridDim.x); }
+
+// Several independent GEMMs (own weights, panels, geometry and K-split; one tile shape) as ONE launch: the members' blocks lie
+// end to end on the 1-D grid.  The frozen Inception trunk (attngan/inception.py) issues the convolutions of one dependency level
+// of a Mixed block this way: 1-5 GFLOP each at B = 16, none of which fills 256 CUs alone.
+constexpr int PK_MAXG = 8;
+struct PkGroup { PkP p[PK_MAXG]; unsigned end[PK_MAXG]; int n; };
+
+template <int TM, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void pgemm_group_kernel(const PkGroup g) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 0; i < PK_MAXG - 1; ++i) if (i + 1 < g.n && blockIdx.x >= g.end[i]) pi = i + 1;
+    const unsigned start = pi ? g.end[pi - 1] : 0u;
+    pgemm_body<TM, TN>(g.p[pi], blockIdx.x - start, g.end[pi] - start);
 }
 
 // ------------------------------------------------------------------------------------------------ pack kernels
@@ -699,6 +718,7 @@ struct PkCfg { int tm, tn; };
 static const PkCfg kPk[] = {{1, 2}, {1, 4}, {2, 2}};
 enum { NPK = 3 };
 static int g_pk_cfg = -1, g_pk_split = 0;
+static inline int a_prof_mode(int dgrad) { return dgrad ? 11 : 10; }    // launch-profile modes of the grouped launches
 
 // OCC = waves per SIMD the register allocation is held to (512 / OCC registers per lane)
 template <int TM, int TN, int OCC>
@@ -818,7 +838,7 @@ static int pk_fwd_from_panel(const void* panel, const void* wpk, float* y, int B
     p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)panel; p.C = y;
     p.M = Cout; p.N = B * OH * OW; p.K = g.K; p.Mt = g.Mt; p.KS = g.KS; p.a_cls_stride = g.cls_bytes;
     p.a_bytes = (unsigned)g.cls_bytes; p.p_bytes = (unsigned)pbytes; p.ntile = g.K / 32; p.slab = (long long)B * Cout * OH * OW;
-    p.accumulate = accumulate; p.dgrad = 0; p.ncls = 1; p.Cc = Cin; p.CG = Cin / 32; p.PH = Hs; p.PW = Ws; p.RH = OH; p.RW = OW;
+    p.accumulate = accumulate; p.dgrad = 0; p.ncls = 1; p.Cc = Cin; p.CG = Cin / 32; p.CGp = Cin / 32; p.cg0 = 0; p.PH = Hs; p.PW = Ws; p.RH = OH; p.RW = OW;
     p.s = stride; p.ph = ph; p.pw = pw; p.nkw = KW; p.outH = OH; p.outW = OW;
     const int rc = run_pk(p, ws, ws_bytes, prof_mode, stream, keep_slabs);
     if (nsplit_out) *nsplit_out = p.nsplit;
@@ -836,7 +856,7 @@ static int pk_dgrad_from_panel(const void* panel, const void* wpk, float* dx, in
     p.A = (const unsigned char*)wpk; p.P = (const unsigned char*)panel; p.C = dx;
     p.M = Cin; p.N = B * (Hs / stride) * (Ws / stride); p.K = g.K; p.Mt = g.Mt; p.KS = g.KS; p.a_cls_stride = g.cls_bytes;
     p.a_bytes = (unsigned)g.cls_bytes; p.p_bytes = (unsigned)pbytes; p.ntile = g.K / 32; p.slab = (long long)B * Cin * Hs * Ws;
-    p.accumulate = 0; p.dgrad = 1; p.ncls = stride * stride; p.Cc = Cout; p.CG = Cout / 32; p.PH = OH; p.PW = OW;
+    p.accumulate = 0; p.dgrad = 1; p.ncls = stride * stride; p.Cc = Cout; p.CG = Cout / 32; p.CGp = Cout / 32; p.cg0 = 0; p.PH = OH; p.PW = OW;
     p.RH = Hs / stride; p.RW = Ws / stride; p.s = stride; p.ph = ph; p.pw = pw; p.nkw = g.nkw; p.outH = Hs; p.outW = Ws;
     return run_pk(p, ws, ws_bytes, 8, stream);
 }
@@ -929,6 +949,44 @@ int mogan_conv2d_wgrad_pk(const float* dy, const float* x, float* dw, int B, int
     // dW (Cout x R) = "1x1 convolution" of the R-pixel, Kpad-channel panel with the Cout x Kpad "filters" dY
     return pk_fwd_from_panel(P, A, dw, 1, Kpad, (int)R, 1, Cout, 1, 1, 1, 0, 0, (char*)ws + ab + pb, ws_bytes - ab - pb, stream, false,
                              nullptr, accumulate, 9);
+}
+
+int mogan_pk_group(int n, MoganPkArgs* args, hipStream_t stream) {
+    if (n <= 0 || n > PK_MAXG || !args) return MOGAN_ERR_SHAPE;
+    PkGroup g{};
+    g.n = n;
+    long long end = 0; double flops = 0;
+    for (int i = 0; i < n; ++i) {
+        const MoganPkArgs& a = args[i];
+        if (!a.wpk || !a.panel || !a.raw || a.B <= 0 || a.M <= 0 || a.Cp <= 0 || a.Cp % 32 || a.cg0 < 0 || a.cg0 + a.Cp / 32 > a.CGp ||
+            a.KH <= 0 || a.KW <= 0 || a.KH * a.KW > 25 || a.stride <= 0 || (a.dgrad && a.stride != 1) || a.PH <= 0 || a.PW <= 0 ||
+            a.outH <= 0 || a.outW <= 0 || a.nsplit <= 0)
+            return MOGAN_ERR_SHAPE;
+        const size_t pbytes = (size_t)a.B * a.PH * a.PW * a.CGp * 192;
+        const long long slab = (long long)a.B * a.M * a.outH * a.outW;
+        PkP& p = g.p[i];
+        p.A = (const unsigned char*)a.wpk; p.P = (const unsigned char*)a.panel; p.C = a.raw; p.ws = a.raw;
+        p.M = a.M; p.N = a.B * a.outH * a.outW; p.K = a.KH * a.KW * a.Cp; p.Mt = (int)cdiv(p.M, 32); p.KS = p.K / 16;
+        const unsigned long long abytes = (unsigned long long)p.Mt * p.KS * 3072ull;
+        if (pbytes >= (1ull << 32) || abytes >= (1ull << 32) || slab >= (1ll << 31)) return MOGAN_ERR_SHAPE;
+        p.a_cls_stride = abytes; p.a_bytes = (unsigned)abytes; p.p_bytes = (unsigned)pbytes; p.ntile = p.K / 32; p.slab = slab;
+        p.accumulate = 0; p.dgrad = a.dgrad; p.ncls = 1; p.Cc = a.Cp; p.CG = a.Cp / 32; p.CGp = a.CGp; p.cg0 = a.cg0;
+        p.PH = a.PH; p.PW = a.PW; p.RH = a.outH; p.RW = a.outW; p.s = a.stride; p.ph = a.ph; p.pw = a.pw; p.nkw = a.KW;
+        p.outH = a.outH; p.outW = a.outW;
+        p.gx = (int)cdiv(p.N, 64); p.gy = (int)cdiv(p.M, 128);
+        p.kt_per = (int)cdiv(cdiv(p.ntile, std::min(a.nsplit, p.ntile)), PK_TRIP) * PK_TRIP;
+        while (cdiv(p.ntile, p.kt_per) > a.nsplit) p.kt_per += PK_TRIP;            // never more slabs than the caller made room for
+        p.nsplit = (int)cdiv(p.ntile, p.kt_per);
+        args[i].nsplit = p.nsplit;
+        end += (long long)p.gx * p.gy * p.nsplit;
+        if (end > 0x7fffffff) return MOGAN_ERR_SHAPE;
+        g.end[i] = (unsigned)end;
+        flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+    }
+    mogan_prof_begin(a_prof_mode(args[0].dgrad), 0, flops, g.p[0].M, g.p[0].N, g.p[0].K, stream);
+    hipLaunchKernelGGL((pgemm_group_kernel<1, 2, 3>), dim3((unsigned)end), dim3(256), 0, stream, g);
+    mogan_prof_end(1, stream);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 
 size_t mogan_pk_panel_bytes(int B, int C, int HW) { return (B > 0 && C > 0 && HW > 0) ? (size_t)B * HW * C * 6 : 0; }

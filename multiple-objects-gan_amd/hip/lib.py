@@ -111,6 +111,8 @@ SIGNATURES = {
     "mogan_conv2d_dgrad_ex": [P, L, P, P, L, P, L, I] + [I] * 10 + [P, Z, P],
     "mogan_conv2d_affine_fwd_group": [I, P, P, Z, P],
     "mogan_conv2d_dgrad_group": [I, P, P, Z, P],
+    "mogan_pk_group": [I, P, P],
+    "mogan_panel_tail_group": [I, P, P],
     "mogan_maxpool_fwd_ex": [P, P, L, P, I, I, I, I, I, I, P],
     "mogan_maxpool_bwd_ex": [P, P, L, P, P, I, I, I, I, I, I, I, P],
     "mogan_avgpool_bwd_ex": [P, P, P, I, I, I, I, I, I, I, P],
@@ -138,6 +140,17 @@ class ConvFwdArgs(ctypes.Structure):            # MoganConvFwdArgs (include/moga
 class ConvDgradArgs(ctypes.Structure):          # MoganConvDgradArgs
     _fields_ = [("dy", P), ("dy_bstride", L), ("w", P), ("dx", P), ("dx_bstride", L), ("relu_of", P), ("relu_bstride", L),
                 ("accumulate", I)] + [(k, I) for k in ("B", "Cin", "Hs", "Ws", "Cout", "KH", "KW", "stride", "ph", "pw")]
+
+
+class PkArgs(ctypes.Structure):                 # MoganPkArgs
+    _fields_ = [("wpk", P), ("panel", P), ("raw", P)] + [(k, I) for k in ("B", "M", "Cp", "CGp", "cg0", "PH", "PW", "outH", "outW",
+                                                                       "KH", "KW", "stride", "ph", "pw", "dgrad", "nsplit")]
+
+
+class TailArgs(ctypes.Structure):               # MoganTailArgs
+    _fields_ = [("src", P * 3), ("src_bs", L * 3), ("src_slab", L * 3), ("src_nsplit", I * 3), ("nsrc", I), ("add", P), ("add_bs", L),
+                ("mask", P), ("mask_bs", L), ("scale", P), ("shift", P), ("relu", I), ("box", I), ("dst", P), ("dst_bs", L),
+                ("panel", P), ("CGp", I), ("cg0", I), ("B", I), ("n", I), ("H", I), ("W", I)]
 
 
 _RESTYPE = {"mogan_wino_prep_bytes": Z, "mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z}

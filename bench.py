@@ -12,8 +12,9 @@ Adam), generator_loss incl. Inception + DAMSM words/sentence losses + KL, backwa
 fp32 everywhere, random-init networks of the full coco_train.yml widths, inputs resident in HBM.
 W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize();
 elapsed = MAX over ranks; rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      dominant kernel family by time (gemm_kernel, the implicit GEMM; since round 3 the weight-heavy layers run on
-                pgemm_kernel, listed under `families` and summed with it under `implicit_gemm_layers`): algorithmic fp32 flops per launch (2*M*N*K
+  roofline      dominant MFMA kernel family by time (round 4: the implicit GEMM runs as gemm_kernel, the weight-heavy layers as
+                pgemm_kernel, the frozen Inception trunk as pgemm_group_kernel; all listed under `families`, their sum under
+                `implicit_gemm_layers`): algorithmic fp32 flops per launch (2*M*N*K
                 of the true GEMM dims) / average launch duration measured live with HIP events on the launch
                 stream (mogan_prof_*).  `peak` = the matrix-pipe peak of the form the library computes fp32
                 products in (mogan_mfma_form): split-bf16 = 2500 TFLOP/s dense bf16 / 6 partial products per
@@ -172,14 +173,16 @@ def roofline_leg(engine, run_step, steps=2):
     rows = []
     for i in range(n):
         m, c, launches, flops, ms = buf[5 * i:5 * i + 5]
-        if int(m) >= 7:         # packed-weight path of the deep discriminator layers (csrc/mogan_pgemm.hip)
+        if int(m) >= 10:        # grouped launches of the same GEMM: the frozen Inception trunk on pixel panels (attngan/inception.py)
+            name = "pgemm_group_kernel<%s,%s>" % ({10: "fwd", 11: "dgrad"}[int(m)], ("128x64", "64x128")[int(c)])
+        elif int(m) >= 7:       # packed-weight path of the deep discriminator layers (csrc/mogan_pgemm.hip)
             name = "pgemm_kernel<%s,%s>" % ({7: "fwd", 8: "dgrad", 9: "wgrad"}[int(m)], ("128x64", "128x128", "256x64")[int(c)])
         elif m < 4:
             name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)])
         elif int(m) == 6:
             name = "wino_wgrad_kernel" if int(c) == 1 else "dconv_wgrad_kernel"
         elif int(c) == 1:       # fused Winograd F(2x2,3x3): flops = the 16/36 of the direct multiplies it executes
-            name = "wino_fwd_kernel<%s>" % MODES[int(m)][6:]
+            name = "wino3_fwd_kernel<%s>" % MODES[int(m)][6:]
         else:
             name = "dconv_fwd_kernel<%s>" % MODES[int(m)][6:]
         rows.append(dict(kernel=name,
@@ -589,7 +592,7 @@ def main():
         # the implicit-GEMM layer set of rounds 1-2 (everything the direct / Winograd kernels do not take) is served by two
         # kernels since round 3: gemm_kernel (gathers and splits fp32 operands) and pgemm_kernel (packed weights); their sum is
         # the figure comparable with the earlier rounds' gemm_kernel family
-        ig = [fams[k] for k in ("gemm_kernel", "pgemm_kernel") if k in fams]
+        ig = [fams[k] for k in ("gemm_kernel", "pgemm_kernel", "pgemm_group_kernel") if k in fams]
         ig_ms, ig_gf = sum(a["ms_per_step"] for a in ig), sum(a["gflop_per_step"] for a in ig)
         tot_ms = sum(r["ms_per_step"] for r in rows)
         tot_gf = sum(r["gflop_per_step"] for r in rows)
@@ -600,7 +603,7 @@ def main():
             "launches_per_step": dom["launches_per_step"],
             "avg_launch_ms": dom["ms_per_step"] / dom["launches_per_step"],
             "gflop_per_launch": dom["gflop_per_step"] / dom["launches_per_step"],
-            "implicit_gemm_layers": {"kernels": "gemm_kernel + pgemm_kernel", "gflop_per_step": ig_gf, "ms_per_step": ig_ms,
+            "implicit_gemm_layers": {"kernels": "gemm_kernel + pgemm_kernel + pgemm_group_kernel", "gflop_per_step": ig_gf, "ms_per_step": ig_ms,
                                      "achieved": ig_gf / ig_ms if ig_ms else 0.0, "frac": (ig_gf / ig_ms) / peak if ig_ms else 0.0},
             "families": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()}
                          for a in sorted(fams.values(), key=lambda a: -a["ms_per_step"])],

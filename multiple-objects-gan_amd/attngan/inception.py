@@ -639,7 +639,9 @@ class FrozenTrunk:
 # Same arithmetic as FrozenTrunk up to fp32 reassociation (pool/conv order, K-split order); checked against it and the CPU
 # restatement in tests/.
 PANEL_TRUNK = os.environ.get("MOGAN_INCEPTION_PANELS", "1") != "0"
-PANEL_TARGET = int(os.environ.get("MOGAN_PT_TARGET", "512"))          # blocks a grouped GEMM launch aims at (K-split)
+# blocks a grouped GEMM launch aims at (K-split).  Measured in the B = 16 step: 256 / 128 / none 407 img/s, 512 404-405, 768 402 (alone
+# on the GPU the launches are fastest at 512: 3.0 vs 3.5 ms per step at 128)
+PANEL_TARGET = int(os.environ.get("MOGAN_PT_TARGET", "256"))
 
 
 def _up32(n):

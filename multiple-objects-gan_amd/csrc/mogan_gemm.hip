@@ -1045,17 +1045,20 @@ int mogan_prof_dump(const char* path) {
 // out: rows of 5 doubles {mode, cfg, launches, algorithmic flops, milliseconds}, one per (mode,cfg) seen
 int mogan_prof_collect(double* out, int max_rows) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    double acc[10][NCFG][3] = {};
+    constexpr int NMODE = 12;             // 0-6 implicit GEMM / direct / Winograd, 7-9 packed-operand GEMM, 10-11 its grouped launches
+    double acc[NMODE][NCFG][3] = {};
     for (auto& r : g_prof) {
         hipEventSynchronize(r.e1);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
-        acc[r.mode][r.cfg][0] += 1; acc[r.mode][r.cfg][1] += r.flops; acc[r.mode][r.cfg][2] += ms;
+        if (r.mode >= 0 && r.mode < NMODE && r.cfg >= 0 && r.cfg < NCFG) {
+            acc[r.mode][r.cfg][0] += 1; acc[r.mode][r.cfg][1] += r.flops; acc[r.mode][r.cfg][2] += ms;
+        }
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
     }
     g_prof.clear();
     int n = 0;
-    for (int m = 0; m < 10; ++m)
+    for (int m = 0; m < NMODE; ++m)
         for (int c = 0; c < NCFG; ++c)
             if (acc[m][c][0] > 0 && n < max_rows) {
                 double* o = out + 5 * n++;

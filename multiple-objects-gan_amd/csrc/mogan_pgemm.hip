@@ -72,13 +72,18 @@ __device__ __forceinline__ uint4 ldg16(__amdgpu_buffer_rsrc_t r, unsigned off, b
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : 0xFFFFFFF0u, 0, 0));
 }
 
-template <int TM, int TN>
+// WM x WN waves (WM * WN = 4): wave (wm, wn) owns rows [wm*TM*32, ..) x columns [wn*TN*32, ..) of the (WM*TM*32) x (WN*TN*32) block
+// tile.  WM = 4: every weight byte is read by one wave of the block (the deep D layers: many rows, few columns); WM = 2: 64-row
+// tiles for the frozen trunk's convolutions with 48..192 filters, whose last 128-row tile would be up to 62 % padding.
+template <int TM, int TN, int WM = 4>
 __device__ __forceinline__ void pgemm_body(const PkP& p, unsigned V, const unsigned nblk) {
-    constexpr int BM = 4 * TM * 32, BN = TN * 32, RS = 208;
+    constexpr int WN = 4 / WM;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, RS = 208;
     constexpr int NCH = BN * 12 / 256;                 // 16-byte chunks of the pixel panel tile per thread and K-tile
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
     // block -> (n-tile, class, m-tile, K-split); n fastest, then the class: the blocks that stream the same weight rows
     // (the n-tiles; for a strided data gradient the classes read interleaved taps of the same filters) sit on one XCD
     V = xcd_order(V, nblk);
@@ -119,7 +124,7 @@ __device__ __forceinline__ void pgemm_body(const PkP& p, unsigned V, const unsig
     unsigned abase[TM]; bool aok[TM];
 #pragma unroll
     for (int ta = 0; ta < TM; ++ta) {
-        const int mt = (m0 >> 5) + wave * TM + ta;
+        const int mt = (m0 >> 5) + wm * TM + ta;
         aok[ta] = mt < p.Mt;
         abase[ta] = (unsigned)mt * (unsigned)p.KS * 3072u + (unsigned)lane * 16u;
     }
@@ -181,7 +186,7 @@ __device__ __forceinline__ void pgemm_body(const PkP& p, unsigned V, const unsig
         X6Frag f;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            f.p[pl] = __builtin_bit_cast(mma_bf16x8, *(const uint4*)(&Bs[buf][brow + tb * 32 * RS + pl * 64 + s2 * 32]));
+            f.p[pl] = __builtin_bit_cast(mma_bf16x8, *(const uint4*)(&Bs[buf][brow + (wn * TN + tb) * 32 * RS + pl * 64 + s2 * 32]));
         return f;
     };
     auto compute = [&](int buf, const uint4 (&ra)[2][TM][3]) {
@@ -251,7 +256,7 @@ __device__ __forceinline__ void pgemm_body(const PkP& p, unsigned V, const unsig
     const size_t cms = (size_t)p.outH * p.outW;
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
-        const int n = n0 + tb * 32 + (lane & 31);
+        const int n = n0 + (wn * TN + tb) * 32 + (lane & 31);
         const bool nok = n < p.N;
         const int nn = nok ? n : 0;
         const int img = nn / RHW, rem = nn - img * RHW;
@@ -262,7 +267,7 @@ __device__ __forceinline__ void pgemm_body(const PkP& p, unsigned V, const unsig
         for (int ta = 0; ta < TM; ++ta) {
 #pragma unroll
             for (int r16 = 0; r16 < 16; ++r16) {
-                const int m = m0 + (wave * TM + ta) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+                const int m = m0 + (wm * TM + ta) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
                 if (nok && m < p.M) {
                     float v = acc[ta][tb][r16];
                     float* dst = (split ? slab : p.C) + cbase + (size_t)m * cms;
@@ -283,13 +288,13 @@ __global__ __launch_bounds__(256, OCC) void pgemm_kernel(const PkP p) { pgemm_bo
 constexpr int PK_MAXG = 8;
 struct PkGroup { PkP p[PK_MAXG]; unsigned end[PK_MAXG]; int n; };
 
-template <int TM, int TN, int OCC>
+template <int TM, int TN, int OCC, int WM>
 __global__ __launch_bounds__(256, OCC) void pgemm_group_kernel(const PkGroup g) {
     int pi = 0;
 #pragma unroll
     for (int i = 0; i < PK_MAXG - 1; ++i) if (i + 1 < g.n && blockIdx.x >= g.end[i]) pi = i + 1;
     const unsigned start = pi ? g.end[pi - 1] : 0u;
-    pgemm_body<TM, TN>(g.p[pi], blockIdx.x - start, g.end[pi] - start);
+    pgemm_body<TM, TN, WM>(g.p[pi], blockIdx.x - start, g.end[pi] - start);
 }
 
 // ------------------------------------------------------------------------------------------------ pack kernels
@@ -718,6 +723,10 @@ struct PkCfg { int tm, tn; };
 static const PkCfg kPk[] = {{1, 2}, {1, 4}, {2, 2}};
 enum { NPK = 3 };
 static int g_pk_cfg = -1, g_pk_split = 0;
+#ifndef PK_G64_OCC
+#define PK_G64_OCC 2
+#endif
+static int g_pk_group_tile = -1;          // lab: MOGAN_PK_GROUP_TILE=0/1 forces the 128x64 / 64x128 tile of mogan_pk_group
 static inline int a_prof_mode(int dgrad) { return dgrad ? 11 : 10; }    // launch-profile modes of the grouped launches
 
 // OCC = waves per SIMD the register allocation is held to (512 / OCC registers per lane)
@@ -952,10 +961,25 @@ int mogan_conv2d_wgrad_pk(const float* dy, const float* x, float* dw, int B, int
 }
 
 int mogan_pk_group(int n, MoganPkArgs* args, hipStream_t stream) {
+    static const int env_tile = [] { const char* e = getenv("MOGAN_PK_GROUP_TILE"); return e ? atoi(e) : -1; }();
+    g_pk_group_tile = env_tile;
     if (n <= 0 || n > PK_MAXG || !args) return MOGAN_ERR_SHAPE;
     PkGroup g{};
     g.n = n;
     long long end = 0; double flops = 0;
+    // tile of the group: 128 x 64 (four waves down the rows) or 64 x 128 (2 x 2 waves), whichever pads less; the wide-row tile stages
+    // half as many pixel-panel bytes per MFMA and is preferred when both pad alike
+    double w128 = 0, w64 = 0;
+    for (int i = 0; i < n; ++i) {
+        const double N = (double)args[i].B * args[i].outH * args[i].outW, K = (double)args[i].KH * args[i].KW * args[i].Cp;
+        w128 += (double)cdiv(args[i].M, 128) * 128 * (double)cdiv((long long)N, 64) * 64 * K;
+        w64 += (double)cdiv(args[i].M, 64) * 64 * (double)cdiv((long long)N, 128) * 128 * K;
+    }
+    // measured on the trunk (B = 16, per launch): the 64-row tile is 15-45 % slower wherever the 128-row tile pads < 40 % and no
+    // faster where it pads 50 % (the launches are bound by the pixel-panel gather, not by the MFMAs) -> lab switch only
+    (void)w64; (void)w128;
+    const int tile64 = g_pk_group_tile > 0 ? 1 : 0;
+    const int bm = tile64 ? 64 : 128, bn = tile64 ? 128 : 64;
     for (int i = 0; i < n; ++i) {
         const MoganPkArgs& a = args[i];
         if (!a.wpk || !a.panel || !a.raw || a.B <= 0 || a.M <= 0 || a.Cp <= 0 || a.Cp % 32 || a.cg0 < 0 || a.cg0 + a.Cp / 32 > a.CGp ||
@@ -973,7 +997,7 @@ int mogan_pk_group(int n, MoganPkArgs* args, hipStream_t stream) {
         p.accumulate = 0; p.dgrad = a.dgrad; p.ncls = 1; p.Cc = a.Cp; p.CG = a.Cp / 32; p.CGp = a.CGp; p.cg0 = a.cg0;
         p.PH = a.PH; p.PW = a.PW; p.RH = a.outH; p.RW = a.outW; p.s = a.stride; p.ph = a.ph; p.pw = a.pw; p.nkw = a.KW;
         p.outH = a.outH; p.outW = a.outW;
-        p.gx = (int)cdiv(p.N, 64); p.gy = (int)cdiv(p.M, 128);
+        p.gx = (int)cdiv(p.N, bn); p.gy = (int)cdiv(p.M, bm);
         p.kt_per = (int)cdiv(cdiv(p.ntile, std::min(a.nsplit, p.ntile)), PK_TRIP) * PK_TRIP;
         while (cdiv(p.ntile, p.kt_per) > a.nsplit) p.kt_per += PK_TRIP;            // never more slabs than the caller made room for
         p.nsplit = (int)cdiv(p.ntile, p.kt_per);
@@ -983,8 +1007,9 @@ int mogan_pk_group(int n, MoganPkArgs* args, hipStream_t stream) {
         g.end[i] = (unsigned)end;
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
     }
-    mogan_prof_begin(a_prof_mode(args[0].dgrad), 0, flops, g.p[0].M, g.p[0].N, g.p[0].K, stream);
-    hipLaunchKernelGGL((pgemm_group_kernel<1, 2, 3>), dim3((unsigned)end), dim3(256), 0, stream, g);
+    mogan_prof_begin(a_prof_mode(args[0].dgrad), tile64, flops, g.p[0].M, g.p[0].N, g.p[0].K, stream);
+    if (tile64) hipLaunchKernelGGL((pgemm_group_kernel<1, 2, PK_G64_OCC, 2>), dim3((unsigned)end), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((pgemm_group_kernel<1, 2, 3, 4>), dim3((unsigned)end), dim3(256), 0, stream, g);
     mogan_prof_end(1, stream);
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }

@@ -964,3 +964,157 @@ def test_deep_blocks_hand_over_their_pixel_panel():
         assert torch.equal(z1, z2)
     finally:
         ops.pk_debug_force(0, -1, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Frozen trunk on pixel panels: mogan_pk_group (grouped packed-operand GEMM) + mogan_panel_tail_group, straight through the C ABI
+def _panel_decode(panel, Q, Cp):
+    """pixel panel bytes -> (Q, Cp) fp32: the three bf16 pieces of every value add up to it exactly (csrc/mogan_mma.h)"""
+    p = panel.view(torch.bfloat16).view(Q, Cp // 32, 3, 32).float()
+    return (p[:, :, 0] + p[:, :, 1] + p[:, :, 2]).reshape(Q, Cp)
+
+
+def _tail_member(B, n, H, W, srcs, dst=None, dst_bs=0, panel=None, Cp=0, c0=0, scale=None, shift=None, relu=0, box=0, add=None,
+                 add_bs=0, mask=None, mask_bs=0):
+    a = lib.TailArgs()
+    for j, (t, bs, slab, ns) in enumerate(srcs):
+        a.src[j], a.src_bs[j], a.src_slab[j], a.src_nsplit[j] = t, bs, slab, ns
+    a.nsrc, a.B, a.n, a.H, a.W, a.relu, a.box = len(srcs), B, n, H, W, relu, box
+    if dst is not None:
+        a.dst, a.dst_bs = dst, dst_bs
+    if panel is not None:
+        a.panel, a.CGp, a.cg0 = panel, Cp // 32, c0 // 32
+    if scale is not None:
+        a.scale, a.shift = scale, shift
+    if add is not None:
+        a.add, a.add_bs = add, add_bs
+    if mask is not None:
+        a.mask, a.mask_bs = mask, mask_bs
+    return a
+
+
+def _run_tail(members):
+    import ctypes
+    arr = (lib.TailArgs * len(members))(*members)
+    lib.call("mogan_panel_tail_group", len(members), ctypes.cast(arr, ctypes.c_void_p), lib.stream_ptr())
+
+
+PANEL_CONVS = [  # Cin, c0 (slice offset in a wider panel), Cp_total, H, W, Cout, KH, KW, stride, ph, pw
+    (48, 32, 128, 9, 11, 64, 5, 5, 1, 2, 2), (64, 0, 64, 17, 17, 40, 1, 7, 1, 0, 3), (96, 64, 192, 17, 17, 96, 7, 1, 1, 3, 0),
+    (160, 0, 160, 8, 8, 200, 3, 3, 1, 1, 1), (288, 0, 288, 13, 13, 72, 3, 3, 2, 0, 0), (192, 0, 224, 8, 8, 136, 1, 1, 1, 0, 0)]
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+def test_panel_group_gemm_forward_and_tail(nsplit):
+    """All PANEL_CONVS as ONE grouped launch + ONE tail launch: input slices inside wider panels (channel offset, a slice of 48
+    channels padded to 64 with zero filters), 1x7 / 7x1 / 5x5 / stride-2 geometries, K-split slabs; y = relu(scale * conv + shift)
+    against fp64, the fp32 copy and the decoded output panel (exact split, zero pad channels)."""
+    import ctypes
+    B = 3
+    L = lib.load()
+    keep, pk, tails, refs = [], [], [], []
+    for i, (Cin, c0, Cp, H, W, Cout, KH, KW, s, ph, pw) in enumerate(PANEL_CONVS):
+        x = T("pgx%d" % i, (B, Cp, H, W)).to(DEV)
+        w = T("pgw%d" % i, (Cout, Cin, KH, KW), 0.2).to(DEV)
+        sc, sh = T("pgs%d" % i, (Cout,), 0.5, 1.0).to(DEV), T("pgh%d" % i, (Cout,), 0.3).to(DEV)
+        Q = B * H * W
+        xp = torch.empty(Q * Cp * 6, dtype=torch.uint8, device=DEV)
+        _run_tail([_tail_member(B, Cp, H, W, [(x.data_ptr(), Cp * H * W, 0, 1)], panel=xp.data_ptr(), Cp=Cp)])
+        assert torch.equal(_panel_decode(xp, Q, Cp), x.permute(0, 2, 3, 1).reshape(Q, Cp)), "panel split is not exact"
+        cin_p = (Cin + 31) // 32 * 32
+        wpad = torch.zeros(Cout, cin_p, KH, KW, device=DEV)
+        wpad[:, :Cin] = w
+        wpk = torch.empty(L.mogan_pk_weight_bytes(Cout, cin_p, KH, KW, 1, 0), dtype=torch.uint8, device=DEV)
+        lib.call("mogan_pk_weight_pack", wpad.data_ptr(), wpk.data_ptr(), Cout, cin_p, KH, KW, 1, ph, pw, 0, lib.stream_ptr())
+        OH, OW = (H + 2 * ph - KH) // s + 1, (W + 2 * pw - KW) // s + 1
+        raw = torch.full((nsplit, B, Cout, OH, OW), float("nan"), device=DEV)
+        a = lib.PkArgs()
+        a.wpk, a.panel, a.raw = wpk.data_ptr(), xp.data_ptr(), raw.data_ptr()
+        a.B, a.M, a.Cp, a.CGp, a.cg0, a.PH, a.PW, a.outH, a.outW = B, Cout, cin_p, Cp // 32, c0 // 32, H, W, OH, OW
+        a.KH, a.KW, a.stride, a.ph, a.pw, a.dgrad, a.nsplit = KH, KW, s, ph, pw, 0, nsplit
+        pk.append(a)
+        Cop = (Cout + 31) // 32 * 32 + 32                         # output panel: the slice sits behind one foreign group
+        y32 = torch.zeros(B, Cout, OH, OW, device=DEV)
+        yp = torch.full((B * OH * OW * Cop * 6,), 0x7f, dtype=torch.uint8, device=DEV)
+        keep += [x, xp, wpad, wpk, raw, sc, sh, y32, yp]
+        tails.append((raw, Cout, OH, OW, sc, sh, y32, yp, Cop))
+        # channels of the slice beyond Cin (48 -> 64) hold data in the panel: the zero filters must silence them
+        refs.append(torch.relu(F.conv2d(x[:, c0:c0 + Cin].double().cpu(), w.double().cpu(), None, s, (ph, pw))
+                               * sc.double().cpu().view(1, -1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1)))
+    arr = (lib.PkArgs * len(pk))(*pk)
+    lib.call("mogan_pk_group", len(pk), ctypes.cast(arr, ctypes.c_void_p), lib.stream_ptr())
+    members = []
+    for a, (raw, Cout, OH, OW, sc, sh, y32, yp, Cop) in zip(arr, tails):
+        assert 1 <= a.nsplit <= nsplit
+        members.append(_tail_member(B, Cout, OH, OW, [(raw.data_ptr(), Cout * OH * OW, B * Cout * OH * OW, a.nsplit)],
+                                    dst=y32.data_ptr(), dst_bs=Cout * OH * OW, panel=yp.data_ptr(), Cp=Cop, c0=32,
+                                    scale=sc.data_ptr(), shift=sh.data_ptr(), relu=1))
+    _run_tail(members)
+    torch.cuda.synchronize()
+    for (raw, Cout, OH, OW, sc, sh, y32, yp, Cop), ref, case in zip(tails, refs, PANEL_CONVS):
+        _check(y32, ref, what="panel conv %s" % (case,))
+        dec = _panel_decode(yp, B * OH * OW, Cop)
+        n_up = (Cout + 31) // 32 * 32
+        assert torch.equal(dec[:, 32:32 + Cout], y32.permute(0, 2, 3, 1).reshape(-1, Cout)), case
+        assert float(dec[:, 32 + Cout:32 + n_up].abs().max() if n_up > Cout else 0.0) == 0.0, "pad channels of the slice must be zero"
+        assert torch.equal(yp.view(-1, Cop // 32, 192)[:, 0], torch.full_like(yp.view(-1, Cop // 32, 192)[:, 0], 0x7f)), \
+            "the foreign channel group in front of the slice was touched"
+
+
+@pytest.mark.parametrize("case", [c for c in PANEL_CONVS if c[8] == 1])
+def test_panel_group_gemm_data_gradient_and_tail(case):
+    """stride-1 data gradient from the dY panel (two members that add into one gradient = two K ranges of one sum), + the gradient's
+    other contributor, ReLU mask of the input: against the fp64 transposed convolution"""
+    import ctypes
+    Cin, _, _, H, W, Cout, KH, KW, s, ph, pw = case
+    B = 2
+    L = lib.load()
+    x = torch.relu(T("pdx", (B, Cin, H, W))).to(DEV)                      # the layer input (a ReLU output: exact zeros)
+    other = T("pdo", (B, Cin, H, W)).to(DEV)
+    coutp = (Cout + 31) // 32 * 32
+    raws, keep, ref = [], [], other.double().cpu()
+    pk = []
+    for j in range(2):
+        w = T("pdw%d" % j, (Cout, Cin, KH, KW), 0.2).to(DEV)
+        dy = T("pdy%d" % j, (B, Cout, H, W)).to(DEV)
+        Q = B * H * W
+        dyp = torch.empty(Q * coutp * 6, dtype=torch.uint8, device=DEV)
+        _run_tail([_tail_member(B, Cout, H, W, [(dy.data_ptr(), Cout * H * W, 0, 1)], panel=dyp.data_ptr(), Cp=coutp)])
+        wpad = torch.zeros(coutp, Cin, KH, KW, device=DEV)
+        wpad[:Cout] = w
+        wpk = torch.empty(L.mogan_pk_weight_bytes(coutp, Cin, KH, KW, 1, 1), dtype=torch.uint8, device=DEV)
+        lib.call("mogan_pk_weight_pack", wpad.data_ptr(), wpk.data_ptr(), coutp, Cin, KH, KW, 1, ph, pw, 1, lib.stream_ptr())
+        raw = torch.full((2, B, Cin, H, W), float("nan"), device=DEV)
+        a = lib.PkArgs()
+        a.wpk, a.panel, a.raw = wpk.data_ptr(), dyp.data_ptr(), raw.data_ptr()
+        a.B, a.M, a.Cp, a.CGp, a.cg0, a.PH, a.PW, a.outH, a.outW = B, Cin, coutp, coutp // 32, 0, H, W, H, W
+        a.KH, a.KW, a.stride, a.ph, a.pw, a.dgrad, a.nsplit = KH, KW, 1, ph, pw, 1, 2
+        pk.append(a)
+        raws.append(raw)
+        keep += [w, dy, dyp, wpad, wpk]
+        ref = ref + F.conv_transpose2d(dy.double().cpu(), w.double().cpu(), None, 1, (ph, pw))
+    ref = ref * (x.double().cpu() > 0)
+    arr = (lib.PkArgs * 2)(*pk)
+    lib.call("mogan_pk_group", 2, ctypes.cast(arr, ctypes.c_void_p), lib.stream_ptr())
+    dx = torch.empty(B, Cin, H, W, device=DEV)
+    cinp = (Cin + 31) // 32 * 32
+    dxp = torch.empty(B * H * W * cinp * 6, dtype=torch.uint8, device=DEV)
+    srcs = [(r.data_ptr(), Cin * H * W, B * Cin * H * W, a.nsplit) for r, a in zip(raws, arr)]
+    _run_tail([_tail_member(B, Cin, H, W, srcs, dst=dx.data_ptr(), dst_bs=Cin * H * W, panel=dxp.data_ptr(), Cp=cinp,
+                            add=other.data_ptr(), add_bs=Cin * H * W, mask=x.data_ptr(), mask_bs=Cin * H * W)])
+    torch.cuda.synchronize()
+    _check(dx, ref, what="panel dgrad %s" % (case,))
+    assert torch.equal(_panel_decode(dxp, B * H * W, cinp)[:, :Cin], dx.permute(0, 2, 3, 1).reshape(-1, Cin))
+
+
+def test_panel_tail_box_filter():
+    """the pool branch's 3x3 mean (zero padding, divisor 9 = F.avg_pool2d(x, 3, 1, 1)) over the sum of two slabs, then affine + ReLU"""
+    B, C, H, W = 3, 40, 8, 17
+    slabs = T("ptb", (2, B, C, H, W)).to(DEV)
+    sc, sh = T("pts", (C,), 0.5, 1.0).to(DEV), T("pth", (C,), 0.3).to(DEV)
+    y = torch.empty(B, C, H, W, device=DEV)
+    _run_tail([_tail_member(B, C, H, W, [(slabs.data_ptr(), C * H * W, B * C * H * W, 2)], dst=y.data_ptr(), dst_bs=C * H * W,
+                            scale=sc.data_ptr(), shift=sh.data_ptr(), relu=1, box=1)])
+    ref = torch.relu(F.avg_pool2d(slabs.double().cpu().sum(0), 3, 1, 1) * sc.double().cpu().view(1, -1, 1, 1)
+                     + sh.double().cpu().view(1, -1, 1, 1))
+    assert max_abs(y.cpu().double(), ref) <= 2e-6

@@ -13,7 +13,7 @@ adam = [x for x in ev if "adam_kernel" in x[2]]
 ends = [adam[i][1] for i in range(3, len(adam), 4)]
 t0, t1 = ends[which - 1], ends[which]
 win = [x for x in ev if t0 <= x[0] < t1]
-main = collections.Counter(x[3] for x in win if "wino_fwd" in x[2]).most_common(1)[0][0]
+main = collections.Counter(x[3] for x in win if "wino3_fwd" in x[2]).most_common(1)[0][0]
 ms = [x for x in win if x[3] == main]
 gap, cut = max((ms[i + 1][0] - ms[i][1], i) for i in range(len(ms) - 1))
 

@@ -18,12 +18,13 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("gemm_kernel", "pgemm_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel", "wino_fwd_kernel", "wino_wgrad_kernel")
+KEEP = ("gemm_kernel", "pgemm_kernel", "pgemm_group_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel", "wino3_fwd_kernel",
+        "wino_wgrad_kernel")
 
 
 def short(name):
     name = name.replace("gemm_group_kernel", "gemm_kernel")      # grouped launches of the same tile kernel
-    m = re.search(r"(pgemm_kernel|gemm_kernel|dconv_fwd_kernel|dconv_wgrad_kernel)<([^>]*)>", name)
+    m = re.search(r"(pgemm_group_kernel|pgemm_kernel|gemm_kernel|dconv_fwd_kernel|dconv_wgrad_kernel|wino3_fwd_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
     for k in ("wino_fwd_kernel", "wino_wgrad_kernel"):

@@ -61,7 +61,7 @@ if __name__ == "__main__":
     _self_launch()
 
 # The eager multi-stream AttnGAN step runs on a fixed hardware-queue arrangement (mogan_amd/hip/lib.py, "hardware queues":
-# 4 queues / 2 reserved streams); must be in the
+# 4 queues; no idle streams ahead of the engine's in a single process, 3 in a process group); must be in the
 # environment before the HIP runtime starts.  The captured (--graph) step and the secondary workloads keep the runtime's default.
 _EAGER_ATTNGAN = "--graph" not in sys.argv and not any(a.startswith("--workload") for a in sys.argv)
 if _EAGER_ATTNGAN:

@@ -63,7 +63,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if cfg.TRAIN.FLAG and not torch.cuda.is_initialized():
-        # the eager multi-stream step: its hardware-queue arrangement (4 queues alone, 3 + 3 reserved streams in a process group), before the HIP runtime starts and before
+        # the eager multi-stream step: its hardware-queue arrangement (4 queues; 3 idle streams first when the process is a member of a group), before the HIP runtime starts and before
         # RCCL creates its streams (hip/lib.py, "hardware queues")
         hiplib.configure_hw_queues()
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))

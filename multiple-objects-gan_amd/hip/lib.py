@@ -234,13 +234,23 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _reserved = []
 
 
+def in_process_group():
+    """this process is (going to be) a member of a torch.distributed group: launched by torch.distributed.run / bench.py --gpus N
+    (WORLD_SIZE > 1) or forced into a 1-rank group by the test knob"""
+    return int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("MOGAN_FORCE_DIST", "0") not in ("", "0")
+
+
 def hw_queue_defaults():
-    """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above).  The same
-    for a single process and for a member of a process group: torch's ProcessGroupNCCL adds ONE stream per device whatever the
-    world size, and that is the arrangement the 1-rank-group measurements above were taken with; what a real multi-GPU world
-    changes is how long that stream's kernels run, not how many streams exist.  MOGAN_HW_QUEUES / MOGAN_RESERVED_STREAMS (or
-    GPU_MAX_HW_QUEUES itself) override it for a node where this turns out wrong."""
-    return (os.environ.get("MOGAN_HW_QUEUES", "4"), 2)
+    """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above).
+    Round 4 (the engines of a process share one stream table, the frozen encoder's graph has fewer nodes; tools/queue_table.sh
+    + a scan of 0..10 idle streams, two interleaved repeats on one box, img/s): one process without a group (4,0) 429.8 / 428.3,
+    (4,1) 395, (4,2) 410 / 408, (4,3) 393 / 397, (4,4) 424 / 426, (4,5) 425 / 426, (4,6..10) 416-418 on a second box; member of a
+    1-rank RCCL group (4,0) 394 / 395, (4,1) 419 / 408, (4,2) 421.0 / 420.5, (4,3) 422.2 / 420.2, (4,4) 420.7 / 419.2, (4,5) 420 --
+    a single process runs without idle streams again, a group member on the middle of its plateau (3).  torch's
+    ProcessGroupNCCL adds ONE stream per device whatever the world size; what a real multi-GPU world changes is how long that
+    stream's kernels run, not how many streams exist.  MOGAN_HW_QUEUES / MOGAN_RESERVED_STREAMS (or GPU_MAX_HW_QUEUES itself)
+    override it for a node where this turns out wrong."""
+    return (os.environ.get("MOGAN_HW_QUEUES", "4"), 3 if in_process_group() else 0)
 
 
 def configure_hw_queues():

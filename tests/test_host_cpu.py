@@ -52,6 +52,28 @@ def test_ctypes_arity_matches_header():
         assert len(params) == len(args), (name, len(params), len(args))
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """the argument structs of the grouped entry points (MoganConvFwdArgs, MoganConvDgradArgs, MoganPkArgs, MoganTailArgs): size and the
+    offset of every field as gcc lays out include/mogan_hip.h against the ctypes mirrors in hip/lib.py"""
+    pairs = (("MoganConvFwdArgs", lib.ConvFwdArgs), ("MoganConvDgradArgs", lib.ConvDgradArgs), ("MoganPkArgs", lib.PkArgs),
+             ("MoganTailArgs", lib.TailArgs))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(got["%s.%s" % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])
+
+
 def test_no_cpu_fallback():
     with pytest.raises(lib.MoganHipError):
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1)

@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         if (idx) idx[i] = (uint8_t)am;
     }
 }
-// gather form: dx[p,iy,ix] = sum over the windows that contain (iy,ix) and whose first maximum is there
+// gather form: dx[p,iy,ix] = sum over the windows that contain (iy,ix) and whose first maximum is there.  k <= 2 s (every caller:
+// 3x3 stride 2, 2x2 stride 2): an element lies in at most 2 x 2 windows -- their index bytes and gradients are loaded unconditionally
+// from clamped addresses (8 loads in flight, no per-window branch) and selected afterwards.
 template <typename IT>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy,
                                                           float* __restrict__ dx, long long total, int H, int W, int OH,
@@ -282,15 +284,26 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
                                                           const float* __restrict__ relu_of, int accumulate) {
     for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < (IT)total; i += (IT)gridDim.x * 256) {
         const int ix = (int)(i % W); const IT t = i / W; const int iy = (int)(t % H); const IT pl = t / H;
+        const int oyb = iy / s, oxb = ix / s;                       // the last window that can contain the element; the other: - 1
+        const IT img = pl / C, ch = pl - img * C;
+        const long long obase = (long long)pl * OH * OW, dbase = (long long)img * dybs + (long long)ch * OH * OW;
+        bool ok[4]; int code[4]; long long off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = oyb - (q >> 1), ox = oxb - (q & 1);
+            const int ky = iy - oy * s, kx = ix - ox * s;
+            ok[q] = oy >= 0 && ox >= 0 && oy < OH && ox < OW && ky < k && kx < k;
+            code[q] = ky * k + kx;
+            off[q] = ok[q] ? (long long)oy * OW + ox : 0;
+        }
+        int am[4]; float gv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) am[q] = (int)idx[obase + off[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[q] = dy[dbase + off[q]];
         float g = 0.f;
-        const int oy0 = max(0, (iy - k + s) / s), oy1 = min(OH - 1, iy / s);
-        const int ox0 = max(0, (ix - k + s) / s), ox1 = min(OW - 1, ix / s);
-        for (int oy = oy0; oy <= oy1; ++oy)
-            for (int ox = ox0; ox <= ox1; ++ox) {
-                const long long o = (pl * OH + oy) * OW + ox;
-                if ((int)idx[o] == (iy - oy * s) * k + (ix - ox * s))
-                    g += dy[(pl / C) * dybs + ((pl % C) * OH + oy) * (long long)OW + ox];
-            }
+#pragma unroll
+        for (int q = 3; q >= 0; --q) if (ok[q] && am[q] == code[q]) g += gv[q];      // (oy, ox) ascending, as the window loops did
         if (relu_of && !(relu_of[i] > 0.f)) g = 0.f;
         dx[i] = accumulate ? dx[i] + g : g;
     }
@@ -789,7 +802,7 @@ int mogan_maxpool_fwd(const float* x, float* y, uint8_t* idx, int planes, int H,
 }
 int mogan_maxpool_bwd_ex(const uint8_t* idx, const float* dy, long long dy_bstride, float* dx, const float* relu_of,
                          int accumulate, int B, int C, int H, int W, int k, int s, hipStream_t stream) {
-    if (B <= 0 || C <= 0 || k <= 0 || s <= 0 || H < k || W < k) return MOGAN_ERR_SHAPE;
+    if (B <= 0 || C <= 0 || k <= 0 || s <= 0 || H < k || W < k || k > 2 * s) return MOGAN_ERR_SHAPE;      // (k <= 2 s: see the kernel)
     const int OH = (H - k) / s + 1, OW = (W - k) / s + 1;
     if (dy_bstride < 0) dy_bstride = (long long)C * OH * OW;
     const long long n = (long long)B * C * H * W;

@@ -18,10 +18,47 @@ namespace {
 
 constexpr int TR = 8, TC = 32;       // thread tile: 8 rows x 32 columns = 256 threads
 
+// Halo tile (NC channels x HH x WW) of an NCHW image into LDS: ALL of a thread's global loads are issued first (clamped addresses, no
+// branch), then stored -- a `for (e ...) Xs[..] = ok ? x[..] : 0` loop serialises one load latency per iteration, and with 11-15
+// iterations per chunk that chain, not the arithmetic, was the run time of these kernels (80 us for a 64 x 64 image).
+template <int NC, int NT, int HH, int WW>
+__device__ __forceinline__ void halo_load(float (&v)[(NC * HH * WW + NT - 1) / NT], const float* __restrict__ base, size_t plane,
+                                          int nvalid, int y0, int x0, int H, int W, int tid) {
+    constexpr int TOT = NC * HH * WW, NE = (TOT + NT - 1) / NT;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + NT * j;
+        const int c = e / (HH * WW), r = e - c * (HH * WW);
+        const int hy = r / WW, hx = r - hy * WW;
+        const int iy = y0 + hy, ix = x0 + hx;
+        const bool ok = e < TOT && c < nvalid && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const float t = base[ok ? (size_t)c * plane + (size_t)iy * W + ix : 0];
+        v[j] = ok ? t : 0.f;
+    }
+}
+template <int NC, int NT, int HH, int WW, int WP>
+__device__ __forceinline__ void halo_store(float (*Xs)[HH][WP], const float (&v)[(NC * HH * WW + NT - 1) / NT], int tid) {
+    constexpr int TOT = NC * HH * WW, NE = (TOT + NT - 1) / NT;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + NT * j;
+        const int c = e / (HH * WW), r = e - c * (HH * WW);
+        const int hy = r / WW, hx = r - hy * WW;
+        if (e < TOT) Xs[c][hy][hx] = v[j];
+    }
+}
+template <int NC, int NT, int HH, int WW, int WP>
+__device__ __forceinline__ void stage_halo(float (*Xs)[HH][WP], const float* __restrict__ base, size_t plane, int nvalid, int y0,
+                                           int x0, int H, int W, int tid) {
+    float v[(NC * HH * WW + NT - 1) / NT];
+    halo_load<NC, NT, HH, WW>(v, base, plane, nvalid, y0, x0, H, W, tid);
+    halo_store<NC, NT, HH, WW, WP>(Xs, v, tid);
+}
+
 template <int COUT>
 __global__ __launch_bounds__(256) void sc_fwd3x3(const float* __restrict__ x, const float* __restrict__ w,
                                                  float* __restrict__ y, int Cin, int H, int W, int tiles_x, int tiles_y) {
-    constexpr int CK = 8, HH = TR + 2, WW = TC + 2, WP = WW + 1;
+    constexpr int CK = 16, HH = TR + 2, WW = TC + 2, WP = WW + 1;
     __shared__ float Xs[CK][HH][WP];
     int t = blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
@@ -33,15 +70,13 @@ __global__ __launch_bounds__(256) void sc_fwd3x3(const float* __restrict__ x, co
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    float pre[(CK * HH * WW + 255) / 256];            // the next chunk's halo: its loads fly while this chunk is computed
+    halo_load<CK, 256, HH, WW>(pre, xb, plane, Cin, ty * TR - 1, tx * TC - 1, H, W, tid);
     for (int c0 = 0; c0 < Cin; c0 += CK) {
-        for (int e = tid; e < CK * HH * WW; e += 256) {
-            const int c = e / (HH * WW), r = e - c * (HH * WW);
-            const int hy = r / WW, hx = r - hy * WW;
-            const int iy = ty * TR - 1 + hy, ix = tx * TC - 1 + hx;
-            const bool ok = c0 + c < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            Xs[c][hy][hx] = ok ? xb[(size_t)(c0 + c) * plane + (size_t)iy * W + ix] : 0.f;
-        }
+        halo_store<CK, 256, HH, WW, WP>(Xs, pre, tid);
         __syncthreads();
+        if (c0 + CK < Cin)
+            halo_load<CK, 256, HH, WW>(pre, xb + (size_t)(c0 + CK) * plane, plane, Cin - c0 - CK, ty * TR - 1, tx * TC - 1, H, W, tid);
         const int nc = min(CK, Cin - c0);
         for (int c = 0; c < nc; ++c) {
             const float* wc = w + (size_t)(c0 + c) * 9;            // + co * Cin * 9: block-uniform -> scalar loads
@@ -73,13 +108,7 @@ __global__ __launch_bounds__(256) void sc_dgrad3x3(const float* __restrict__ dy,
     const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
     const int iy = ty * TR + ly, ix = tx * TC + lx;
     const size_t plane = (size_t)H * W;
-    for (int e = tid; e < COUT * HH * WW; e += 256) {
-        const int c = e / (HH * WW), r = e - c * (HH * WW);
-        const int hy = r / WW, hx = r - hy * WW;
-        const int oy = ty * TR - 1 + hy, ox = tx * TC - 1 + hx;
-        const bool ok = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
-        Ys[c][hy][hx] = ok ? dy[((size_t)b * COUT + c) * plane + (size_t)oy * W + ox] : 0.f;
-    }
+    stage_halo<COUT, 256, HH, WW, WP>(Ys, dy + (size_t)b * COUT * plane, plane, COUT, ty * TR - 1, tx * TC - 1, H, W, tid);
     __syncthreads();
     // dx[iy][ix] = sum_co sum_{kh,kw} dy[iy+1-kh][ix+1-kw] * w[co][ci][kh][kw];  LDS position of dy[iy+1-kh] is ly+2-kh
     float r[COUT][9];
@@ -120,15 +149,14 @@ __global__ __launch_bounds__(256) void sc_dgrad_k4s2(const float* __restrict__ d
     float acc[CIN][2][2];
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci) acc[ci][0][0] = acc[ci][0][1] = acc[ci][1][0] = acc[ci][1][1] = 0.f;
+    float pre[(CK * HH * WW + 255) / 256];            // the next chunk's halo: its loads fly while this chunk is computed
+    halo_load<CK, 256, HH, WW>(pre, dy + (size_t)b * Cout * oplane, oplane, Cout, ty * TR - 1, tx * TC - 1, OH, OW, tid);
     for (int c0 = 0; c0 < Cout; c0 += CK) {
-        for (int e = tid; e < CK * HH * WW; e += 256) {
-            const int c = e / (HH * WW), r = e - c * (HH * WW);
-            const int hy = r / WW, hx = r - hy * WW;
-            const int oy = ty * TR - 1 + hy, ox = tx * TC - 1 + hx;
-            const bool ok = c0 + c < Cout && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
-            Ys[c][hy][hx] = ok ? dy[((size_t)b * Cout + c0 + c) * oplane + (size_t)oy * OW + ox] : 0.f;
-        }
+        halo_store<CK, 256, HH, WW, WP>(Ys, pre, tid);
         __syncthreads();
+        if (c0 + CK < Cout)
+            halo_load<CK, 256, HH, WW>(pre, dy + ((size_t)b * Cout + c0 + CK) * oplane, oplane, Cout - c0 - CK, ty * TR - 1, tx * TC - 1, OH,
+                                       OW, tid);
         const int nc = min(CK, Cout - c0);
         for (int c = 0; c < nc; ++c) {
             float d[3][3];                                          // d[a][bb] = dy[Y-1+a][X-1+bb]
@@ -199,18 +227,27 @@ __global__ __launch_bounds__(192) void sc_wgrad3x3(const float* __restrict__ dy,
 #pragma unroll
             for (int co = 0; co < COUT; ++co) acc[kw][co] = 0.f;
         for (int tx = 0; tx < tiles_x; ++tx) {
-            for (int e = tid; e < CK * HH * WW; e += 192) {
-                const int cc = e / (HH * WW), q = e - cc * (HH * WW);
-                const int hy = q / WW, hx = q - hy * WW;
-                const int iy = ty * TR - 1 + hy, ix = tx * TC - 1 + hx;
-                const bool ok = c0 + cc < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                Xs[cc][hy][hx] = ok ? xb[(size_t)(c0 + cc) * plane + (size_t)iy * W + ix] : 0.f;
-            }
-            for (int e = tid; e < COUT * TR * TC; e += 192) {
-                const int co = e / (TR * TC), q = e - co * (TR * TC);
-                const int py = q / TC, px = q - py * TC;
-                const int oy = ty * TR + py, ox = tx * TC + px;
-                Ys[co][py][px] = (oy < H && ox < W) ? yb[(size_t)co * plane + (size_t)oy * W + ox] : 0.f;
+            {
+                constexpr int NY = (COUT * TR * TC + 191) / 192;
+                float yv[NY];
+#pragma unroll
+                for (int j = 0; j < NY; ++j) {                       // (issued ahead of the halo's loads: all in flight together)
+                    const int e = tid + 192 * j;
+                    const int co = e / (TR * TC), q = e - co * (TR * TC);
+                    const int py = q / TC, px = q - py * TC;
+                    const int oy = ty * TR + py, ox = tx * TC + px;
+                    const bool ok = e < COUT * TR * TC && oy < H && ox < W;
+                    const float t = yb[ok ? (size_t)co * plane + (size_t)oy * W + ox : 0];
+                    yv[j] = ok ? t : 0.f;
+                }
+                stage_halo<CK, 192, HH, WW, WP>(Xs, xb + (size_t)c0 * plane, plane, Cin - c0, ty * TR - 1, tx * TC - 1, H, W, tid);
+#pragma unroll
+                for (int j = 0; j < NY; ++j) {
+                    const int e = tid + 192 * j;
+                    const int co = e / (TR * TC), q = e - co * (TR * TC);
+                    const int py = q / TC, px = q - py * TC;
+                    if (e < COUT * TR * TC) Ys[co][py][px] = yv[j];
+                }
             }
             __syncthreads();
             const float* xr = &Xs[c][r + kh][0];
@@ -277,15 +314,14 @@ __global__ __launch_bounds__(256) void sc_dgrad_k3s2(const float* __restrict__ d
     float acc[CIN][2][2];
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci) acc[ci][0][0] = acc[ci][0][1] = acc[ci][1][0] = acc[ci][1][1] = 0.f;
+    float pre[(CK * HH * WW + 255) / 256];            // the next chunk's halo: its loads fly while this chunk is computed
+    halo_load<CK, 256, HH, WW>(pre, dy + (size_t)b * Cout * oplane, oplane, Cout, ty * TR - 1, tx * TC - 1, OH, OW, tid);
     for (int c0 = 0; c0 < Cout; c0 += CK) {
-        for (int e = tid; e < CK * HH * WW; e += 256) {
-            const int c = e / (HH * WW), r = e - c * (HH * WW);
-            const int hy = r / WW, hx = r - hy * WW;
-            const int oy = ty * TR - 1 + hy, ox = tx * TC - 1 + hx;
-            const bool ok = c0 + c < Cout && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
-            Ys[c][hy][hx] = ok ? dy[((size_t)b * Cout + c0 + c) * oplane + (size_t)oy * OW + ox] : 0.f;
-        }
+        halo_store<CK, 256, HH, WW, WP>(Ys, pre, tid);
         __syncthreads();
+        if (c0 + CK < Cout)
+            halo_load<CK, 256, HH, WW>(pre, dy + ((size_t)b * Cout + c0 + CK) * oplane, oplane, Cout - c0 - CK, ty * TR - 1, tx * TC - 1, OH,
+                                       OW, tid);
         const int nc = min(CK, Cout - c0);
         for (int c = 0; c < nc; ++c) {
             const float d00 = Ys[c][ly][lx], d01 = Ys[c][ly][lx + 1];        // (Y-1, X-1), (Y-1, X)

@@ -464,17 +464,30 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     // running statistics are updated group after group, as G calls would), one launch (the object pathways)
     for (int grp = 0; grp < G; ++grp, x += (size_t)B * C * HW, y += (size_t)B * Cy * HW, mean += C, invstd += C) {
     if (grp) __syncthreads();
+    // a thread's <= 16 values (x2 for GLU) are loaded ONCE, all loads in flight (clamped addresses, no branch), and stay in registers
+    // for the apply pass (a `for (e ...)` loop with one dependent load per iteration made this kernel 13-16 us for 4096 values)
+    constexpr int EPT = SMALL_NE / 256;
+    float v[NCH][EPT];
+    unsigned off[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const bool ok = e < NE;
+        const int b = e / HW, pos = e - b * HW;
+        off[i] = ok ? (unsigned)((b * C + c) * HW + pos) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float t = x[ok ? (size_t)off[i] + (size_t)k * Cy * HW : 0];
+            v[k][i] = ok ? t : 0.f;
+        }
+    }
     double acc[2 * NCH];
 #pragma unroll
     for (int k = 0; k < 2 * NCH; ++k) acc[k] = 0.0;
-    for (int e = threadIdx.x; e < NE; e += 256) {
-        const int b = e / HW, pos = e - b * HW;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const double v = x[((size_t)b * C + c + k * Cy) * HW + pos];
-            acc[2 * k] += v; acc[2 * k + 1] += v * v;
-        }
-    }
+    for (int i = 0; i < EPT; ++i)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { const double t = v[k][i]; acc[2 * k] += t; acc[2 * k + 1] += t * t; }
     block_sum<2 * NCH>(acc, sh);
     if (threadIdx.x == 0) {
         const double n = (double)NE;
@@ -497,11 +510,14 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     const float sc = gamma[c] * st[1], shf = beta[c] - st[0] * sc;
     float sc2 = 0.f, sh2 = 0.f;
     if (ACT == MOGAN_ACT_GLU) { sc2 = gamma[c + Cy] * st[3]; sh2 = beta[c + Cy] - st[2] * sc2; }
-    for (int e = threadIdx.x; e < NE; e += 256) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        if (off[i] == 0xFFFFFFFFu) continue;
+        const int e = threadIdx.x + 256 * i;
         const int b = e / HW, pos = e - b * HW;
-        const size_t ix = ((size_t)b * C + c) * HW + pos, iy = ((size_t)b * Cy + c) * HW + pos;
-        float t = x[ix] * sc + shf;
-        if (ACT == MOGAN_ACT_GLU) t = t * sigmoidf_(x[ix + (size_t)Cy * HW] * sc2 + sh2);
+        const size_t iy = ((size_t)b * Cy + c) * HW + pos;
+        float t = v[0][i] * sc + shf;
+        if (ACT == MOGAN_ACT_GLU) t = t * sigmoidf_(v[NCH - 1][i] * sc2 + sh2);
         if (ACT == MOGAN_ACT_RELU) t = t > 0.f ? t : 0.f;
         if (ACT == MOGAN_ACT_LRELU) t = t > 0.f ? t : t * slope;
         if (res) t += res[iy];
@@ -530,12 +546,30 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     if (ACT == MOGAN_ACT_GLU) { mu2 = mean[c + Cy]; is2 = invstd[c + Cy]; sc2 = gamma[c + Cy] * is2; sh2 = beta[c + Cy] - mu2 * sc2; }
     double acc[4] = {0, 0, 0, 0};
     float dummy = 0;
-    for (int e = threadIdx.x; e < NE; e += 256) {
+    // x (both halves for GLU) and dy of a thread's <= 16 elements: loaded once, all in flight, kept for the second pass
+    constexpr int EPT = SMALL_NE / 256, NCH = (ACT == MOGAN_ACT_GLU) ? 2 : 1;
+    float xv[NCH][EPT], dv[EPT];
+    unsigned off[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const bool ok = e < NE;
         const int b = e / HW, pos = e - b * HW;
-        const size_t ia = ((size_t)b * C + c) * HW + pos;
-        const float xa = x[ia], xg = (ACT == MOGAN_ACT_GLU) ? x[ia + (size_t)Cy * HW] : 0.f;
+        off[i] = ok ? (unsigned)((b * C + c) * HW + pos) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float t = x[ok ? (size_t)off[i] + (size_t)k * Cy * HW : 0];
+            xv[k][i] = ok ? t : 0.f;
+        }
+        const float t = dy[ok ? ((size_t)b * Cy + c) * HW + pos : 0];
+        dv[i] = ok ? t : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        if (off[i] == 0xFFFFFFFFu) continue;
+        const float xa = xv[0][i], xg = xv[NCH - 1][i];
         float da, dg;
-        act_bwd<ACT>(xa, xg, dy[((size_t)b * Cy + c) * HW + pos], sc, sh, sc2, sh2, slope, da, dg, dummy);
+        act_bwd<ACT>(xa, xg, dv[i], sc, sh, sc2, sh2, slope, da, dg, dummy);
         acc[0] += da; acc[1] += (double)da * ((xa - mu) * is);
         if (ACT == MOGAN_ACT_GLU) { acc[2] += dg; acc[3] += (double)dg * ((xg - mu2) * is2); }
     }
@@ -551,12 +585,13 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     }
     __syncthreads();
     const float inv_n = 1.f / ((float)B * (float)HW);
-    for (int e = threadIdx.x; e < NE; e += 256) {
-        const int b = e / HW, pos = e - b * HW;
-        const size_t ia = ((size_t)b * C + c) * HW + pos, ig = ia + (size_t)Cy * HW;
-        const float xa = x[ia], xg = (ACT == MOGAN_ACT_GLU) ? x[ig] : 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        if (off[i] == 0xFFFFFFFFu) continue;
+        const size_t ia = off[i], ig = ia + (size_t)Cy * HW;
+        const float xa = xv[0][i], xg = xv[NCH - 1][i];
         float da, dg;
-        act_bwd<ACT>(xa, xg, dy[((size_t)b * Cy + c) * HW + pos], sc, sh, sc2, sh2, slope, da, dg, dummy);
+        act_bwd<ACT>(xa, xg, dv[i], sc, sh, sc2, sh2, slope, da, dg, dummy);
         dx[ia] = sc * (da - sums[0] * inv_n - (xa - mu) * is * sums[1] * inv_n);
         if (ACT == MOGAN_ACT_GLU) dx[ig] = sc2 * (dg - sums[2] * inv_n - (xg - mu2) * is2 * sums[3] * inv_n);
     }

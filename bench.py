@@ -625,8 +625,13 @@ def main():
         dist.destroy_process_group()
     if os.environ.get("MOGAN_CHAIN_EVENTS") and rank == 0:       # diagnostic: where the main stream (generator chain) spends the step
         out["chain_ms"] = engine.chain_report()
-    if rank == 0:                      # the JSON line is the last thing on stdout (RCCL prints its banner there too)
-        sys.stdout.flush()
+    if rank == 0:                      # the JSON line is the last thing on stdout (RCCL prints its banner there too, through C stdio:
+        sys.stdout.flush()             # flush that buffer first, or the banner lands behind the line at exit)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
 

@@ -1,4 +1,6 @@
-python -m pytest tests/test_kernels_gpu.py -q -x -k "bn_act or deep_block or group_sum" 2>&1 | tail -2
-python -m pytest tests/test_model_gpu.py tests/test_fullwidth_parity_gpu.py -q -x 2>&1 | grep -E "passed|failed|error" | tail -2
-bash tools/prof_stats.sh r4s_ks_single > /dev/null 2>&1
-for i in 1 2; do python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'])"; done
+mkdir -p gpurun_out/r4q
+P=$(python -c "import socket; s=socket.socket(); s.bind(('127.0.0.1',0)); print(s.getsockname()[1])")
+MOGAN_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$P python bench.py --no-cpu-baseline --no-roofline > gpurun_out/r4q/pg.out 2> gpurun_out/r4q/pg.err
+echo rc=$?
+tail -5 gpurun_out/r4q/pg.err | cut -c1-300
+tail -1 gpurun_out/r4q/pg.out | cut -c1-100

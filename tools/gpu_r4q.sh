@@ -1,6 +1,7 @@
-mkdir -p gpurun_out/r4q
-P=$(python -c "import socket; s=socket.socket(); s.bind(('127.0.0.1',0)); print(s.getsockname()[1])")
-MOGAN_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$P python bench.py --no-cpu-baseline --no-roofline > gpurun_out/r4q/pg.out 2> gpurun_out/r4q/pg.err
-echo rc=$?
-tail -5 gpurun_out/r4q/pg.err | cut -c1-300
-tail -1 gpurun_out/r4q/pg.out | cut -c1-100
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; RN=r04
+cd /tmp && export TMPDIR=/tmp
+E="MOGAN_FAST_INIT=1 MOGAN_STREAMS=0 MOGAN_WGRAD_STREAM=0 MOGAN_GRAPH_ENCODER=0"
+B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+env $E rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- $B > /tmp/pf.log 2>&1
+env $E rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- $B > /tmp/pw.log 2>&1
+python $R/tools/pmc_traffic.py /tmp/pf/f_counter_collection.csv /tmp/pw/w_counter_collection.csv $O/${RN}_pmc_traffic.json

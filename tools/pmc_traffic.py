@@ -23,7 +23,8 @@ KEEP = ("gemm_kernel", "pgemm_kernel", "pgemm_group_kernel", "dconv_fwd_kernel",
 
 
 def short(name):
-    name = name.replace("gemm_group_kernel", "gemm_kernel")      # grouped launches of the same tile kernel
+    if "pgemm_group_kernel" not in name:
+        name = name.replace("gemm_group_kernel", "gemm_kernel")      # grouped launches of the same tile kernel
     m = re.search(r"(pgemm_group_kernel|pgemm_kernel|gemm_kernel|dconv_fwd_kernel|dconv_wgrad_kernel|wino3_fwd_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))

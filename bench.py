@@ -119,8 +119,13 @@ def load_traffic():
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not found:
-        return {}
+        return {}, None
     path = found[-1]
+    import hashlib
+    # the counters cannot be read inside a timed run (rocprofv3 --pmc serialises the kernels): `traffic` is a lookup in the
+    # newest committed counter pass -- the line says which file, so a reader can tell a stale pass from a current one
+    source = {"file": os.path.relpath(path, ROOT), "sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16],
+              "measured_in_this_run": False}
     acc = {}
     for name, v in json.load(open(path))["kernels"].items():
         fam = name.split("<")[0]
@@ -129,7 +134,7 @@ def load_traffic():
         # fetch x2: the guide's gfx950 correction for 16-byte coalesced reads (an upper bound here, see tools/pmc_traffic.py)
         a[0] += (2.0 * (v.get("fetch_kb_per_launch") or 0.0) + (v.get("write_kb_per_launch") or 0.0)) * 1024.0 * n
         a[1] += n
-    return {f: (b / n if n else None) for f, (b, n) in acc.items()}
+    return {f: (b / n if n else None) for f, (b, n) in acc.items()}, source
 
 
 def roofline_leg(engine, run_step, steps=2):
@@ -582,7 +587,7 @@ def main():
             a = fams.setdefault(f, dict(kernel=f, launches_per_step=0.0, gflop_per_step=0.0, ms_per_step=0.0))
             for k in ("launches_per_step", "gflop_per_step", "ms_per_step"):
                 a[k] += r[k]
-        traffic = load_traffic()
+        traffic, traffic_source = load_traffic()
         peak, peak_note = mfma_peak()
         for f, a in fams.items():
             a["tflops"] = a["gflop_per_step"] / a["ms_per_step"] if a["ms_per_step"] else 0.0
@@ -599,7 +604,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "peak_note": peak_note,
             "unit": "TFLOP/s", "frac": dom["frac"], "frac_f32_mfma": dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
-            "traffic": dom["traffic_bytes_per_launch"],
+            "traffic": dom["traffic_bytes_per_launch"], "traffic_source": traffic_source,
             "launches_per_step": dom["launches_per_step"],
             "avg_launch_ms": dom["ms_per_step"] / dom["launches_per_step"],
             "gflop_per_launch": dom["gflop_per_step"] / dom["launches_per_step"],

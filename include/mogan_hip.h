@@ -230,17 +230,23 @@ int mogan_conv2d_wgrad_pk(const float* dy, const float* x, float* dw, int B, int
  *             rmean / rvar updated like nn.BatchNorm (momentum, unbiased variance), nullable
  *   backward  dz -> dy (B,Cout,OH,OW: gradient at the conv output, what the weight gradient needs), dgamma / dbeta (nullable;
  *             accumulate != 0 adds), dx (nullable: no data gradient) from wpk_dgrad = data-gradient packed weights
+ *   groups    1, or 2 (round 5): the B images are `groups` batches of B / groups images one behind the other which the reference
+ *             passes through the layer in separate calls -- D(real) and D(fake.detach()) of a discriminator update,
+ *             miscc/losses.py:136-174 --: ONE convolution over all B images (the weights stream once), batch statistics per
+ *             group (stats = mean[groups][Cout] | invstd[groups][Cout]), running statistics updated group after group in that
+ *             order, d gamma / d beta = the groups' sums.  B / groups * OH*OW <= 2048.
  * Same arithmetic as mogan_bn_stats / mogan_bn_act_fwd / mogan_bn_act_bwd (fp64 sums). */
 size_t mogan_pk_panel_bytes(int B, int C, int HW);
-int mogan_deep_block_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act);
+int mogan_deep_block_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act,
+                              int groups);
 int mogan_deep_conv_bn_act_fwd(const float* x, const void* xpanel, const void* wpk, const float* gamma, const float* beta,
                                float* rmean, float* rvar, float* y, float* stats, float* z, void* zpanel, int B, int Cin, int Hs,
                                int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, float eps, float momentum, int act,
-                               float slope, void* ws, size_t ws_bytes, hipStream_t stream);
+                               float slope, int groups, void* ws, size_t ws_bytes, hipStream_t stream);
 int mogan_deep_conv_bn_act_bwd(const float* dz, const float* y, const float* stats, const float* gamma, const float* beta,
                                const void* wpk_dgrad, float* dy, float* dgamma, float* dbeta, int accumulate, float* dx, int B,
                                int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act, float slope,
-                               void* ws, size_t ws_bytes, hipStream_t stream);
+                               int groups, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* ---- Frozen CNN_ENCODER trunk on pixel panels (code/coco/attngan/model.py:258-299: Mixed_5b .. Mixed_7c of the frozen, eval-mode
  * Inception-v3; trainer.py:329-333 sends only the image gradient through it).  With frozen weights every filter is packed ONCE
@@ -313,6 +319,15 @@ int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
  * BN+residual: 75,80. */
 int mogan_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                      const float* residual, float* y, int B, int C, int HW, int act, float slope, hipStream_t stream);
+/* The running-statistics update of a BatchNorm call that was made with running_mean = running_var = NULL, from the batch
+ * statistics that call wrote (mean / invstd, n = B*HW values per channel): nn.BatchNorm's momentum update with the unbiased
+ * variance.  Lets a call's arithmetic run EARLIER than its place in the reference's call order while the running buffers are
+ * updated in that order: round 5 evaluates the real-image terms of discriminator_loss (miscc/losses.py:146-160: D(real), the
+ * conditional head on real and on the "wrong" pairs) and back-propagates them before the fake images exist; the reference
+ * calls COND_DNET on the fake features BEFORE the wrong pairs, so the wrong call's update is deferred behind the fake call's. */
+int mogan_bn_running_update(const float* mean, const float* invstd, float* running_mean, float* running_var, int C, long long n,
+                            float eps, float momentum, hipStream_t stream);
+
 /* mogan_bn_stats + mogan_bn_act_fwd in one call (training-mode BatchNorm + activation, model.py:48-81, 575-613): maps with
  * B*HW <= 4096 values per channel (and HW >= 16) take ONE launch -- a block per output channel reduces, finalises and applies --,
  * larger ones the three launches of the two calls above; mean / invstd [C] are written for mogan_bn_act_bwd either way (which
@@ -397,7 +412,12 @@ int mogan_conv2d_dgrad_wp(const float* dy, const void* planes, float* dx, int B,
  *   x_plane  x is (xB, C): one value per (image, channel), constant over the Hin x Win plane -- the label vector the
  *            reference first .repeat()s over 16 x 16 (model.py:109-111); dx is (xB, C);
  *   theta_G  > 0: theta is stored (B / theta_G, theta_G, 2, 3) -- the loader's (image, object) order -- while the batch is
- *            object-major, sample b = g (B / theta_G) + b' using theta[b'][g] (the batched object loops); 0: theta[b]. */
+ *            object-major, sample b = g (B / theta_G) + b' using theta[b'][g] (the batched object loops); 0: theta[b].
+ * Determinism: mogan_stn_bwd (like torch's grid_sample backward) scatters with fp32 atomicAdd, so the sum of the <= 4 output
+ * pixels' contributions that meet in one source pixel depends on execution order; the shared-source forms add all OBJECTS'
+ * contributions to that same sum (the reference adds G separately computed tensors in object order).  The result is
+ * therefore reproducible to fp32 rounding of a sum of <= 4 G terms (measured run to run: <= 2 ulp of the largest term), not
+ * bit for bit -- tests/test_kernels_gpu.py::test_stn_shared_source_gradient_is_order_independent_to_rounding pins that. */
 int mogan_stn_fwd_ex(const float* x, const float* theta, float* y, int B, int C, int Hin, int Win, int Hout, int Wout,
                      int align_corners, int xB, int x_plane, int theta_G, hipStream_t stream);
 int mogan_stn_bwd_ex(const float* dy, const float* theta, float* dx, int B, int C, int Hin, int Win, int Hout, int Wout,

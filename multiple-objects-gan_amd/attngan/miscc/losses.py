@@ -7,6 +7,7 @@ Same function names / arguments / return values as the reference.  Differences u
     reference's B-iteration python loop over func_attention (losses.py:72-112).
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -103,13 +104,50 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
     return l0, l1, att_maps
 
 
+# D(real) and D(fake.detach()) of a discriminator update as ONE pass over the batch [real; fake] with BatchNorm statistics per
+# half (round 5): the reference makes two calls (losses.py:146,152), i.e. two sets of batch statistics and two running-
+# statistics updates, real first -- the grouped BatchNorm / deep-block kernels (groups = 2) compute exactly those, while every
+# convolution sees 2B images: the deep layers' weights (up to 300 MB per layer of D_NET256) stream once per direction instead
+# of twice and their GEMMs have twice the columns.  MOGAN_D_PAIR=0: the two calls.  Networks without the PAIRED attribute
+# (D_NET64: the object pathway already runs as a 3-group batch) keep the two calls.
+D_PAIR = os.environ.get("MOGAN_D_PAIR", "0") != "0"
+
+
+def paired(netD):
+    return D_PAIR and bool(getattr(netD, "PAIRED", False)) and netD.training and torch.is_grad_enabled()
+
+
+def _paired_features(netD, real_imgs, fake_imgs):
+    B = real_imgs.shape[0]
+    x = ops._cat_batch(real_imgs.detach(), fake_imgs.detach())
+    trace0 = len(ops.ACT_TRACE) if ops.ACT_TRACE is not None else None
+    ops.TRACE_GROUPS = 2
+    try:
+        f = netD(x, groups=2)
+    finally:
+        ops.TRACE_GROUPS = 1
+    if trace0 is not None:
+        # test hook: the recorded activations back into the reference's call order -- all of D(real), then all of D(fake)
+        new = []
+        for e in ops.ACT_TRACE[trace0:]:
+            new.extend([e] if len(e) == 3 else [(e[0], e[1][:B], 0), (e[0], e[1][B:], 1)])
+        del ops.ACT_TRACE[trace0:]
+        for g in (0, 1):
+            ops.ACT_TRACE.extend((e[0], e[1]) for e in new if e[2] == g)
+    return ops.split_batch(f, B)
+
+
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels, gpus=None,
                        local_labels=None, transf_matrices=None, transf_matrices_inv=None, real_features=None):
-    """losses.py:136-174.  D(real) and D(fake.detach()) are two separate calls (separate BN batch
-    statistics); real_labels/fake_labels are the constant 1/0 vectors of prepare_labels."""
-    if real_features is None:       # (the engine may have run D(real) already, concurrently with the G forward)
-        real_features = _call_d(netD, real_imgs, local_labels, transf_matrices, transf_matrices_inv)
-    fake_features = _call_d(netD, fake_imgs.detach(), local_labels, transf_matrices, transf_matrices_inv)
+    """losses.py:136-174.  D(real) and D(fake.detach()) are two separate calls in the reference (separate BN batch
+    statistics) -- here one pass over [real; fake] with per-half statistics where the network supports it and MOGAN_D_PAIR=1
+    (see D_PAIR); real_labels/fake_labels are the constant 1/0 vectors of prepare_labels."""
+    if real_features is None and local_labels is None and paired(netD) and real_imgs.shape == fake_imgs.shape:
+        real_features, fake_features = _paired_features(netD, real_imgs, fake_imgs)
+    else:
+        if real_features is None:   # (the engine may have run D(real) already, concurrently with the G forward)
+            real_features = _call_d(netD, real_imgs, local_labels, transf_matrices, transf_matrices_inv)
+        fake_features = _call_d(netD, fake_imgs.detach(), local_labels, transf_matrices, transf_matrices_inv)
     if parallel.enabled():          # heads, wrong-pair shift and BCE means over the gathered batch (parallel.py)
         real_features, fake_features = parallel.gather_cat(real_features), parallel.gather_cat(fake_features)
         conditions = parallel.gather_const(conditions)
@@ -124,6 +162,55 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
         return ops.scalar_sum([real_errD, cond_real_errD, fake_errD, cond_fake_errD, cond_wrong_errD],
                               [0.5, 0.5, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0])
     return ops.scalar_sum([cond_real_errD, cond_fake_errD, cond_wrong_errD], [1.0, 0.5, 0.5])
+
+
+# The discriminator loss in two halves (round 5).  errD = R(real images) + F(fake images): losses.py:146-174 evaluates
+#   R = (BCE(uncond(real), 1) + BCE(cond(real), 1)) / 2 + BCE(cond(real[:-1], conditions[1:]), 0) / 3      [no fake image in it]
+#   F = (BCE(uncond(fake), 0) + BCE(cond(fake), 0)) / 3
+# (without the unconditional head: R = cond_real + cond_wrong / 2, F = cond_fake / 2).  d errD / d theta = dR + dF, and the
+# parameter gradients accumulate in place, so R can be evaluated AND back-propagated as soon as the batch is on the device --
+# beside the generator's forward (and the tail of the previous step) -- and only F waits for the fake images: one of the two
+# backward passes through D_i leaves the window between the generator's forward and its backward, which the D_NET256 branch
+# bounds (trainer.TrainEngine).  Same terms, same gradients up to the order of two additions.  BatchNorm running statistics
+# keep the reference's CALL order (D(real), D(fake), cond(real), cond(fake), cond(wrong)): only the conditional head's
+# BatchNorm sees more than one call per half, and its wrong-pair call -- made early, with the real half -- defers its running
+# update behind the fake call's (hip/ops.BN_DEFER, mogan_bn_running_update).
+def discriminator_loss_real(netD, real_imgs, conditions, local_labels=None, transf_matrices=None, transf_matrices_inv=None):
+    """R of the comment above; returns (R, pending running-statistics updates of the wrong-pair head call)"""
+    real_features = _call_d(netD, real_imgs, local_labels, transf_matrices, transf_matrices_inv)
+    batch_size = real_features.size(0)
+    cond_real_errD = ops.bce(netD.COND_DNET(real_features, conditions), 1.0)
+    pending, ops.BN_DEFER = [], []
+    try:
+        cond_wrong_errD = ops.bce(netD.COND_DNET(real_features[:(batch_size - 1)], conditions[1:batch_size]), 0.0)
+    finally:
+        pending, ops.BN_DEFER = ops.BN_DEFER, None
+    if netD.UNCOND_DNET is not None:
+        real_errD = ops.bce(netD.UNCOND_DNET(real_features), 1.0)
+        return ops.scalar_sum([real_errD, cond_real_errD, cond_wrong_errD], [0.5, 0.5, 1.0 / 3.0]), pending
+    return ops.scalar_sum([cond_real_errD, cond_wrong_errD], [1.0, 0.5]), pending
+
+
+def discriminator_loss_fake(netD, fake_imgs, conditions, pending, local_labels=None, transf_matrices=None,
+                            transf_matrices_inv=None):
+    """F of the comment above; applies the deferred running-statistics updates behind the fake call of the conditional head"""
+    fake_features = _call_d(netD, fake_imgs.detach(), local_labels, transf_matrices, transf_matrices_inv)
+    cond_fake_errD = ops.bce(netD.COND_DNET(fake_features, conditions), 0.0)
+    if pending:
+        with torch.no_grad():
+            ops.bn_apply_deferred(pending)
+    if netD.UNCOND_DNET is not None:
+        fake_errD = ops.bce(netD.UNCOND_DNET(fake_features), 0.0)
+        return ops.scalar_sum([fake_errD, cond_fake_errD], [1.0 / 3.0, 1.0 / 3.0])
+    return ops.scalar_sum([cond_fake_errD], [0.5])
+
+
+D_SPLIT = os.environ.get("MOGAN_D_SPLIT", "0") != "0"
+
+
+def split_d_loss():
+    """may the engine take the two-halves form?  (not with the gathered global-batch heads, not with the paired pass)"""
+    return D_SPLIT and not D_PAIR and not parallel.enabled()
 
 
 def generator_d_branch(netD, fake_img, sent_emb, local_labels=None, transf_matrices=None, transf_matrices_inv=None):

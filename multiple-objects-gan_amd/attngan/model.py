@@ -460,8 +460,11 @@ class D_NET128(_D_BASE):
         self.img_code_s32_1 = Block3x3_leakRelu(ndf * 16, ndf * 8)
         self._logit_heads(b_jcu)
 
-    def forward(self, x_var):
-        return self.img_code_s32_1(self.img_code_s32(self.img_code_s16(x_var)))
+    PAIRED = True           # forward(x, groups=2): x = [real; fake], one pass with per-half BatchNorm statistics (losses.py)
+
+    def forward(self, x_var, groups=1):
+        x = self.img_code_s32(self.img_code_s16(x_var, groups=groups), groups=groups)
+        return self.img_code_s32_1(x, groups=groups)
 
 
 class D_NET256(_D_BASE):
@@ -477,6 +480,9 @@ class D_NET256(_D_BASE):
         self.img_code_s64_2 = Block3x3_leakRelu(ndf * 16, ndf * 8)
         self._logit_heads(b_jcu)
 
-    def forward(self, x_var):
-        x = self.img_code_s64(self.img_code_s32(self.img_code_s16(x_var)))
-        return self.img_code_s64_2(self.img_code_s64_1(x))
+    PAIRED = True
+
+    def forward(self, x_var, groups=1):
+        x = self.img_code_s32(self.img_code_s16(x_var, groups=groups), groups=groups)
+        x = self.img_code_s64(x, groups=groups)
+        return self.img_code_s64_2(self.img_code_s64_1(x, groups=groups), groups=groups)

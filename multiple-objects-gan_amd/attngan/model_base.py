@@ -55,27 +55,26 @@ class _HipBNMixin:
             else:
                 self.num_batches_tracked += 1
 
-    def fused_with_conv(self, x, conv, act=ops.ACT_NONE, slope=0.2):
+    def fused_with_conv(self, x, conv, act=ops.ACT_NONE, slope=0.2, groups=1):
         """conv -> this BatchNorm (training statistics) -> act as ONE deep block (hip/ops.DeepConvBNActFn); the caller has
-        checked ops.deep_block_eligible."""
-        self._count_call()
+        checked ops.deep_block_eligible.  groups: BatchNorm calls the batch stands for (see fused)."""
+        for _ in range(groups):
+            self._count_call()
         ph, pw = conv.padding if isinstance(conv.padding, tuple) else (conv.padding, conv.padding)
         return ops.deep_conv_bn_act(x, conv.weight, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
-                                    self.eps, self.momentum, conv.stride[0], ph, pw)
+                                    self.eps, self.momentum, conv.stride[0], ph, pw, groups)
 
     def fused(self, x, act=ops.ACT_NONE, slope=0.2, residual=None, groups=1):
         """groups > 1: x holds `groups` batches one behind the other, each of which the reference passes through this layer in a
-        call of its own (one BatchNorm call per object): own batch statistics per group, running statistics and the
-        call counter updated group after group -- one launch where the maps are small, else one call per group."""
+        call of its own (one BatchNorm call per object; D(real) and D(fake) of a discriminator update): own batch
+        statistics per group, running statistics and the call counter updated group after group -- one launch where the maps
+        are small, else the large-map kernels once per group on the group's slice (hip/ops.BNActGroupedFn)."""
         if self.training and groups > 1:
             assert residual is None
-            if ops.bn_groups_ok(x, groups):
-                for _ in range(groups):
-                    self._count_call()
-                return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope, None, self.eps,
-                                  self.momentum, groups=groups)
-            n = x.shape[0] // groups
-            return torch.cat([self.fused(x[g * n:(g + 1) * n], act, slope) for g in range(groups)])
+            for _ in range(groups):
+                self._count_call()
+            return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope, None, self.eps,
+                              self.momentum, groups=groups)
         if self.training:
             self._count_call()
             return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, act, slope,
@@ -127,8 +126,6 @@ class FusedSeq(nn.Sequential):
         """conv (no bias) -> BatchNorm2d (training) [-> LeakyReLU / ReLU] on a small map with packed weights: one fused deep
         block (model.py:575-613, 616-642); returns (output, index behind the matched children) or None"""
         m, n = mods[i], len(mods)
-        if groups > 1:
-            return None                                   # (per-group statistics: the grouped BatchNorm kernels)
         if up or not isinstance(m, HipConv2d) or m.bias is not None or i + 1 >= n or m.stride[0] != m.stride[1]:
             return None
         bn = mods[i + 1]
@@ -145,9 +142,9 @@ class FusedSeq(nn.Sequential):
         if j == n and residual is not None:
             return None
         ph, pw = m.padding if isinstance(m.padding, tuple) else (m.padding, m.padding)
-        if not ops.deep_block_eligible(x, m.weight, m.stride[0], ph, pw, code):
-            return None
-        return bn.fused_with_conv(x, m, code, slope), j
+        if not ops.deep_block_eligible(x, m.weight, m.stride[0], ph, pw, code, groups):
+            return None                                   # (more than two groups: the grouped BatchNorm kernels)
+        return bn.fused_with_conv(x, m, code, slope, groups), j
 
     def forward(self, x, residual=None, groups=1):
         """groups: see _HipBNMixin.fused (the convolutions / linears see one batch of groups*B samples)"""
@@ -170,7 +167,7 @@ class FusedSeq(nn.Sequential):
                     x = ops.logits_head(x, m.weight, m.bias)
                     i += 2
                     continue
-                if (isinstance(m, HipConv2d) and not up and m.bias is None and groups == 1 and i + 1 < n
+                if (isinstance(m, HipConv2d) and not up and m.bias is None and i + 1 < n
                         and _act_of(mods[i + 1])[0] == ops.ACT_LRELU and x.dim() == 4 and x.shape[1] <= 16):
                     # conv -> LeakyReLU with no BatchNorm in between (the first layer of a discriminator, model.py:597-598):
                     # the activation rides in the convolution's epilogue

@@ -30,8 +30,8 @@ import torch.distributed as dist
 
 from ..hip import ops
 from .miscc.config import cfg
-from .miscc.losses import (KL_loss, discriminator_loss, generator_d_branch, generator_damsm_branch, generator_loss,
-                           generator_total)
+from .miscc.losses import (KL_loss, discriminator_loss, discriminator_loss_fake, discriminator_loss_real,
+                           generator_d_branch, generator_damsm_branch, generator_loss, generator_total, split_d_loss)
 from .miscc.utils import copy_G_params, load_params, mkdir_p, weights_init
 from .model_base import BNCallCounter
 from .model import CNN_ENCODER, D_NET64, D_NET128, D_NET256, G_NET, RNN_ENCODER
@@ -67,8 +67,27 @@ class FlatAdam:
         # that qualify, re-packed here after every change of the bucket
         self._pk_cell = [0]
         self.packs = [ops.attach_packs(p, self._pk_cell) for p in self.params if p.dim() == 4] if dev.type == "cuda" else []
+        self._hook = None
         if isinstance(module, torch.nn.Module):
-            module.register_load_state_dict_post_hook(lambda m, keys: self.touch())
+            # through a weak reference: the module must not keep a dropped optimizer (and its four flat buckets, 2.5 GB for
+            # D_NET256) alive -- nor let it go on re-packing the shared weight copies at every later load_state_dict
+            import weakref
+            ref = weakref.ref(self)
+
+            def _touch(m, keys, _ref=ref):
+                me = _ref()
+                if me is not None:
+                    me.touch()
+            self._hook = module.register_load_state_dict_post_hook(_touch)
+
+    def close(self):
+        """Detach from the module (a second optimizer over the same network follows): the load_state_dict hook goes, and this
+        object no longer re-packs the weight copies it shares with its successor."""
+        if self._hook is not None:
+            self._hook.remove()
+            self._hook = None
+        self.repack_on_touch = False
+        self.packs = []
 
     repack_on_touch = False     # set by an engine that holds captured graphs: those read the packed copies without asking
 
@@ -436,6 +455,9 @@ class TrainEngine:
         # there for hosts whose python is slower than the GPU's 40 ms step.
         self.g_graphs = self.branch_graphs and not self.distributed and os.environ.get("MOGAN_G_GRAPHS", "0") != "0"
         self._bg = None
+        # the discriminator loss in two halves: the real-image terms evaluated and back-propagated ahead of the generator's
+        # forward (miscc/losses.py: discriminator_loss_real / _fake; MOGAN_D_SPLIT=0: one loss, one backward after the forward)
+        self.split_d = self.multi_stream and split_d_loss()
         self.side = [_engine_stream(("side", i)) for i in range(len(netsD) + 1)]
         bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
         if bmap:
@@ -481,6 +503,12 @@ class TrainEngine:
         for r in self.reducers.values():
             r.close()
         self.reducers = {}
+        # the optimizers' buckets and the captured graphs (with their private memory pools) go with the engine: a successor
+        # builds its own over the same networks (its FlatAdam re-points the parameters at its buckets)
+        for o in [self.optG] + list(self.optDs):
+            if o is not None:
+                o.close()
+        self._bg, self._graph, self._enc_graphs = None, None, {}
 
     def repack_all(self):
         """Weights were written behind the optimizers' backs (load_params / invalidate_all_packs, a checkpoint restore) while
@@ -550,13 +578,36 @@ class TrainEngine:
             self._enc_graphs[key] = g
         return g
 
-    def _d_real(self, i, b):
-        """zero_grad + D_i(real): independent of the generator, so it can run beside the G forward."""
-        from .miscc.losses import _call_d
+    def _d_kw(self, i, b):
+        return dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"], transf_matrices_inv=b["tmi"]) if i == 0 else {}
+
+    def _d_real(self, i, b, sent_emb=None):
+        """zero_grad + the real-image half of D_i's update: independent of the generator, so it runs beside the G forward (and the
+        tail of the previous step).  Split form (miscc/losses.split_d_loss, the default): the real-image terms of the loss are
+        evaluated AND back-propagated here -- returns ("split", R, pending running-statistics updates); otherwise only D_i(real)
+        is evaluated and its features are returned (None with the paired pass)."""
+        from .miscc.losses import _call_d, paired
         self.optDs[i].zero_grad()
+        if paired(self.netsD[i]):                # D_i(real) rides with D_i(fake) as one [real; fake] pass (losses.D_PAIR)
+            return None
+        if self.split_d:
+            errR, pend = discriminator_loss_real(self.netsD[i], b["imgs"][i], b["sent_emb"] if sent_emb is None else sent_emb,
+                                                 **self._d_kw(i, b))
+            with ops.wgrad_overlap():
+                errR.backward()
+            return ("split", errR.detach(), pend)
         if i == 0:
             return _call_d(self.netsD[i], b["imgs"][i], b["label_one_hot"], b["tm"], b["tmi"])
         return _call_d(self.netsD[i], b["imgs"][i], None, None, None)
+
+    def _d_fake(self, i, b, fake_imgs, early, sent_emb=None):
+        """the fake-image half (split form): F, its backward; returns errD_i = R + F (detached)"""
+        _, errR, pend = early
+        errF = discriminator_loss_fake(self.netsD[i], fake_imgs[i], b["sent_emb"] if sent_emb is None else sent_emb, pend,
+                                       **self._d_kw(i, b))
+        with ops.wgrad_overlap():
+            errF.backward()
+        return ops.scalar_sum([errR, errF.detach()])
 
     def _d_loss(self, i, b, fake_imgs, real_labels, fake_labels, real_features=None):
         kw = dict(local_labels=b["label_one_hot"], transf_matrices=b["tm"],
@@ -648,9 +699,12 @@ class TrainEngine:
             # Adam): only their own stream order (D_i's previous Adam) and the input batch matter.
             cur0 = torch.cuda.current_stream()
             ready = b.get("inputs_ready")
+            text_ev = self._text_first(b, ready) if self.split_d else None     # (the real half needs the sentence embedding)
             for i in range(len(netsD))[::-1]:
                 if ready is not None:
                     self.side[i].wait_event(ready)
+                    if text_ev is not None:
+                        self.side[i].wait_event(text_ev)
                 else:
                     self.side[i].wait_stream(cur0)
                 with torch.cuda.stream(self.side[i]):
@@ -681,10 +735,14 @@ class TrainEngine:
                 s = self.side[i]
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
-                    errD = self._d_loss(i, b, fake_imgs, real_labels, fake_labels, real_feat.get(i))
-                    with ops.wgrad_overlap():
-                        errD.backward()
-                    out["errD%d" % i] = errD.detach()
+                    early = real_feat.get(i)
+                    if isinstance(early, tuple):
+                        out["errD%d" % i] = self._d_fake(i, b, fake_imgs, early)
+                    else:
+                        errD = self._d_loss(i, b, fake_imgs, real_labels, fake_labels, early)
+                        with ops.wgrad_overlap():
+                            errD.backward()
+                        out["errD%d" % i] = errD.detach()
 
             def d_tail(i):          # all-reduce, Adam, then the G-step forward through the updated D_i
                 with torch.cuda.stream(self.side[i]):
@@ -779,11 +837,13 @@ class TrainEngine:
         The forward of D_i(real) and the rest live in two graphs of one memory pool so that D_i(real) can be replayed early,
         beside the generator's forward."""
         from ..hip import lib as _lib
-        from .miscc.losses import _call_d
+        from .miscc.losses import _call_d, paired
         netsD, nD = self.netsD, len(self.netsD)
         st = {k: b[k].clone() for k in self._BG_KEYS}
         st["imgs"] = [t.clone() for t in b["imgs"]]
         st["fake"] = [t.detach().clone() for t in fake_imgs]
+        st["sent"] = [b["sent_emb"].clone() for _ in self.netsD]       # split form: a copy per branch, written on ITS stream
+        split = self.split_d
         B = b["z"].shape[0]
         real_labels, fake_labels = b["z"].new_ones(B), b["z"].new_zeros(B)
         bg = {"static": st, "gR": [], "gU": [], "gA": [], "out": [], "calls": [], "B": B}
@@ -812,16 +872,14 @@ class TrainEngine:
                    torch.empty((), dtype=torch.float32, device=st["fake"][i].device), torch.empty_like(st["fake"][i]))
             with _lib.capture_guard():
                 with torch.cuda.graph(gR, pool=pool, stream=s):
-                    self.optDs[i].zero_grad()
-                    feat = _call_d(netsD[i], st["imgs"][i], kw.get("local_labels"), kw.get("transf_matrices"),
-                                   kw.get("transf_matrices_inv"))
+                    feat = self._d_real(i, st, st["sent"][i])          # (zero_grad; D_i(real) or the whole real half)
                 def tail(errD):
                     # Adam (+ re-pack), then the generator-step forward through the updated D_i and its image gradient
                     self._opt_step(self.optDs[i], None)
                     for p in netsD[i].parameters():
                         p.requires_grad_(False)
                     leaf = st["fake"][i].detach().requires_grad_(True)
-                    g_loss = generator_d_branch(netsD[i], leaf, st["sent_emb"], **kw)
+                    g_loss = generator_d_branch(netsD[i], leaf, st["sent"][i] if split else st["sent_emb"], **kw)
                     g_img, = torch.autograd.grad(g_loss, leaf)
                     for p in netsD[i].parameters():
                         p.requires_grad_(True)
@@ -830,10 +888,13 @@ class TrainEngine:
                     return res
 
                 with torch.cuda.graph(gU, pool=pool, stream=s):
-                    errD = discriminator_loss(netsD[i], st["imgs"][i], st["fake"][i], st["sent_emb"], real_labels, fake_labels,
-                                              None, real_features=feat, **kw)
-                    with ops.wgrad_overlap():
-                        errD.backward()
+                    if isinstance(feat, tuple):
+                        errD = self._d_fake(i, st, st["fake"], feat, st["sent"][i])
+                    else:
+                        errD = discriminator_loss(netsD[i], st["imgs"][i], st["fake"][i], st["sent_emb"], real_labels,
+                                                  fake_labels, None, real_features=feat, **kw)
+                        with ops.wgrad_overlap():
+                            errD.backward()
                     if gA is None:
                         out = tail(errD)
                 if gA is not None:
@@ -935,11 +996,15 @@ class TrainEngine:
             torch.cuda.synchronize()
         bg, st = self._bg, self._bg["static"]
         ready = b.get("inputs_ready")
-        # D_i(real): beside the text encoder and the generator's forward (and the tail of the previous step)
+        text_ev = self._text_first(b, ready) if self.split_d else None
+        # D_i(real) -- split form: the whole real half of D_i's update --: beside the text encoder and the generator's forward
+        # (and the tail of the previous step)
         for i in range(nD)[::-1]:
             s = self.side[i]
             if ready is not None:
                 s.wait_event(ready)
+                if text_ev is not None:
+                    s.wait_event(text_ev)
             else:
                 s.wait_stream(cur)
             with torch.cuda.stream(s):
@@ -947,6 +1012,8 @@ class TrainEngine:
                 if i == 0:
                     for k in ("label_one_hot", "tm", "tmi"):
                         st[k].copy_(b[k])
+                if self.split_d:
+                    st["sent"][i].copy_(b["sent_emb"])
                 bg["gR"][i].replay()
         if ready is not None:
             cur.wait_event(ready)
@@ -1051,20 +1118,39 @@ class TrainEngine:
         branch streams and finished just as late.)  step() picks the result up when it is given the very same captions tensor."""
         self._tx_next = (captions, cap_lens_cpu)
 
+    def _text_first(self, b, ready=None):
+        """split discriminator loss: the batch's text embeddings BEFORE the branches fork (their real halves read the sentence
+        embedding); returns the event behind the encoder's launches, or None when the caller supplied the embeddings (they are
+        then part of the batch, covered by its inputs_ready event / the stream order)"""
+        if "words_embs" in b:
+            return None
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
+        b["words_embs"], b["sent_emb"], b["mask"] = self._text_for(b)
+        return self._text_ev
+
     def _text_in_window(self):
         """called by the step between the generator forward and the join with the side branches"""
         nxt, self._tx_next = getattr(self, "_tx_next", None), None
         if nxt is None:
             return
         w, s_, m = self.encode_text(nxt[0], nxt[1])
-        self._tx_ready = (nxt[0], (w, s_, m))
+        ev = torch.cuda.Event()
+        ev.record()
+        self._tx_ready = (nxt[0], (w, s_, m), ev)
 
     def _text_for(self, b):
         """the batch's text embeddings: prefetched (see prefetch_text; same stream, so no event) or computed here"""
         hit, self._tx_ready = getattr(self, "_tx_ready", None), None
         if hit is not None and hit[0] is b["captions"]:
+            self._text_ev = hit[2]
             return hit[1]
-        return self.encode_text(b["captions"], b["cap_lens_cpu"])
+        out = self.encode_text(b["captions"], b["cap_lens_cpu"])
+        self._text_ev = None
+        if not torch.cuda.is_current_stream_capturing():
+            self._text_ev = torch.cuda.Event()
+            self._text_ev.record()
+        return out
 
     def encode_text(self, captions, cap_lens):
         """trainer.py:281-289."""

@@ -126,6 +126,25 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     }
 }
 
+// Deferred running-statistics update of a BatchNorm call that ran with running_mean / running_var = NULL: from the batch
+// statistics it left (mean, invstd), applied later so that the running buffers see the reference's CALL ORDER although the call's
+// arithmetic ran earlier (the "wrong pair" head of a discriminator update, miscc/losses.py:152-160, evaluated with the real half
+// before the fake images exist).  var = 1 / invstd^2 - eps in double (invstd is a rounded float: relative error of the variance
+// <= 1.2e-7 (var + eps) / var).
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar, int C, double n,
+                                                                float eps, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+    if (rvar) {
+        const double is = (double)invstd[c];
+        double var = 1.0 / (is * is) - (double)eps; if (var < 0) var = 0;
+        const double unb = n > 1 ? var * n / (n - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
 // -------------------------------------------------------------------------------- forward apply
 template <int ACT, bool VEC>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -715,6 +734,14 @@ int mogan_bn_stats(const float* x, int B, int C, int HW, float eps, float moment
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)part, C, YS,
                        (double)B * HW, eps, momentum, mean, invstd, running_mean, running_var);
+    return ok_launch();
+}
+
+int mogan_bn_running_update(const float* mean, const float* invstd, float* running_mean, float* running_var, int C, long long n,
+                            float eps, float momentum, hipStream_t stream) {
+    if (!mean || !invstd || C <= 0 || n <= 0) return MOGAN_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, mean, invstd, running_mean,
+                       running_var, C, (double)n, eps, momentum);
     return ok_launch();
 }
 

@@ -516,7 +516,7 @@ __device__ __forceinline__ double half_wave_sum(double v) {          // all 32 l
 // 8 channels x NE pixels of fp32 in LDS (L[ch][e]) -> pieces of the pixel panel: one 16-byte unit per pixel and piece
 __device__ __forceinline__ void panel_from_lds(const float* L, int NE, unsigned char* P, int C, int c0) {
     const int cg = c0 >> 5, g8 = (c0 & 31) >> 3;
-    for (int e = threadIdx.x; e < NE; e += 256) {
+    for (int e = threadIdx.x; e < NE; e += blockDim.x) {
         uint32_t w[3][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) x6_split2(L[(2 * j) * NE + e], L[(2 * j + 1) * NE + e], w[0][j], w[1][j], w[2][j]);
@@ -526,26 +526,31 @@ __device__ __forceinline__ void panel_from_lds(const float* L, int NE, unsigned 
     }
 }
 
+// Groups (G > 1): the tensor holds G batches of B images one behind the other, each of which the reference passes through the
+// layer in a call of its own (D(real) and D(fake.detach()) of a discriminator update, miscc/losses.py:136-174): own batch statistics
+// per group, running statistics updated group after group in that order.  256 threads per group (blockDim = 256 * G, G <= 2): the groups'
+// loads, sums and stores run side by side, the 8 channels' pixel panel covers all G * B images.
 struct TailP {
     const float* src; int nsplit; long long slab;       // conv output = sum of nsplit slabs (nsplit == 1: src is y itself)
     const float* gamma; const float* beta; float* rmean; float* rvar;
-    float* y; float* mean; float* invstd; float* z; unsigned char* zpanel;
-    int B, C, HW; float eps, momentum, slope;
+    float* y; float* mean; float* invstd; float* z; unsigned char* zpanel;     // mean / invstd: [G][C]
+    int B, C, HW, G; float eps, momentum, slope;
 };
 
-template <int ACT, int EPT>
-__global__ __launch_bounds__(256) void deep_tail_fwd_kernel(const TailP p) {
+template <int ACT, int EPT, int GT>
+__global__ __launch_bounds__(256 * GT) void deep_tail_fwd_kernel(const TailP p) {
     extern __shared__ float L[];
-    const int tid = threadIdx.x, chl = tid >> 5, j = tid & 31;
+    __shared__ float S[GT * 8 * 2];                     // (group, channel) -> batch mean, unbiased variance
+    const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8, chl = tid >> 5, j = tid & 31;
     const int c0 = blockIdx.x * 8, c = c0 + chl;
-    const int NE = p.B * p.HW;
+    const int NE = p.B * p.HW, b0 = grp * p.B;
     float v[EPT];
     unsigned idx[EPT];                                  // (the tensor has < 2^31 elements: checked by the entry point)
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = j + 32 * i;
         const int b = e / p.HW, pos = e - b * p.HW;
-        idx[i] = ((unsigned)b * p.C + c) * p.HW + pos;
+        idx[i] = ((unsigned)(b0 + b) * p.C + c) * p.HW + pos;
         v[i] = e < NE ? p.src[idx[i]] : 0.f;
     }
     // the K-split slabs in their fixed order, EPT independent loads in flight per slab (a dependent chain of nsplit loads per
@@ -586,42 +591,53 @@ __global__ __launch_bounds__(256) void deep_tail_fwd_kernel(const TailP p) {
     double var = s2 / n - m * m; if (var < 0) var = 0;
     const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)p.eps));
     if (j == 0) {
-        p.mean[c] = mu; p.invstd[c] = is;
-        if (p.rmean) p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * mu;
-        if (p.rvar) {
-            const double unb = n > 1 ? var * n / (n - 1.0) : var;
-            p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
+        p.mean[grp * p.C + c] = mu; p.invstd[grp * p.C + c] = is;
+        const double unb = n > 1 ? var * n / (n - 1.0) : var;
+        if (GT == 1) {
+            if (p.rmean) p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * mu;
+            if (p.rvar) p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
+        } else {
+            S[(grp * 8 + chl) * 2] = mu; S[(grp * 8 + chl) * 2 + 1] = (float)unb;
         }
     }
     const float sc = p.gamma[c] * is, sh = p.beta[c] - mu * sc;
+    const int NT = NE * GT;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = j + 32 * i;
         if (e < NE) {
             const float t = act_apply<ACT>(v[i] * sc + sh, p.slope);
             p.z[idx[i]] = t;
-            if (p.zpanel) L[chl * NE + e] = t;
+            if (p.zpanel) L[chl * NT + grp * NE + e] = t;
         }
     }
-    if (p.zpanel) {
-        __syncthreads();
-        panel_from_lds(L, NE, p.zpanel, p.C, c0);
+    if (p.zpanel || GT > 1) __syncthreads();
+    if (GT > 1 && grp == 0 && j == 0) {                // the groups' running-statistics updates, in call order
+        float rm = p.rmean ? p.rmean[c] : 0.f, rv = p.rvar ? p.rvar[c] : 0.f;
+        for (int g = 0; g < GT; ++g) {
+            rm = (1.f - p.momentum) * rm + p.momentum * S[(g * 8 + chl) * 2];
+            rv = (1.f - p.momentum) * rv + p.momentum * S[(g * 8 + chl) * 2 + 1];
+        }
+        if (p.rmean) p.rmean[c] = rm;
+        if (p.rvar) p.rvar[c] = rv;
     }
+    if (p.zpanel) panel_from_lds(L, NT, p.zpanel, p.C, c0);
 }
 
 struct TailBwdP {
     const float* dz; const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta;
     float* dy; unsigned char* dypanel; float* dgamma; float* dbeta; int accumulate;
-    int B, C, HW; float slope;
+    int B, C, HW, G; float slope;
 };
 
-template <int ACT, int EPT>
-__global__ __launch_bounds__(256) void deep_tail_bwd_kernel(const TailBwdP p) {
+template <int ACT, int EPT, int GT>
+__global__ __launch_bounds__(256 * GT) void deep_tail_bwd_kernel(const TailBwdP p) {
     extern __shared__ float L[];
-    const int tid = threadIdx.x, chl = tid >> 5, j = tid & 31;
+    __shared__ float S[GT * 8 * 2];
+    const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8, chl = tid >> 5, j = tid & 31;
     const int c0 = blockIdx.x * 8, c = c0 + chl;
-    const int NE = p.B * p.HW;
-    const float mu = p.mean[c], is = p.invstd[c];
+    const int NE = p.B * p.HW, b0 = grp * p.B, NT = NE * GT;
+    const float mu = p.mean[grp * p.C + c], is = p.invstd[grp * p.C + c];
     const float sc = p.gamma[c] * is, sh = p.beta[c] - mu * sc;
     float g[EPT], xh[EPT];
     double a0 = 0.0, a1 = 0.0;
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(256) void deep_tail_bwd_kernel(const TailBwdP p) {
         g[i] = 0.f; xh[i] = 0.f;
         if (e < NE) {
             const int b = e / p.HW, pos = e - b * p.HW;
-            const size_t idx = ((size_t)b * p.C + c) * p.HW + pos;
+            const size_t idx = ((size_t)(b0 + b) * p.C + c) * p.HW + pos;
             const float xa = p.y[idx], d = p.dz[idx];
             const float t = xa * sc + sh;
             float da = d;
@@ -644,8 +660,12 @@ __global__ __launch_bounds__(256) void deep_tail_bwd_kernel(const TailBwdP p) {
     a0 = half_wave_sum(a0); a1 = half_wave_sum(a1);
     const float f0 = (float)a0, f1 = (float)a1;
     if (j == 0) {
-        if (p.dbeta) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + f0;
-        if (p.dgamma) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + f1;
+        if (GT == 1) {
+            if (p.dbeta) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + f0;
+            if (p.dgamma) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + f1;
+        } else {
+            S[(grp * 8 + chl) * 2] = f0; S[(grp * 8 + chl) * 2 + 1] = f1;
+        }
     }
     const float inv_n = 1.f / ((float)p.B * (float)p.HW);
 #pragma unroll
@@ -654,40 +674,69 @@ __global__ __launch_bounds__(256) void deep_tail_bwd_kernel(const TailBwdP p) {
         if (e < NE) {
             const int b = e / p.HW, pos = e - b * p.HW;
             const float d = sc * (g[i] - f0 * inv_n - xh[i] * f1 * inv_n);
-            p.dy[((size_t)b * p.C + c) * p.HW + pos] = d;
-            if (p.dypanel) L[chl * NE + e] = d;
+            p.dy[((size_t)(b0 + b) * p.C + c) * p.HW + pos] = d;
+            if (p.dypanel) L[chl * NT + grp * NE + e] = d;
         }
     }
-    if (p.dypanel) {
-        __syncthreads();
-        panel_from_lds(L, NE, p.dypanel, p.C, c0);
+    if (p.dypanel || GT > 1) __syncthreads();
+    if (GT > 1 && grp == 0 && j == 0) {                // d gamma / d beta: the groups' contributions in call order
+        float db = (p.accumulate && p.dbeta) ? p.dbeta[c] : 0.f, dg = (p.accumulate && p.dgamma) ? p.dgamma[c] : 0.f;
+        for (int q = 0; q < GT; ++q) { db += S[(q * 8 + chl) * 2]; dg += S[(q * 8 + chl) * 2 + 1]; }
+        if (p.dbeta) p.dbeta[c] = db;
+        if (p.dgamma) p.dgamma[c] = dg;
     }
+    if (p.dypanel) panel_from_lds(L, NT, p.dypanel, p.C, c0);
 }
 
+// dynamic LDS beyond 64 KB (two groups of a 8 x 8 map at B = 16: 8 channels x 2048 values) needs the attribute, once per kernel
+template <typename K>
+static void tail_lds_attr(K kern, size_t lds) {
+    if (lds > 60 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+}
+template <int ACT, int EPT, int GT>
+static void launch_tail_fwd_g(const TailP& p, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr && lds > 60 * 1024) { tail_lds_attr(deep_tail_fwd_kernel<ACT, EPT, GT>, lds); attr = true; }
+    hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, EPT, GT>), dim3(p.C / 8), dim3(256 * GT), lds, st, p);
+}
+template <int ACT, int EPT>
+static void launch_tail_fwd_e(const TailP& p, size_t lds, hipStream_t st) {
+    if (p.G == 2) launch_tail_fwd_g<ACT, (EPT < 64 ? EPT : 32), 2>(p, lds, st); else launch_tail_fwd_g<ACT, EPT, 1>(p, lds, st);
+}
+template <int ACT, int EPT, int GT>
+static void launch_tail_bwd_g(const TailBwdP& p, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr && lds > 60 * 1024) { tail_lds_attr(deep_tail_bwd_kernel<ACT, EPT, GT>, lds); attr = true; }
+    hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, EPT, GT>), dim3(p.C / 8), dim3(256 * GT), lds, st, p);
+}
+template <int ACT, int EPT>
+static void launch_tail_bwd_e(const TailBwdP& p, size_t lds, hipStream_t st) {
+    if (p.G == 2) launch_tail_bwd_g<ACT, (EPT < 64 ? EPT : 32), 2>(p, lds, st); else launch_tail_bwd_g<ACT, EPT, 1>(p, lds, st);
+}
 template <int ACT>
 static int launch_tail_fwd(const TailP& p, hipStream_t st) {
     const int NE = p.B * p.HW;
-    const size_t lds = p.zpanel ? (size_t)8 * NE * sizeof(float) : 0;
-    const dim3 grid(p.C / 8);
-    if (NE <= 256) hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 8>), grid, dim3(256), lds, st, p);
-    else if (NE <= 512) hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 16>), grid, dim3(256), lds, st, p);
-    else if (NE <= 1024) hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 32>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((deep_tail_fwd_kernel<ACT, 64>), grid, dim3(256), lds, st, p);
+    const size_t lds = p.zpanel ? (size_t)8 * NE * p.G * sizeof(float) : 0;
+    if (NE <= 256) launch_tail_fwd_e<ACT, 8>(p, lds, st);
+    else if (NE <= 512) launch_tail_fwd_e<ACT, 16>(p, lds, st);
+    else if (NE <= 1024) launch_tail_fwd_e<ACT, 32>(p, lds, st);
+    else launch_tail_fwd_e<ACT, 64>(p, lds, st);
     return 0;
 }
 template <int ACT>
 static int launch_tail_bwd(const TailBwdP& p, hipStream_t st) {
     const int NE = p.B * p.HW;
-    const size_t lds = p.dypanel ? (size_t)8 * NE * sizeof(float) : 0;
-    const dim3 grid(p.C / 8);
-    if (NE <= 256) hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 8>), grid, dim3(256), lds, st, p);
-    else if (NE <= 512) hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 16>), grid, dim3(256), lds, st, p);
-    else if (NE <= 1024) hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 32>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((deep_tail_bwd_kernel<ACT, 64>), grid, dim3(256), lds, st, p);
+    const size_t lds = p.dypanel ? (size_t)8 * NE * p.G * sizeof(float) : 0;
+    if (NE <= 256) launch_tail_bwd_e<ACT, 8>(p, lds, st);
+    else if (NE <= 512) launch_tail_bwd_e<ACT, 16>(p, lds, st);
+    else if (NE <= 1024) launch_tail_bwd_e<ACT, 32>(p, lds, st);
+    else launch_tail_bwd_e<ACT, 64>(p, lds, st);
     return 0;
 }
-static bool tail_ok(int B, int C, int HW, int act) {
-    return B > 0 && HW > 0 && C > 0 && C % 32 == 0 && (long long)B * HW <= 2048 &&
+// B images per group, G groups: a half wave holds a (channel, group)'s B * HW values in registers (<= 2048; two groups = 512
+// threads = half the registers per lane: <= 1024), the block's LDS the 8-channel panel of all groups (<= 64 KB)
+static bool tail_ok(int B, int C, int HW, int act, int G = 1) {
+    return B > 0 && HW > 0 && C > 0 && C % 32 == 0 && G >= 1 && G <= 2 && (long long)B * HW * G <= 2048 &&
            (act == MOGAN_ACT_NONE || act == MOGAN_ACT_RELU || act == MOGAN_ACT_LRELU);
 }
 
@@ -1016,20 +1065,24 @@ int mogan_pk_group(int n, MoganPkArgs* args, hipStream_t stream) {
 
 size_t mogan_pk_panel_bytes(int B, int C, int HW) { return (B > 0 && C > 0 && HW > 0) ? (size_t)B * HW * C * 6 : 0; }
 
-int mogan_deep_block_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act) {
+int mogan_deep_block_eligible(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act,
+                              int groups) {
+    if (groups < 1 || B <= 0 || B % groups) return 0;
     if (!mogan_pk_conv_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0)) return 0;
     if (!mogan_pk_conv_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 1)) return 0;
     const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
-    return tail_ok(B, Cout, OH * OW, act) ? 1 : 0;
+    return tail_ok(B / groups, Cout, OH * OW, act, groups) ? 1 : 0;
 }
 
+// B = all images of the tensor; groups > 1: `groups` BatchNorm calls on consecutive B / groups images each (stats: [2][groups][Cout])
 int mogan_deep_conv_bn_act_fwd(const float* x, const void* xpanel, const void* wpk, const float* gamma, const float* beta,
                                float* rmean, float* rvar, float* y, float* stats, float* z, void* zpanel, int B, int Cin, int Hs,
                                int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, float eps, float momentum, int act,
-                               float slope, void* ws, size_t ws_bytes, hipStream_t stream) {
-    if (B <= 0 || Cin <= 0 || Cin % 32 || Hs <= 0 || Ws <= 0 || stride <= 0) return MOGAN_ERR_SHAPE;
+                               float slope, int groups, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || groups < 1 || B % groups || Cin <= 0 || Cin % 32 || Hs <= 0 || Ws <= 0 || stride <= 0) return MOGAN_ERR_SHAPE;
     const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
-    if (OH <= 0 || OW <= 0 || !tail_ok(B, Cout, OH * OW, act) || !gamma || !beta || !y || !stats || !z) return MOGAN_ERR_SHAPE;
+    if (OH <= 0 || OW <= 0 || !tail_ok(B / groups, Cout, OH * OW, act, groups) || !gamma || !beta || !y || !stats || !z)
+        return MOGAN_ERR_SHAPE;
     char* w0 = (char*)ws; size_t wn = ws_bytes;
     if (!xpanel) {                       // the producer of x handed over no panel: pack it here
         const size_t pbytes = up256((size_t)B * Hs * Ws * Cin * 6);
@@ -1042,8 +1095,9 @@ int mogan_deep_conv_bn_act_fwd(const float* x, const void* xpanel, const void* w
     if (rc) return rc;
     TailP t{};
     t.src = nsplit > 1 ? (const float*)w0 : y; t.nsplit = nsplit; t.slab = (long long)B * Cout * OH * OW;
-    t.gamma = gamma; t.beta = beta; t.rmean = rmean; t.rvar = rvar; t.y = y; t.mean = stats; t.invstd = stats + Cout; t.z = z;
-    t.zpanel = (unsigned char*)zpanel; t.B = B; t.C = Cout; t.HW = OH * OW; t.eps = eps; t.momentum = momentum; t.slope = slope;
+    t.gamma = gamma; t.beta = beta; t.rmean = rmean; t.rvar = rvar; t.y = y; t.mean = stats; t.invstd = stats + (size_t)groups * Cout;
+    t.z = z; t.zpanel = (unsigned char*)zpanel; t.B = B / groups; t.G = groups; t.C = Cout; t.HW = OH * OW; t.eps = eps;
+    t.momentum = momentum; t.slope = slope;
     if (act == MOGAN_ACT_LRELU) launch_tail_fwd<MOGAN_ACT_LRELU>(t, stream);
     else if (act == MOGAN_ACT_RELU) launch_tail_fwd<MOGAN_ACT_RELU>(t, stream);
     else launch_tail_fwd<MOGAN_ACT_NONE>(t, stream);
@@ -1053,18 +1107,18 @@ int mogan_deep_conv_bn_act_fwd(const float* x, const void* xpanel, const void* w
 int mogan_deep_conv_bn_act_bwd(const float* dz, const float* y, const float* stats, const float* gamma, const float* beta,
                                const void* wpk_dgrad, float* dy, float* dgamma, float* dbeta, int accumulate, float* dx, int B,
                                int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int act, float slope,
-                               void* ws, size_t ws_bytes, hipStream_t stream) {
-    if (B <= 0 || stride <= 0) return MOGAN_ERR_SHAPE;
+                               int groups, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || stride <= 0 || groups < 1 || B % groups) return MOGAN_ERR_SHAPE;
     const int OH = (Hs + 2 * ph - KH) / stride + 1, OW = (Ws + 2 * pw - KW) / stride + 1;
-    if (OH <= 0 || OW <= 0 || !tail_ok(B, Cout, OH * OW, act) || !dz || !y || !stats || !gamma || !beta || !dy)
+    if (OH <= 0 || OW <= 0 || !tail_ok(B / groups, Cout, OH * OW, act, groups) || !dz || !y || !stats || !gamma || !beta || !dy)
         return MOGAN_ERR_SHAPE;
     const size_t pbytes = up256((size_t)B * OH * OW * Cout * 6);
     const bool want_dx = dx != nullptr;
     if (want_dx && (!ws || ws_bytes < pbytes || !wpk_dgrad)) return MOGAN_ERR_WS;
     TailBwdP t{};
-    t.dz = dz; t.y = y; t.mean = stats; t.invstd = stats + Cout; t.gamma = gamma; t.beta = beta; t.dy = dy;
+    t.dz = dz; t.y = y; t.mean = stats; t.invstd = stats + (size_t)groups * Cout; t.gamma = gamma; t.beta = beta; t.dy = dy;
     t.dypanel = want_dx ? (unsigned char*)ws : nullptr; t.dgamma = dgamma; t.dbeta = dbeta; t.accumulate = accumulate;
-    t.B = B; t.C = Cout; t.HW = OH * OW; t.slope = slope;
+    t.B = B / groups; t.G = groups; t.C = Cout; t.HW = OH * OW; t.slope = slope;
     if (act == MOGAN_ACT_LRELU) launch_tail_bwd<MOGAN_ACT_LRELU>(t, stream);
     else if (act == MOGAN_ACT_RELU) launch_tail_bwd<MOGAN_ACT_RELU>(t, stream);
     else launch_tail_bwd<MOGAN_ACT_NONE>(t, stream);

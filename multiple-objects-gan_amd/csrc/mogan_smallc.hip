@@ -413,12 +413,13 @@ __global__ __launch_bounds__(256) void logits_head_fwd_kernel(const float* __res
     }
 }
 // backward: dz[b][co] = dp * p * (1 - p) on the fly.  Blocks [0, nbx): dx[b][k] = sum_co dz[b][co] w[co][k] (when dx != NULL);
-// the rest: dw[co][k] (+)= sum_b dz[b][co] x[b][k] (images in order), and the block's thread 0 of the first of them: db[co].
+// the next nbw: dw[co][k] (+)= sum_b dz[b][co] x[b][k] (images in order); one more block when db != NULL: db[co] (a bias gradient
+// without a weight gradient -- frozen filter, trainable bias -- is its own block, not a rider of the dw blocks).
 __global__ __launch_bounds__(256) void logits_head_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p,
                                                               const float* __restrict__ x, const float* __restrict__ w,
                                                               float* __restrict__ dx, float* __restrict__ dw,
                                                               float* __restrict__ db, int B, int K, int Cout, int accumulate,
-                                                              unsigned nbx) {
+                                                              unsigned nbx, unsigned nbw) {
     if (blockIdx.x < nbx) {
         const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
         if (i >= (long long)B * K) return;
@@ -431,18 +432,20 @@ __global__ __launch_bounds__(256) void logits_head_bwd_kernel(const float* __res
         dx[i] = acc;
         return;
     }
-    if (dw == nullptr) return;
-    const int i = (blockIdx.x - nbx) * 256 + threadIdx.x;
-    if (i < Cout * K) {
-        const int co = i / K, k = i - co * K;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float q = p[b * Cout + co];
-            acc = fmaf(dp[b * Cout + co] * q * (1.f - q), x[(size_t)b * K + k], acc);
+    if (blockIdx.x < nbx + nbw) {
+        const int i = (blockIdx.x - nbx) * 256 + threadIdx.x;
+        if (i < Cout * K) {
+            const int co = i / K, k = i - co * K;
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const float q = p[b * Cout + co];
+                acc = fmaf(dp[b * Cout + co] * q * (1.f - q), x[(size_t)b * K + k], acc);
+            }
+            dw[i] = accumulate ? dw[i] + acc : acc;
         }
-        dw[i] = accumulate ? dw[i] + acc : acc;
+        return;
     }
-    if (db != nullptr && blockIdx.x == nbx && threadIdx.x < Cout) {
+    if (db != nullptr && threadIdx.x < Cout) {
         const int co = threadIdx.x;
         float acc = 0.f;
         for (int b = 0; b < B; ++b) { const float q = p[b * Cout + co]; acc += dp[b * Cout + co] * q * (1.f - q); }
@@ -572,9 +575,10 @@ int mogan_logits_head_bwd(const float* dp, const float* p, const float* x, const
     if (B <= 0 || K <= 0 || Cout < 1 || Cout > 4 || (long long)B * K >= (1ll << 31)) return MOGAN_ERR_SHAPE;
     const unsigned nbx = dx ? (unsigned)(((long long)B * K + 255) / 256) : 0u;
     const unsigned nbw = dw ? (unsigned)((Cout * K + 255) / 256) : 0u;
-    if (nbx + nbw == 0) return 0;
-    hipLaunchKernelGGL(logits_head_bwd_kernel, dim3(nbx + nbw), dim3(256), 0, stream, dp, p, x, w, dx, dw, db, B, K, Cout,
-                       accumulate, nbx);
+    const unsigned nbb = db ? 1u : 0u;
+    if (nbx + nbw + nbb == 0) return 0;
+    hipLaunchKernelGGL(logits_head_bwd_kernel, dim3(nbx + nbw + nbb), dim3(256), 0, stream, dp, p, x, w, dx, dw, db, B, K, Cout,
+                       accumulate, nbx, nbw);
     return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
 }
 

@@ -49,9 +49,9 @@ SIGNATURES = {
     "mogan_pk_wgrad_eligible": [I] * 10 + [Z],
     "mogan_conv2d_wgrad_pk": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_pk_panel_bytes": [I, I, I],
-    "mogan_deep_block_eligible": [I] * 11,
-    "mogan_deep_conv_bn_act_fwd": [P] * 11 + [I] * 10 + [F, F, I, F, P, Z, P],
-    "mogan_deep_conv_bn_act_bwd": [P] * 9 + [I, P] + [I] * 10 + [I, F, P, Z, P],
+    "mogan_deep_block_eligible": [I] * 12,
+    "mogan_deep_conv_bn_act_fwd": [P] * 11 + [I] * 10 + [F, F, I, F, I, P, Z, P],
+    "mogan_deep_conv_bn_act_bwd": [P] * 9 + [I, P] + [I] * 10 + [I, F, I, P, Z, P],
     "mogan_upconv3x3_ws_bytes": [I, I],
     "mogan_upconv3x3_fwd": [P, P, P, I, I, I, I, I, P, Z, P],
     "mogan_upconv3x3_dgrad": [P, P, P, I, I, I, I, I, P, Z, P],
@@ -60,6 +60,7 @@ SIGNATURES = {
     "mogan_bmm": [P, P, P, I, I, I, I] + [L] * 9 + [I, P, Z, P],
     "mogan_bn_ws_bytes": [I, I, I],
     "mogan_bn_stats": [P, I, I, I, F, F, P, P, P, P, P, Z, P],
+    "mogan_bn_running_update": [P, P, P, P, I, L, F, F, P],
     "mogan_bn_act_fwd": [P, P, P, P, P, P, P, I, I, I, I, F, P],
     "mogan_bn_act_grouped_eligible": [I, I, I, I],
     "mogan_bn_act_grouped_fwd": [P] * 8 + [I] * 5 + [F, F, F, P],

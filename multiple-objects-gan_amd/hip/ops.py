@@ -21,6 +21,36 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GLU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 ACT_TRACE = None
 
 
+# Deferred running statistics (include/mogan_hip.h: mogan_bn_running_update).  While this is a list, training-mode BatchNorm
+# launches leave running_mean / running_var alone and append what the update needs; bn_apply_deferred() performs the updates
+# later, in list order -- the arithmetic of a call runs early, its place in the reference's call order is kept
+# (miscc/losses.py: the "wrong pair" head of a discriminator update).
+BN_DEFER = None
+
+
+def bn_apply_deferred(pending):
+    for mean, invstd, n, rm, rv, eps, momentum in pending:
+        if rm is not None or rv is not None:
+            call("mogan_bn_running_update", ptr(mean), ptr(invstd), ptr(rm), ptr(rv), mean.numel(), int(n), float(eps),
+                 float(momentum), stream_ptr())
+    del pending[:]
+
+
+TRACE_GROUPS = 1            # set by a paired pass for the launches that do not know about groups (no BatchNorm inside)
+
+
+def _trace(act, y, groups=1):
+    """one ACT_TRACE entry per reference call: a tensor that stands for `groups` calls (groups batches one behind the other)
+    is recorded as its per-call slices; inside a paired pass (TRACE_GROUPS > 1) the entries carry the call's index as a third
+    element (discriminator_loss puts them back into the reference's call order: every layer of D(real), then of D(fake))"""
+    if groups <= 1:
+        ACT_TRACE.append((act, y))
+        return
+    n = y.shape[0] // groups
+    for g in range(groups):
+        ACT_TRACE.append((act, y[g * n:(g + 1) * n], g) if TRACE_GROUPS > 1 else (act, y[g * n:(g + 1) * n]))
+
+
 # When a parameter already owns a dense .grad (the trainer's flat gradient buckets), the weight-gradient
 # kernels accumulate straight into it (C += ...) and the Function returns None for that input: same result as
 # autograd's `grad += new`, without the temporary and the extra read-modify-write pass (~350 launches/step).
@@ -115,11 +145,36 @@ def _cat_batch(a, b):
     """torch.cat([a, b]) along the batch axis of two dense tensors as one mogan_concat_fwd launch (the images of a tensor are the
     "channels" of a one-row concat)."""
     a, b = _c(a), _c(b)
+    if a.shape[1:] != b.shape[1:]:
+        raise lib.MoganHipError("_cat_batch: %r and %r differ behind the batch axis" % (tuple(a.shape), tuple(b.shape)))
     per = a[0].numel()
     out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
     arrs = _cat_arrays([(a.shape[0], 1, 0, 0, 0), (b.shape[0], 1, 0, 0, 0)], [a.data_ptr(), b.data_ptr()])
     call("mogan_concat_fwd", *arrs, 2, ptr(out), 1, per, stream_ptr())
     return out
+
+
+class SplitBatchFn(torch.autograd.Function):
+    """x (N, ...) -> (x[:B], x[B:]) as views; the two gradients come back as ONE dense tensor through one concat launch
+    (autograd's own slice backward is a zero fill + a copy + an add per half)."""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.B, ctx.shape = B, tuple(x.shape)
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        B, shape = ctx.B, ctx.shape
+        if da is None:
+            da = torch.zeros((B,) + shape[1:], dtype=torch.float32, device=db.device)
+        if db is None:
+            db = torch.zeros((shape[0] - B,) + shape[1:], dtype=torch.float32, device=da.device)
+        return _cat_batch(da, db), None
+
+
+def split_batch(x, B):
+    return SplitBatchFn.apply(_c(x), int(B))
 
 
 def _wgrad_flush():
@@ -522,7 +577,7 @@ class ConvLReLUFn(torch.autograd.Function):
         elif rc != 0:
             raise lib.MoganHipError("mogan_conv2d_lrelu_fwd failed: %s" % lib._ERRORS.get(rc, rc))
         if ACT_TRACE is not None:
-            ACT_TRACE.append((ACT_LRELU, z))
+            _trace(ACT_LRELU, z, TRACE_GROUPS)
         ctx.save_for_backward(x, w, z)
         ctx.cfg = (stride, ph, pw, slope)
         return z
@@ -572,13 +627,14 @@ class LogitsHeadFn(torch.autograd.Function):
         gw = _grad_buf(w) if want_w else None
         gb = _grad_buf(bias) if want_b else None
         # one accumulate flag for both: direct only when every wanted gradient has its buffer
-        direct = want_w and gw is not None and (not want_b or gb is not None)
+        direct = (want_w or want_b) and (not want_w or gw is not None) and (not want_b or gb is not None)
         dw = gw if direct else (torch.empty_like(w) if want_w else None)
         db = (gb if direct else torch.empty_like(bias)) if want_b else None
         call("mogan_logits_head_bwd", ptr(dp), ptr(p), ptr(x), ptr(w), ptr(dx), ptr(dw), ptr(db), B, K, Cout,
              1 if direct else 0, stream_ptr())
         if direct:
-            _grad_hit(gw)
+            if gw is not None:
+                _grad_hit(gw)
             if gb is not None:
                 _grad_hit(gb)
             dw = db = None
@@ -593,8 +649,13 @@ def logits_head_ok(x, conv):
     """conv + Sigmoid as the fused head: the filter covers the whole (unpadded) map, <= 4 logits, K a multiple of 4"""
     w = conv.weight
     ph, pw = conv.padding if isinstance(conv.padding, tuple) else (conv.padding, conv.padding)
-    return (x.dim() == 4 and ph == 0 and pw == 0 and w.shape[2] == x.shape[2] and w.shape[3] == x.shape[3] and w.shape[0] <= 4
-            and w[0].numel() % 4 == 0 and x.shape[1] == w.shape[1])
+    if not (x.dim() == 4 and ph == 0 and pw == 0 and w.shape[2] == x.shape[2] and w.shape[3] == x.shape[3] and w.shape[0] <= 4
+            and w[0].numel() % 4 == 0 and x.shape[1] == w.shape[1]):
+        return False
+    # the kernels read x and w as 16-byte quads: a dense view whose storage offset is not a multiple of four floats (a batch
+    # slice of an odd-sized tensor) takes the convolution + sigmoid path instead of failing with MOGAN_ERR_SHAPE
+    # (a non-contiguous operand is copied to a fresh, aligned tensor by the Function)
+    return (not x.is_contiguous() or x.data_ptr() % 16 == 0) and (not w.is_contiguous() or w.data_ptr() % 16 == 0)
 
 
 def conv2d_lrelu(x, w, stride, padding, slope=0.2):
@@ -625,18 +686,19 @@ def pk_debug_force(take_all, cfg=-1, split=0):
     _pk_wgrad_elig.clear()
 
 
-def deep_block_eligible(x, w, stride, ph, pw, act):
+def deep_block_eligible(x, w, stride, ph, pw, act, groups=1):
     """conv -> BatchNorm(train) -> act as the fused deep block (csrc/mogan_pgemm.hip): the weight has packed copies, both
     directions of the convolution take the packed path and the output map is small enough for the one-block-per-8-channels
-    tail kernels."""
+    tail kernels.  groups: BatchNorm calls the batch stands for (see deep_conv_bn_act)."""
     if not (PK_ENABLED and DEEP_ENABLED) or getattr(w, "_mogan_pk", None) is None or x.dim() != 4:
         return False
     B, Cin, Hs, Ws = x.shape
     Cout, _, KH, KW = w.shape
-    key = (B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act)
+    key = (B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act, groups)
     e = _deep_elig.get(key)
     if e is None:
-        e = _deep_elig[key] = bool(lib.load().mogan_deep_block_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act))
+        e = _deep_elig[key] = bool(lib.load().mogan_deep_block_eligible(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act,
+                                                                        groups))
     if e:
         # one weight used with two convolution geometries has packed copies for the first one only (WeightPacks.pointer
         # returns None for the other): such a call takes the unfused path
@@ -651,10 +713,11 @@ def deep_block_eligible(x, w, stride, ph, pw, act):
 class DeepConvBNActFn(torch.autograd.Function):
     """z = act(BatchNorm2d_train(conv2d(x, w))) for the deep discriminator layers (model.py:575-613: downBlock,
     Block3x3_leakRelu; 616-642: jointConv) in two launches forward (packed-weight GEMM, tail) and two + the weight gradient
-    backward.  The output carries the pixel panel of z for the next deep block (attribute _mogan_panel)."""
+    backward.  The output carries the pixel panel of z for the next deep block (attribute _mogan_panel).  groups = 2: the batch
+    is [real; fake] of a discriminator update (miscc/losses.py:136-174) -- one convolution, BatchNorm statistics per half."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, running_mean, running_var, act, slope, eps, momentum, stride, ph, pw):
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, act, slope, eps, momentum, stride, ph, pw, groups):
         x, gamma, beta = _c(x), _c(gamma), _c(beta)
         B, Cin, Hs, Ws = x.shape
         Cout, _, KH, KW = w.shape
@@ -667,7 +730,7 @@ class DeepConvBNActFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         y = torch.empty((B, Cout, OH, OW), **f32)
         z = torch.empty((B, Cout, OH, OW), **f32)
-        stats = torch.empty((2, Cout), **f32)
+        stats = torch.empty((2, groups, Cout), **f32)
         zpanel = torch.empty(int(lib.load().mogan_pk_panel_bytes(B, Cout, OH * OW)), dtype=torch.uint8, device=dev)
         xp = getattr(x, "_mogan_panel", None)
         if xp is not None and (xp[1] != x.data_ptr() or xp[2] != x._version):
@@ -675,21 +738,26 @@ class DeepConvBNActFn(torch.autograd.Function):
         if xp is not None:
             DEEP_STATS["panel_hits"] += 1
         wsp, wsn = workspace(dev)
+        if BN_DEFER is not None:
+            if groups != 1:
+                raise lib.MoganHipError("deferred running statistics: one BatchNorm call per launch only")
+            BN_DEFER.append((stats[0, 0], stats[1, 0], B * OH * OW, running_mean, running_var, eps, momentum))
+            running_mean = running_var = None
         call("mogan_deep_conv_bn_act_fwd", ptr(x), ptr(xp[0]) if xp is not None else None, wp, ptr(gamma), ptr(beta),
              ptr(running_mean), ptr(running_var), ptr(y), ptr(stats), ptr(z), ptr(zpanel), B, Cin, Hs, Ws, Cout, KH, KW,
-             stride, ph, pw, eps, momentum, act, slope, wsp, wsn, stream_ptr())
+             stride, ph, pw, eps, momentum, act, slope, groups, wsp, wsn, stream_ptr())
         DEEP_STATS["fwd"] += 1
         if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
-            ACT_TRACE.append((act, z))
+            _trace(act, z, groups)
         ctx.save_for_backward(x, w, y, stats, gamma, beta)
-        ctx.cfg = (act, slope, stride, ph, pw)
+        ctx.cfg = (act, slope, stride, ph, pw, groups)
         z._mogan_panel = (zpanel, z.data_ptr(), z._version)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         x, w, y, stats, gamma, beta = ctx.saved_tensors
-        act, slope, stride, ph, pw = ctx.cfg
+        act, slope, stride, ph, pw, groups = ctx.cfg
         dz = _c(dz)
         B, Cin, Hs, Ws = x.shape
         Cout, _, KH, KW = w.shape
@@ -713,7 +781,8 @@ class DeepConvBNActFn(torch.autograd.Function):
             pg = pb = None
         wsp, wsn = workspace(dev)
         call("mogan_deep_conv_bn_act_bwd", ptr(dz), ptr(y), ptr(stats), ptr(gamma), ptr(beta), wpd, ptr(dy), ptr(pg), ptr(pb),
-             1 if direct else 0, ptr(dx), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act, slope, wsp, wsn, stream_ptr())
+             1 if direct else 0, ptr(dx), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, act, slope, groups, wsp, wsn,
+             stream_ptr())
         DEEP_STATS["bwd"] += 1
         if direct:
             _grad_hit(gg)
@@ -727,12 +796,12 @@ class DeepConvBNActFn(torch.autograd.Function):
                 _wgrad_accumulate(dy, x, w, (stride, ph, pw, 0), g)
             else:
                 dw = conv2d_wgrad(dy, x, w.shape, stride, ph, pw, 0)
-        return (dx, dw, dg, db) + (None,) * 9
+        return (dx, dw, dg, db) + (None,) * 10
 
 
-def deep_conv_bn_act(x, w, gamma, beta, running_mean, running_var, act, slope, eps, momentum, stride, ph, pw):
+def deep_conv_bn_act(x, w, gamma, beta, running_mean, running_var, act, slope, eps, momentum, stride, ph, pw, groups=1):
     return DeepConvBNActFn.apply(x, w, gamma, beta, running_mean, running_var, int(act), float(slope), float(eps),
-                                 float(momentum), int(stride), int(ph), int(pw))
+                                 float(momentum), int(stride), int(ph), int(pw), int(groups))
 
 
 # ------------------------------------------------------------------------------- strided bmm / linear
@@ -852,6 +921,9 @@ class BNActFn(torch.autograd.Function):
         Cy = C // 2 if act == ACT_GLU else C
         y = torch.empty((B, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
         res = _c(residual) if residual is not None else None
+        if BN_DEFER is not None:
+            BN_DEFER.append((stats[0], stats[1], B * HW, running_mean, running_var, eps, momentum))
+            running_mean = running_var = None
         call("mogan_bn_act_fwd_fused", ptr(x), ptr(gamma), ptr(beta), ptr(res), ptr(running_mean), ptr(running_var),
              ptr(stats[0]), ptr(stats[1]), ptr(y), B, C, HW, act, slope, eps, momentum, wsp, wsn, stream_ptr())
         if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
@@ -885,9 +957,11 @@ class BNActFn(torch.autograd.Function):
 
 
 class BNActGroupedFn(torch.autograd.Function):
-    """`groups` training-mode BatchNorm(+activation) calls on the groups of B images of one (groups*B, C, ...) tensor in one launch
-    each way: own batch statistics per group, running statistics updated group after group (the per-object BatchNorm calls of the
-    object pathways, model.py:395-407, 662-672)."""
+    """`groups` training-mode BatchNorm(+activation) calls on the groups of B images of one (groups*B, C, ...) tensor: own batch
+    statistics per group, running statistics updated group after group (the per-object BatchNorm calls of the object pathways,
+    model.py:395-407, 662-672; SURVEY F11 -- and, round 5, the [real; fake] batch of a discriminator update,
+    miscc/losses.py:136-174).  One launch each way where a group has <= 4096 values per channel; larger maps: the two-launch
+    kernels of BNActFn once per group on the group's slice of x / y (the groups are contiguous: no copies, no concatenation)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, act, slope, eps, momentum, groups):
@@ -897,31 +971,53 @@ class BNActGroupedFn(torch.autograd.Function):
         stats = torch.empty((2, groups, C), dtype=torch.float32, device=x.device)
         Cy = C // 2 if act == ACT_GLU else C
         y = torch.empty((N, Cy) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-        call("mogan_bn_act_grouped_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(stats[0]),
-             ptr(stats[1]), ptr(y), groups, B, C, HW, act, slope, eps, momentum, stream_ptr())
+        one = bn_groups_ok(x, groups)
+        if BN_DEFER is not None:
+            raise lib.MoganHipError("deferred running statistics: one BatchNorm call per launch only")
+        if one:
+            call("mogan_bn_act_grouped_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(stats[0]),
+                 ptr(stats[1]), ptr(y), groups, B, C, HW, act, slope, eps, momentum, stream_ptr())
+        else:
+            wsp, wsn = workspace(x.device)
+            if lib.bn_ws_bytes(B, C, HW) > wsn:
+                raise lib.MoganHipError("workspace too small for bn")
+            for g in range(groups):
+                call("mogan_bn_act_fwd_fused", ptr(x[g * B:(g + 1) * B]), ptr(gamma), ptr(beta), None, ptr(running_mean),
+                     ptr(running_var), ptr(stats[0, g]), ptr(stats[1, g]), ptr(y[g * B:(g + 1) * B]), B, C, HW, act, slope, eps,
+                     momentum, wsp, wsn, stream_ptr())
         if ACT_TRACE is not None and act in (ACT_RELU, ACT_LRELU):
-            for g in range(groups):                      # (one entry per reference call, in call order)
-                ACT_TRACE.append((act, y[g * B:(g + 1) * B]))
+            _trace(act, y, groups)                       # (one entry per reference call, in call order)
         ctx.save_for_backward(x, gamma, beta, stats)
-        ctx.cfg = (act, slope, groups)
+        ctx.cfg = (act, slope, groups, one)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, stats = ctx.saved_tensors
-        act, slope, groups = ctx.cfg
+        act, slope, groups, one = ctx.cfg
         dy = _c(dy)
         N, C, HW = _bchw(x)
+        B = N // groups
         dx = torch.empty_like(x)
         gg, gb = _grad_buf(gamma), _grad_buf(beta)
         direct = gg is not None and gb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
         if direct:
             dg, db = gg, gb
-        else:
+        elif one:
             dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
             dg, db = dgb[0], dgb[1]
-        call("mogan_bn_act_grouped_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(dx), ptr(dg),
-             ptr(db), groups, N // groups, C, HW, act, slope, 1 if direct else 0, stream_ptr())
+        else:
+            dgb = torch.zeros((2, C), dtype=torch.float32, device=x.device)      # (the per-group calls accumulate)
+            dg, db = dgb[0], dgb[1]
+        if one:
+            call("mogan_bn_act_grouped_bwd", ptr(x), ptr(dy), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(dx),
+                 ptr(dg), ptr(db), groups, B, C, HW, act, slope, 1 if direct else 0, stream_ptr())
+        else:
+            wsp, wsn = workspace(x.device)
+            for g in range(groups):
+                call("mogan_bn_act_bwd", ptr(x[g * B:(g + 1) * B]), ptr(dy[g * B:(g + 1) * B]), ptr(stats[0, g]), ptr(stats[1, g]),
+                     ptr(gamma), ptr(beta), ptr(dx[g * B:(g + 1) * B]), ptr(dg), ptr(db), B, C, HW, act, slope, 1, wsp, wsn,
+                     stream_ptr())
         if direct:
             _grad_hit(gg)
             _grad_hit(gb)
@@ -930,7 +1026,8 @@ class BNActGroupedFn(torch.autograd.Function):
 
 
 def bn_groups_ok(x, groups):
-    """can `groups` BatchNorm calls on this (groups*B, C, ...) tensor go out as one launch (B*HW <= 4096 values per channel)?"""
+    """can `groups` BatchNorm calls on this (groups*B, C, ...) tensor go out as ONE launch (B*HW <= 4096 values per channel)?
+    (bn_act(groups=...) itself takes any size: larger maps run the two-launch kernels per group, in place)"""
     N, C, HW = _bchw(x)
     return groups > 1 and N % groups == 0 and bool(lib.load().mogan_bn_act_grouped_eligible(groups, N // groups, C, HW))
 
@@ -1213,8 +1310,14 @@ def cat_channels(parts, N, spatial=()):
         else:
             raise ValueError(mode)
         want = {"full": N, "plane": N, "rep": N // G, "rep_plane": N // G, "obj": N // G, "obj_plane": N // G}[kind]
-        if t.shape[0] != want or (kind.startswith("obj") and t.shape[1] != G):
-            raise lib.MoganHipError("cat_channels: part of shape %r does not fit mode %r at N = %d" % (tuple(t.shape), mode, N))
+        lead = 3 if kind.startswith("obj") else 2                 # (batch[, object], channel) in front of the plane
+        tail = () if kind.endswith("plane") else tuple(int(d) for d in spatial)
+        # the kernels index every part with the destination's plane size: a part whose trailing dims differ would be read out
+        # of bounds where torch.cat raises a shape error
+        if (t.shape[0] != want or (kind.startswith("obj") and t.shape[1] != G) or t.dim() != lead + len(tail)
+                or tuple(t.shape[lead:]) != tail):
+            raise lib.MoganHipError("cat_channels: part of shape %r does not fit mode %r at N = %d, plane %r"
+                                    % (tuple(t.shape), mode, N, tuple(spatial)))
         meta.append(m)
         ts.append(t)
     if len(ts) > 4:

@@ -220,12 +220,15 @@ def _act_ref(y, act):
     return y
 
 
-@pytest.mark.parametrize("shape", [(3, 4, 6, 8, 8), (3, 16, 12, 15, 15), (2, 5, 10), (3, 16, 8, 16, 16)])
+@pytest.mark.parametrize("shape", [(3, 4, 6, 8, 8), (3, 16, 12, 15, 15), (2, 5, 10), (3, 16, 8, 16, 16), (2, 16, 8, 32, 32),
+                                   (2, 3, 4, 70, 70)])
 @pytest.mark.parametrize("act", ["none", "relu", "lrelu", "glu"])
 def test_bn_act_grouped(shape, act):
     """mogan_bn_act_grouped_fwd/bwd: G BatchNorm(train)+activation calls on the G groups of one (G*B, C, ...) tensor in one launch
     each way = G separate calls in sequence (own statistics per group, running statistics updated group after group, d gamma / d beta
-    summed) -- against fp64 and against the looped HIP calls; (2,5,10) is a BatchNorm1d."""
+    summed) -- against fp64 and against the looped HIP calls; (2,5,10) is a BatchNorm1d.  The last two shapes have more than 4096
+    values per channel and group: the large-map kernels once per group, in place (the [real; fake] batch of a discriminator
+    update on the 64 x 64 ... 16 x 16 maps, miscc/losses.py:136-174)."""
     G, B, C = shape[:3]
     full = (G * B, C) + tuple(shape[3:])
     x = T("gbx%s" % (shape,), full, 1.5, 0.3).requires_grad_(True)
@@ -243,7 +246,7 @@ def test_bn_act_grouped(shape, act):
     code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "glu": ops.ACT_GLU}[act]
     xd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, gm, bt))
     rmd, rvd = rm.to(DEV), rv.to(DEV)
-    assert ops.bn_groups_ok(xd, G)
+    assert ops.bn_groups_ok(xd, G) == (B * int(torch.tensor(shape[3:]).prod()) <= 4096)
     y = ops.bn_act(xd, gd, bd, rmd, rvd, code, 0.2, None, 1e-5, 0.1, groups=G)
     y.backward(go.to(DEV))
     torch.cuda.synchronize()
@@ -408,6 +411,34 @@ def test_winograd_prepared_filter_planes_follow_the_weight_version(monkeypatch):
     xs = T("wp.xs", (B, Cin, 4, 4)).to(DEV)
     _check(ops.conv2d_forward(xs, w2, 1, 1, 1, 0), F.conv2d(xs.double().cpu(), w2.double().cpu(), None, 1, 1), 2e-6, "4x4 map")
     assert ops.PK_STATS.get("wino", 0) == n1
+
+
+
+def test_stn_shared_source_gradient_is_order_independent_to_rounding():
+    """mogan_stn_bwd_ex adds every object's contribution to the ONE image-batch gradient with fp32 atomics (include/mogan_hip.h,
+    "Determinism"): two runs agree to the rounding of a short sum, and both agree with the fixed-order sum of the per-object
+    gradients to the same bound -- not bit for bit."""
+    B, G, C, S = 5, 3, 7, 16
+    x = T("sdx", (B, C, 32, 32)).to(DEV)
+    th = (T("sdth", (B, G, 2, 3), 0.3) + torch.tensor([[1.0, 0, 0], [0, 1.0, 0]])).to(DEV)
+    gy = T("sdg", (G * B, C, S, S)).to(DEV)
+    outs = []
+    for _ in range(3):
+        xd = x.clone().requires_grad_(True)
+        y = ops.stn_shared(xd, th, G * B, (32, 32), (S, S), False, False, G)
+        y.backward(gy)
+        outs.append(xd.grad.clone())
+    ref = torch.zeros_like(x, dtype=torch.float64)
+    for g in range(G):                                   # the reference: one stn per object, gradients added in object order
+        xd = x.clone().requires_grad_(True)
+        y = ops.stn(xd, th[:, g].contiguous(), (B, C, S, S))
+        y.backward(gy[g * B:(g + 1) * B])
+        ref += xd.grad.double()
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    for o in outs:
+        assert float((o.double() - ref).abs().max()) <= 4e-6 * scale
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * scale and float((outs[1] - outs[2]).abs().max()) <= 4e-6 * scale
 
 
 @pytest.mark.parametrize("ac", [False, True])
@@ -937,6 +968,88 @@ def test_deep_block_conv_bn_act(case, split):
         assert rel_l2(seq[0].weight.grad, wd.grad) <= 5e-6
         assert max_abs(seq[1].weight.grad, gd.grad) <= 2e-4 * max(1.0, float(gd.grad.abs().max()))
         assert max_abs(seq[1].bias.grad, bd.grad) <= 2e-4 * max(1.0, float(bd.grad.abs().max()))
+    finally:
+        ops.pk_debug_force(0, -1, 0)
+
+
+@pytest.mark.parametrize("case", [(16, 64, 8, 8, 64, 4, 2, 1, ops.ACT_LRELU), (16, 32, 16, 16, 96, 4, 2, 1, ops.ACT_LRELU),
+                                  (5, 64, 4, 4, 96, 3, 1, 1, ops.ACT_RELU), (16, 64, 4, 4, 32, 3, 1, 1, ops.ACT_NONE)])
+@pytest.mark.parametrize("split", [0, 3])
+def test_deep_block_two_groups(case, split):
+    """The deep block on a [real; fake] batch (groups = 2; miscc/losses.py:136-174 makes two calls): ONE convolution over 2B
+    images, BatchNorm statistics per half, running statistics updated half after half -- against fp64 torch making the two
+    calls, and against two calls of the one-group deep block (same kernels up to the K-split of the GEMM)."""
+    import torch.nn as nn
+    from mogan_amd.attngan.model_base import FusedSeq, HipBatchNorm2d, HipConv2d
+    B, Cin, H, W, Cout, k, s, pad, act = case
+    ops.pk_debug_force(1, -1, split)
+    before = dict(ops.DEEP_STATS)
+    try:
+        def make():
+            mods = [HipConv2d(Cin, Cout, k, s, pad, bias=False), HipBatchNorm2d(Cout)]
+            if act == ops.ACT_LRELU:
+                mods.append(nn.LeakyReLU(0.2))
+            elif act == ops.ACT_RELU:
+                mods.append(nn.ReLU())
+            seq = FusedSeq(*mods)
+            with torch.no_grad():
+                seq[0].weight.copy_(T("d2w%s" % (case,), (Cout, Cin, k, k), 0.1))
+                seq[1].weight.copy_(T("d2g%s" % (case,), (Cout,), 0.3, 1.0))
+                seq[1].bias.copy_(T("d2b%s" % (case,), (Cout,), 0.2))
+            return seq
+        x = torch.cat([T("d2xa%s" % (case,), (B, Cin, H, W)), T("d2xb%s" % (case,), (B, Cin, H, W), 0.7, 0.4)])
+        seq = make()
+        xd = x.double().requires_grad_(True)
+        wd = seq[0].weight.detach().double().requires_grad_(True)
+        gd = seq[1].weight.detach().double().requires_grad_(True)
+        bd = seq[1].bias.detach().double().requires_grad_(True)
+        rm, rv = torch.zeros(Cout, dtype=torch.float64), torch.ones(Cout, dtype=torch.float64)
+        outs = []
+        for g in range(2):
+            zd = F.batch_norm(F.conv2d(xd[g * B:(g + 1) * B], wd, None, s, pad), rm, rv, gd, bd, True, 0.1, 1e-5)
+            outs.append(F.leaky_relu(zd, 0.2) if act == ops.ACT_LRELU else (F.relu(zd) if act == ops.ACT_RELU else zd))
+        zd = torch.cat(outs)
+        gz = T("d2gz%s" % (case,), zd.shape)
+        zd.backward(gz.double())
+        # one pass, two groups
+        seq = seq.to(DEV).train()
+        ops.attach_packs(seq[0].weight)
+        xg = x.to(DEV).requires_grad_(True)
+        z = seq(xg, groups=2)
+        assert ops.DEEP_STATS["fwd"] == before["fwd"] + 1, "the grouped deep block was not taken"
+        assert getattr(z, "_mogan_panel", None) is not None
+        z.backward(gz.to(DEV))
+        torch.cuda.synchronize()
+        assert ops.DEEP_STATS["bwd"] == before["bwd"] + 1
+        assert max_abs(z, zd) <= 2e-5
+        assert max_abs(seq[1].running_mean, rm) <= 1e-6 and max_abs(seq[1].running_var, rv) <= 1e-5
+        assert int(seq[1].num_batches_tracked) == 2
+        assert rel_l2(xg.grad, xd.grad) <= 5e-6, rel_l2(xg.grad, xd.grad)
+        assert rel_l2(seq[0].weight.grad, wd.grad) <= 5e-6
+        assert max_abs(seq[1].weight.grad, gd.grad) <= 2e-4 * max(1.0, float(gd.grad.abs().max()))
+        assert max_abs(seq[1].bias.grad, bd.grad) <= 2e-4 * max(1.0, float(bd.grad.abs().max()))
+        # ... and the two calls of the one-group block
+        seq2 = make().to(DEV).train()
+        ops.attach_packs(seq2[0].weight)
+        x2 = x.to(DEV).requires_grad_(True)
+        z2 = torch.cat([seq2(x2[:B]), seq2(x2[B:])])
+        z2.backward(gz.to(DEV))
+        torch.cuda.synchronize()
+        assert max_abs(z, z2.double().cpu()) <= 1e-5
+        assert max_abs(seq[1].running_mean, seq2[1].running_mean.double().cpu()) <= 1e-7
+        assert max_abs(seq[1].running_var, seq2[1].running_var.double().cpu()) <= 1e-6
+        assert rel_l2(xg.grad, x2.grad.double().cpu()) <= 2e-6
+        assert rel_l2(seq[0].weight.grad, seq2[0].weight.grad.double().cpu()) <= 2e-6
+        # the next deep block takes the 2B panel: same result as from the plain tensor
+        nxt = FusedSeq(HipConv2d(Cout, 64, 3, 1, 1, bias=False), HipBatchNorm2d(64), nn.LeakyReLU(0.2)).to(DEV).train()
+        ops.attach_packs(nxt[0].weight)
+        if Cout % 32 == 0 and z.shape[2] * z.shape[3] <= 64:
+            hits = ops.DEEP_STATS["panel_hits"]
+            a1 = nxt(z, groups=2)
+            assert ops.DEEP_STATS["panel_hits"] == hits + 1
+            a2 = nxt(z.detach().clone(), groups=2)
+            torch.cuda.synchronize()
+            assert torch.equal(a1, a2)
     finally:
         ops.pk_debug_force(0, -1, 0)
 

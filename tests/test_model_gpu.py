@@ -216,6 +216,120 @@ def test_losses():
     close(mu.grad, g["dmu"], 1e-7, 1e-4); close(lv.grad, g["dlv"], 1e-7, 1e-4)
 
 
+@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("force_deep", [False, True])
+def test_discriminator_loss_paired_pass_equals_the_two_calls(which, force_deep):
+    """discriminator_loss runs D(real) and D(fake.detach()) (two calls in the reference, miscc/losses.py:146,152) as ONE pass over
+    [real; fake] with BatchNorm statistics per half (losses.D_PAIR, groups = 2 down the network): loss, every gradient, the
+    running statistics (updated real first, then fake) and the call counters against the two-call path of the same kernels;
+    with the packed-weight deep blocks forced on (grouped tail kernels) and off (grouped BatchNorm kernels); the activation
+    trace comes out in the reference's call order."""
+    from mogan_amd.attngan import model
+    from mogan_amd.attngan.miscc import losses as L
+    from mogan_amd.hip import ops
+    cfg.GAN.DF_DIM = 32
+    B, S = 4, 64 << which
+    cls = (model.D_NET64, model.D_NET128, model.D_NET256)[which]
+    real = T("pp.real%d" % which, (B, 3, S, S), 0.5).to(DEV)
+    fake = T("pp.fake%d" % which, (B, 3, S, S), 0.5, 0.1).to(DEV).requires_grad_(True)
+    sent = T("pp.sent", (B, 16)).to(DEV)
+    ones, zeros = torch.ones(B, device=DEV), torch.zeros(B, device=DEV)
+    res = {}
+    ops.pk_debug_force(1 if force_deep else 0, -1, 0)
+    was = L.D_PAIR
+    try:
+        for pair in (True, False):
+            D = cls()
+            det_fill_state(D, "PP%d." % which)
+            D = D.to(DEV).train()
+            if force_deep:
+                for p_ in D.parameters():
+                    if p_.dim() == 4:
+                        ops.attach_packs(p_)
+            L.D_PAIR = pair
+            deep0 = ops.DEEP_STATS["fwd"]
+            ops.ACT_TRACE = []
+            try:
+                err = L.discriminator_loss(D, real, fake, sent, ones, zeros, None)
+            finally:
+                trace, ops.ACT_TRACE = ops.ACT_TRACE, None
+            err.backward()
+            torch.cuda.synchronize()
+            res[pair] = (float(err), {k: v.grad.clone() for k, v in D.named_parameters()},
+                         {k: v.clone() for k, v in D.state_dict().items() if "running" in k or "tracked" in k},
+                         [(a, t.clone()) for a, t in trace], ops.DEEP_STATS["fwd"] - deep0)
+    finally:
+        L.D_PAIR = was
+        ops.pk_debug_force(0, -1, 0)
+    assert fake.grad is None                              # (the D update detaches the fake image)
+    (e1, g1, s1, t1, n1), (e2, g2, s2, t2, n2) = res[True], res[False]
+    if force_deep:
+        assert n2 > 0 and n1 > 0 and n1 < n2, "deep blocks: %d launches paired, %d in two calls" % (n1, n2)
+    assert abs(e1 - e2) <= 2e-6 * abs(e2)
+    for k in g2:
+        d = float((g1[k] - g2[k]).norm() / (g2[k].norm() + 1e-30))
+        assert d <= (2e-5 if g2[k].dim() > 1 else 2e-4), "%s: %.3e" % (k, d)
+    for k in s2:
+        if "tracked" in k:
+            assert int(s1[k]) == int(s2[k]), k
+        else:
+            assert float((s1[k] - s2[k]).abs().max()) <= 1e-6 * max(1.0, float(s2[k].abs().max())), k
+    assert len(t1) == len(t2)
+    for (a1, x1), (a2, x2) in zip(t1, t2):
+        assert a1 == a2 and x1.shape == x2.shape
+        assert float((x1 - x2).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_discriminator_loss_in_two_halves_equals_the_whole(which):
+    """miscc/losses.discriminator_loss_real + _fake (the real-image terms evaluated and back-propagated before the fake images
+    exist, then the fake-image terms) against discriminator_loss with one backward: the loss value, every parameter gradient
+    (accumulated in place by the two backward passes), and the BatchNorm running statistics -- the conditional head's
+    wrong-pair call runs early but updates the running buffers in the reference's call order (real, fake, wrong;
+    mogan_bn_running_update) -- and the call counters."""
+    from mogan_amd.attngan import model
+    from mogan_amd.attngan.miscc import losses as L
+    B = 4
+    cls = (model.D_NET64, model.D_NET128, model.D_NET256)[which]
+    bt = synthetic.to_device(synthetic.make_batch(B, words_num=5, nef=16, seed=17), DEV)
+    real = bt["imgs"][which]
+    fake = T("h2.fake%d" % which, real.shape, 0.5, 0.1).to(DEV).requires_grad_(True)
+    kw = dict(local_labels=bt["label_one_hot"], transf_matrices=bt["tm"], transf_matrices_inv=bt["tmi"]) if which == 0 else {}
+    ones, zeros = torch.ones(B, device=DEV), torch.zeros(B, device=DEV)
+    res = {}
+    for split in (True, False):
+        D = cls()
+        det_fill_state(D, "H2%d." % which)
+        D = D.to(DEV).train()
+        for p_ in D.parameters():
+            p_.grad = torch.zeros_like(p_)                # (dense .grad buffers: the kernels accumulate in place)
+        if split:
+            errR, pend = L.discriminator_loss_real(D, real, bt["sent_emb"], **kw)
+            errR.backward()
+            assert len(pend) == 1                         # the wrong-pair call of the conditional head's BatchNorm
+            errF = L.discriminator_loss_fake(D, fake, bt["sent_emb"], pend, **kw)
+            errF.backward()
+            err = float(errR) + float(errF)
+        else:
+            e = L.discriminator_loss(D, real, fake, bt["sent_emb"], ones, zeros, None, **kw)
+            e.backward()
+            err = float(e)
+        torch.cuda.synchronize()
+        res[split] = (err, {k: v.grad.clone() for k, v in D.named_parameters()},
+                      {k: v.clone() for k, v in D.state_dict().items() if "running" in k or "tracked" in k})
+    assert fake.grad is None
+    (e1, g1, s1), (e2, g2, s2) = res[True], res[False]
+    assert abs(e1 - e2) <= 2e-6 * abs(e2)
+    for k in g2:
+        d = float((g1[k] - g2[k]).norm() / (g2[k].norm() + 1e-30))
+        assert d <= 2e-6, "%s: %.3e" % (k, d)
+    for k in s2:
+        if "tracked" in k:
+            assert int(s1[k]) == int(s2[k]), k
+        else:
+            assert float((s1[k] - s2[k]).abs().max()) <= 2e-7 * max(1.0, float(s2[k].abs().max())), k
+
+
 def test_g_net_eval_mode():
     """netG.eval() forward of the sampling path (trainer.py:398,431-437): BN folded into per-channel affines."""
     g = golden("gnet_eval")

@@ -11,9 +11,12 @@ env $E rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw 
 python $R/tools/pmc_traffic.py /tmp/pf/f_counter_collection.csv /tmp/pw/w_counter_collection.csv $R/profiles/${RN}_pmc_traffic.json > /tmp/pt.log 2>&1
 cp $R/profiles/${RN}_pmc_traffic.json $O/
 B2="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline"
-env MOGAN_STREAMS=0 MOGAN_WGRAD_STREAM=0 MOGAN_GRAPH_ENCODER=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- $B2 > /tmp/ks.log 2>&1
+# MOGAN_FAST_INIT=1: plain normal_ initialisation instead of orthogonal_ (rocSOLVER QR + Tensile GEMMs on the GPU were 82 % of the
+# round-4 summary); tools/stats_summary.py turns the csv into the per-step table <round>_bench_kernel_stats_per_step.txt
+env MOGAN_FAST_INIT=1 MOGAN_STREAMS=0 MOGAN_WGRAD_STREAM=0 MOGAN_GRAPH_ENCODER=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- $B2 > /tmp/ks.log 2>&1
 cp /tmp/ks/ks_kernel_stats.csv $O/${RN}_bench_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/km -o km -- $B2 > /tmp/km.log 2>&1
+python $R/tools/stats_summary.py $O/${RN}_bench_kernel_stats.csv 13 > $O/${RN}_bench_kernel_stats_per_step.txt 2>&1
+env MOGAN_FAST_INIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/km -o km -- $B2 > /tmp/km.log 2>&1
 cp /tmp/km/km_kernel_stats.csv $O/${RN}_bench_kernel_stats_multistream.csv
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/${RN}_bench_n1.json.log 2>/dev/null

@@ -188,6 +188,8 @@ def roofline_leg(engine, run_step, steps=2):
             name = "wino_wgrad_kernel" if int(c) == 1 else "dconv_wgrad_kernel"
         elif int(c) == 1:       # fused Winograd F(2x2,3x3): flops = the 16/36 of the direct multiplies it executes
             name = "wino3_fwd_kernel<%s>" % MODES[int(m)][6:]
+        elif int(c) == 2:       # the pre-split direct kernel (csrc/mogan_dconv2.hip, round 5)
+            name = "dconv2_fwd_kernel<%s>" % MODES[int(m)][6:]
         else:
             name = "dconv_fwd_kernel<%s>" % MODES[int(m)][6:]
         rows.append(dict(kernel=name,
@@ -455,6 +457,8 @@ def main():
     torch.cuda.set_device(device)                       # before the process group: RCCL binds to the current device
     if _EAGER_ATTNGAN:
         lib.reserve_hw_queues()                         # before any other stream exists (RCCL's included)
+        from mogan_amd.attngan import trainer as _tr
+        _tr.create_engine_streams()                     # the step's streams, bound to their queues before RCCL's exist
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -88,7 +88,8 @@ int mogan_gemm_tune_clear(void);
  * arrangement ("hardware queues").  Returns the number of streams held, or a negative error. */
 int mogan_reserve_streams(int n);
 
-/* test hook: force a GEMM tile config (0..4, -1 = heuristic) and a split-K factor (0 = heuristic) */
+/* test hook: force a GEMM tile config (0..4; -1 = the default dispatch; -2 = the default dispatch without the Winograd kernels, so
+ * that 3x3 stride-1 shapes reach the direct kernels) and a split-K factor (0 = heuristic) */
 int mogan_gemm_debug_force(int cfg, int split);
 /* tuning hook: grouped launches (mogan_conv2d_*_group) with fewer tiles than this run their members one by one (default 1600, see csrc/mogan_gemm.hip) */
 int mogan_gemm_group_min_tiles(int tiles);
@@ -390,22 +391,6 @@ int mogan_stn_fwd(const float* x, const float* theta, float* y, int B, int C, in
                   int align_corners, hipStream_t stream);
 int mogan_stn_bwd(const float* dy, const float* theta, float* dx, int B, int C, int Hin, int Win, int Hout,
                   int Wout, int align_corners, hipStream_t stream);
-/* ---------------------------------------------------------------- Winograd F(2x2,3x3) with prepared filter planes (round 4)
- * The 3x3 stride-1 convolutions of the ResBlocks (model.py:67-81) run on a fused Winograd kernel whose transformed filters
- * arrive pre-split into their three bf16 pieces in matrix-instruction lane order.  mogan_conv2d_fwd / _dgrad build those planes
- * per call in the workspace; a caller that owns the weight (the optimizer) builds them ONCE per weight version instead:
- *   mogan_wino_prep_bytes   size of the planes for this call geometry, 0 = the geometry does not take this kernel
- *   mogan_wino_prep         w (Cout,Cin,3,3) -> planes (dgrad = 1: the rotated / transposed filters of the data gradient)
- *   mogan_conv2d_fwd_wp     y (B,Cout,H+2p-2,W+2p-2) = conv3x3 s1 (x (B,Cin,H,W)) from forward planes
- *   mogan_conv2d_dgrad_wp   dx (B,Cin,H,W) from dy and data-gradient planes
- * (split-bf16 build only; the native-fp32 build returns 0 bytes and the caller stays on mogan_conv2d_fwd.) */
-size_t mogan_wino_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up,
-                             int dgrad);
-int mogan_wino_prep(const float* w, void* planes, int Cout, int Cin, int dgrad, hipStream_t stream);
-int mogan_conv2d_fwd_wp(const float* x, const void* planes, float* y, int B, int Cin, int Hs, int Ws, int Cout, int ph, int pw,
-                        hipStream_t stream);
-int mogan_conv2d_dgrad_wp(const float* dy, const void* planes, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int ph,
-                          int pw, hipStream_t stream);
 /* The same with a shared / constant source (round 4; the object pathways' inputs without their materialised copies):
  *   xB       x holds xB images and output sample b reads image b % xB -- `stn(image, transf_matrices[:, idx], ...)` for every
  *            object idx from ONE copy of the image batch (model.py:663-665); dx then has xB images and collects all objects;

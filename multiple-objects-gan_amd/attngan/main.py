@@ -63,11 +63,13 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if cfg.TRAIN.FLAG and not torch.cuda.is_initialized():
-        # the eager multi-stream step: its hardware-queue arrangement (4 queues; 3 idle streams first when the process is a member of a group), before the HIP runtime starts and before
-        # RCCL creates its streams (hip/lib.py, "hardware queues")
+        # the eager multi-stream step: 4 hardware queues, and the engine's streams created / bound to them in their fixed order
+        # before RCCL creates its own (hip/lib.py "hardware queues", trainer.create_engine_streams)
         hiplib.configure_hw_queues()
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         hiplib.reserve_hw_queues()
+        from .trainer import create_engine_streams
+        create_engine_streams()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")       # RCCL's stream on its own priority queue (see bench.py)

@@ -411,6 +411,50 @@ def _engine_stream(key):
     return s
 
 
+# first-use order of the step's streams (tokens: s<i> = branch stream of D_i / s3 = the Inception-DAMSM branch, w<i> / wm = the
+# weight-gradient streams of the branches / of the main stream, cG / cD = communication streams, x = an unused stream).
+# Measured (profiles/r05_queue_table.csv; 4 hardware queues, no reserved streams, img/s single process / member of a 1-rank
+# RCCL group): this order 437 / 435 (two repeats each), "s2,s3,wm,s1,s0" 438 / 435, "s0,s1,s2,s3,w2,w1,w0,wm" 411 / 409,
+# "s2,s1,s0,s3,w2,w1,w0,wm" 399 / 398, "s3,s2,s1,x,s0,wm" 407; streams bound lazily at their first use in the step (rounds 1-4):
+# 432-434 / 401.  The layout is a function of this order alone, and the two kinds of process agree to 1 %.
+ENGINE_STREAM_ORDER = "s2,s3,s1,wm,s0,w2,w1,w0,cG,cD"
+_KEEP_STREAMS = []
+_STREAMS_CREATED = set()
+
+
+def create_engine_streams(n_discriminators=3, touch=True):
+    """The streams a TrainEngine of this process will run on, created NOW, in the engine's canonical order (branch streams, their
+    weight-gradient streams in the order the branches run, the generator's weight-gradient stream, the communication streams of
+    the chunked buckets) and, with `touch`, each used once so that the runtime binds it to its hardware queue in that order.
+    Entry points call this right after torch.cuda.set_device -- BEFORE torch.distributed creates the process group -- so the
+    stream -> hardware-queue layout of the step does not depend on whether (and when) RCCL adds its own stream: one layout, one
+    queue default for every kind of process (hip/lib.py: hw_queue_defaults; profiles/r05_queue_table.csv)."""
+    dev = torch.cuda.current_device()
+    if dev in _STREAMS_CREATED:
+        return []
+    _STREAMS_CREATED.add(dev)
+    side = [_engine_stream(("side", i)) for i in range(n_discriminators + 1)]
+    table = {"s%d" % i: (lambda i=i: side[i]) for i in range(n_discriminators + 1)}
+    table.update({"w%d" % i: (lambda i=i: ops.precreate_wgrad_stream(side[i])) for i in range(n_discriminators)})
+    table["wm"] = lambda: ops.precreate_wgrad_stream(torch.cuda.current_stream())
+    table["cG"] = lambda: _engine_stream(("comm", "G"))
+    table["cD"] = lambda: _engine_stream(("comm", "D256"))
+    table["x"] = lambda: torch.cuda.Stream()              # a stream nobody uses: takes a slot of the round-robin
+    order = os.environ.get("MOGAN_STREAM_ORDER") or ENGINE_STREAM_ORDER
+    made = [table[k]() for k in order.split(",") if k in table]
+    _KEEP_STREAMS.extend(made)
+    if touch:
+        t = torch.zeros(64, device="cuda")
+        cur = torch.cuda.current_stream()
+        for s in made:
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                t.add_(1.0)
+            cur.wait_stream(s)
+        torch.cuda.synchronize()
+    return made
+
+
 class TrainEngine:
     """Device-side state of one rank: networks, flat optimizers, DP communicator, optional hipGraph."""
 
@@ -455,6 +499,8 @@ class TrainEngine:
         # there for hosts whose python is slower than the GPU's 40 ms step.
         self.g_graphs = self.branch_graphs and not self.distributed and os.environ.get("MOGAN_G_GRAPHS", "0") != "0"
         self._bg = None
+        if torch.cuda.is_available() and self.multi_stream and not use_graph:
+            create_engine_streams(len(netsD))       # (a no-op when the entry point has done it before the process group came up)
         # the discriminator loss in two halves: the real-image terms evaluated and back-propagated ahead of the generator's
         # forward (miscc/losses.py: discriminator_loss_real / _fake; MOGAN_D_SPLIT=0: one loss, one backward after the forward)
         self.split_d = self.multi_stream and split_d_loss()

@@ -745,6 +745,13 @@ static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 template <int KH, int KW, int S, int CK>
 static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
+    if constexpr (S == 1) {           // round 5: the pre-split form (mogan_dconv2.hip) where its tile grid fits
+        if (p.up == 0) {
+            const int rc2 = mogan_dconv2_fwd_try(p.X, p.Wt, 0, p.Y, p.B, p.Cin, p.Cout, p.H, p.W, p.OH, p.OW, KH, KW, p.pt, p.pl, p.yH,
+                                                 p.yW, p.ys, p.npar, p.accumulate, ws, ws_bytes, st);
+            if (rc2 != 0) return rc2 < 0 ? rc2 : 0;
+        }
+    }
     // tile config: 96-wide M when it pads less
     const bool m96 = cdiv(p.Cout, 96) * 96 < cdiv(p.Cout, 128) * 128;
     const int bm = m96 ? 96 : 128;
@@ -896,6 +903,12 @@ int mogan_dconv_dgrad_try(const float* dy, const float* w, float* dx, int B, int
     if (!ws || ws_bytes < wbytes + 256) return 0;
     if ((long long)B * Cout * OH * OW >= (1ll << 29) || (long long)Cout * Cin * KH * KW >= (1ll << 29) ||
         (long long)B * Cin * H * W >= (1ll << 30)) return 0;
+    {   // round 5: the pre-split form takes the ORIGINAL filters (its prep kernel indexes them flipped / by parity class)
+        const int rc2 = k33 ? mogan_dconv2_fwd_try(dy, w, 1, dx, B, Cout, Cin, OH, OW, H, W, 3, 3, KH - 1 - ph, KW - 1 - pw, H, W, 1, 1,
+                                                   0, ws, ws_bytes, st)
+                            : mogan_dconv2_fwd_try(dy, w, 2, dx, B, Cout, Cin, OH, OW, gH, gW, 2, 2, 0, 0, H, W, 2, 4, 0, ws, ws_bytes, st);
+        if (rc2 != 0) return rc2;
+    }
     float* wt = (float*)ws;                                          // transformed weights live at the head of ws
     void* ws2 = (char*)ws + ((wbytes + 255) & ~(size_t)255);
     const size_t ws2_bytes = ws_bytes - ((wbytes + 255) & ~(size_t)255);

@@ -763,6 +763,7 @@ void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipS
     hipEventCreate(&r.e0); hipEventCreate(&r.e1); hipEventRecord(r.e0, st);
     g_prof_open = r; g_prof_open_valid = true;
 }
+void mogan_prof_relabel(int cfg) { if (g_prof_open_valid) g_prof_open.cfg = cfg; }     // the open record belongs to another kernel
 void mogan_prof_end(int taken, hipStream_t st) {       // !taken: the attempt fell through, drop the record
     if (!g_prof_open_valid) return;
     g_prof_open_valid = false;
@@ -1081,7 +1082,7 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
         rc = mogan_smallc_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
-    if (g_force_cfg < 0) {          // 3x3 s1 p1 at >= 32 channels: fused Winograd F(2x2,3x3), 2.25x fewer multiplies
+    if (g_force_cfg == -1) {        // 3x3 s1 p1 at >= 32 channels: fused Winograd F(2x2,3x3), 2.25x fewer multiplies (-2: test hook, off)
         // (recorded flops = the multiplies the kernel executes: 16 per 2x2 outputs instead of 36)
         mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
         rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 0, nullptr, nullptr, 0, ws, ws_bytes, stream);
@@ -1257,7 +1258,7 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
         rc = mogan_smallc_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
-    if (g_force_cfg < 0) {
+    if (g_force_cfg == -1) {
         mogan_prof_begin(5, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
         rc = mogan_wino_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 1, nullptr, nullptr, 0, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
@@ -1311,7 +1312,7 @@ int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Ci
         rc = mogan_smallc_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
-    if (g_force_cfg < 0) {
+    if (g_force_cfg == -1) {
         mogan_prof_begin(6, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, Cin * KH * KW, B * p.OH * p.OW, stream);
         rc = mogan_wino_wgrad_try(dy, x, dw, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, accumulate, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);

@@ -16,6 +16,10 @@ MOGAN_HIDDEN int mogan_dconv_dgrad_try(const float* dy, const float* w, float* d
 MOGAN_HIDDEN int mogan_dconv_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws,
                                        int Cout, int KH, int KW, int stride, int ph, int pw, int up, int accumulate,
                                        void* ws, size_t ws_bytes, hipStream_t st);
+// direct convolution, second form (mogan_dconv2.hip: both MFMA operands pre-split; 3x3 / 2x2 stride-1 filters on 8 x 32 tile grids)
+MOGAN_HIDDEN int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, int B, int Cin, int Cout, int H, int W,
+                                      int OH, int OW, int KH, int KW, int pt, int pl, int yH, int yW, int ys, int npar,
+                                      int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 // direct VALU kernels for convolutions with <= 4 channels on one side (mogan_smallc.hip); same return convention
 MOGAN_HIDDEN int mogan_smallc_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout,
                                       int KH, int KW, int stride, int ph, int pw, int up, hipStream_t st);
@@ -37,5 +41,6 @@ MOGAN_HIDDEN void mogan_splitk_reduce_dense(const float* ws, float* out, long lo
 MOGAN_HIDDEN int mogan_split_target(hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_end(int taken, hipStream_t st);
+MOGAN_HIDDEN void mogan_prof_relabel(int cfg);     // the open launch record's kernel id (2 = dconv2_fwd_kernel)
 MOGAN_HIDDEN extern int mogan_use_dconv;
 #endif

@@ -3,13 +3,12 @@
 //   Y = A^t [ sum_ci (G g G^t) .* (B^t d B) ] A         g = 3x3 filter, d = 4x4 input tile, Y = 2x2 outputs
 // 16 multiplies per (ci, co, 2x2 outputs) instead of 36: 2.25x fewer MFMA flops, no intermediate in HBM.
 //
-// A block owns 96 output channels x 32 tiles (2 tile rows x 16 tile columns = 4 x 32 output pixels) of one image.  Per chunk
-// of 8 input channels it stages the 6 x 34 input halo (Xs), transforms it in registers (one thread = one (channel, tile):
-// 16 LDS reads, 32 add/sub) into Vs[xi][c][tile], stages the pre-transformed weights Us[xi][c][co] (global layout
-// U[xi][ci][co], 16-byte loads and stores), and runs the 16 small GEMMs  M_xi[co][tile] += U_xi[co][c] V_xi[c][tile]  on
-// v_mfma_f32_32x32x2_f32: wave w owns the four positions xi = 4w..4w+3 (row w of the 4x4 grid), 4 x 3 accumulator tiles =
-// 192 registers.  Both operand reads are ds_read_b32 with the lanes on consecutive dwords (conflict-free).  Epilogue: the
-// row transform M A is local to a wave, the column transform A^t (.) goes through LDS (one pass per output column parity).
+// Forward / data gradient (wino3_fwd_kernel, split-bf16 build): a block owns 96 output channels x 32 tiles (2 tile rows x 16 tile
+// columns = 4 x 32 output pixels) of one image, 8 waves, wave w the two transform positions 2w, 2w + 1; the transformed filters
+// arrive pre-split in lane order (wino3_weight_kernel), the halo is staged and transformed in LDS (see the kernel's comment).
+// Weight gradient (wino_wgrad_kernel + wino_wgrad_finish): tiles on K, both operands transformed in LDS, K-split partials.
+// One forward form since round 5: the round-2 kernel (fp32 filter planes split in registers), the prepared-planes entry points
+// and the lab switches lost their A/Bs and were removed; the native-fp32 build takes the direct kernels for these layers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -31,329 +30,6 @@ __device__ __forceinline__ float ldgx(__amdgpu_buffer_rsrc_t r, unsigned idx, bo
 }
 __device__ __forceinline__ f32x4 ldgx4(__amdgpu_buffer_rsrc_t r, unsigned idx, bool ok) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? idx * 4u : 0xFFFFFFF0u, 0, 0));
-}
-
-// Pre-transformed weights in the order the MFMA lanes consume them.  The A operand of v_mfma_f32_32x32x2_f32 is one
-// value per lane: lane (h, l31) of wave w supplies U_xi[m = 32a + l31][c = 2kk + h] for its two positions xi = 2w + j.  Per
-// chunk of 8 input channels that is 2*4*3 = 24 values per lane, stored so that a wave fetches them with six fully
-// coalesced 16-byte loads straight into registers (no LDS round trip for the weights):
-//   U2[mb][w][chunk][i = 0..5][lane][e = 0..3]   with v = (j*4 + kk)*3 + a = 4i + e
-// U_xi = (G g G^t)[xi], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  flip = 1: the data-gradient filter
-// g'(ci' = co, co' = ci) = rot180(w[co][ci]), i.e. the kernel then maps dY (Cout channels) to dX (Cin channels).
-__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
-                                                          int Cin, int flip, long long ngroups) {
-    // one thread per 16-byte group of U2 (coalesced stores); U_xi = (G g G^t)[xi] = sum_{a,b} G[r][a] G[q][b] g[a][b]
-    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gidx >= ngroups) return;
-    const int Kin = flip ? Cout : Cin, Kout = flip ? Cin : Cout;       // reduction / output channels of the kernel
-    const int nchunk = Kin / CK;
-    const int lane = (int)(gidx & 63); long long rr = gidx >> 6;
-    const int i = (int)(rr % 6); rr /= 6;
-    const int chunk = (int)(rr % nchunk); rr /= nchunk;
-    const int wv = (int)(rr % 8); const int mb = (int)(rr / 8);
-    const int h = lane >> 5, l31 = lane & 31;
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-    f32x4 out;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int v = 4 * i + e, j = v / 12, kk = (v - j * 12) / 3, a3 = v - j * 12 - kk * 3;
-        const int xi = 2 * wv + j, r = xi >> 2, q = xi & 3;
-        const int kout = mb * BM + a3 * 32 + l31, kin = chunk * CK + 2 * kk + h;
-        float u = 0.f;
-        if (kout < Kout) {
-            const int co = flip ? kin : kout, ci = flip ? kout : kin;
-            const float* g = w + ((size_t)co * Cin + ci) * 9;
-            float t[3];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                float tt = 0.f;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) tt += G[r][a] * (flip ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b]);
-                t[b] = tt;
-            }
-            u = G[q][0] * t[0] + G[q][1] * t[1] + G[q][2] * t[2];
-        }
-        out[e] = u;
-    }
-    *(f32x4*)(U + gidx * 4) = out;
-}
-
-// (H, W) = input dims, (OH, OW) = output dims = (H, W) + 2 pad - 2 (pad 0 / 1 / 2; ragged tiles are masked), optional fused
-// per-channel epilogue y = act(scale[co] * y + shift[co]) (the frozen BN + ReLU of the Inception trunk)
-__global__ __launch_bounds__(512) void wino_fwd_kernel(const float* __restrict__ X, const float* __restrict__ U,
-                                                       float* __restrict__ Y, int Cin, int H, int W, int Cout, int OH, int OW,
-                                                       int pad, int tiles_x, int tiles_y, int ntile, int nimg,
-                                                       const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
-                                                       int ep_relu, unsigned x_bytes, unsigned u_bytes) {
-    constexpr int XSZ = CK * XR * XCP, VSZ = 16 * CK * NT;
-    __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ + 4];      // + a dump slot for the idle staging lanes
-    __shared__ __attribute__((aligned(16))) float Vs[2 * VSZ];
-    __shared__ __attribute__((aligned(16))) float Ts[8 * BM * NT];      // epilogue exchange
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    const int plane = H * W;
-    const int nchunk = Cin / CK;
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U, (short)0, (int)u_bytes, 0x00020000);
-
-    // staging plan, tile independent part: element e = tid + 512 i of the 8 x 6 x 34 halo
-    constexpr int NXE = (CK * XR * XC + 511) / 512;         // 4
-    int xl[NXE], xhy[NXE], xhx[NXE]; unsigned xc[NXE];
-#pragma unroll
-    for (int i = 0; i < NXE; ++i) {
-        const int e = tid + 512 * i;
-        const int c = e / (XR * XC), r = e - c * (XR * XC);
-        const int hy = r / XC, hx = r - hy * XC;
-        xl[i] = e < CK * XR * XC ? c * (XR * XCP) + hy * XCP + hx : -1;
-        xhy[i] = e < CK * XR * XC ? hy - pad : -0x10000; xhx[i] = hx - pad;
-        xc[i] = (unsigned)c * plane;
-    }
-    const int th = tid >> 8, tc = (tid >> 5) & 7, tt = tid & 31, tty = tt >> 4, ttx = tt & 15;
-
-    // per tile: (mb, img, ty, tx) with tx fastest; xg = global element index of this thread's halo elements at chunk 0
-    unsigned xg[NXE]; unsigned ubase; int m0, img, oy0, ox0;
-    auto plan = [&](int tile, unsigned (&g)[NXE], unsigned& ub, int& m0_, int& img_, int& oy_, int& ox_) {
-        int t = tile;
-        const int tx = t % tiles_x; t /= tiles_x;
-        const int ty = t % tiles_y; t /= tiles_y;
-        img_ = t % nimg; const int mb = t / nimg;
-        m0_ = mb * BM; oy_ = ty * 2 * TROWS; ox_ = tx * 2 * TCOLS;
-#pragma unroll
-        for (int i = 0; i < NXE; ++i) {
-            const int iy = oy_ + xhy[i], ix = ox_ + xhx[i];
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            g[i] = ok ? (unsigned)(img_ * Cin) * plane + xc[i] + (unsigned)(iy * W + ix) : 0x30000000u;   // reads 0
-        }
-        ub = (unsigned)((mb * 8 + wave) * nchunk) * (6 * 64 * 4) + (unsigned)lane * 4;
-    };
-
-    float rx[NXE], rx1[NXE];
-    auto load_x = [&](float (&r)[NXE], const unsigned (&g)[NXE], int c0) {
-#pragma unroll
-        for (int i = 0; i < NXE; ++i) r[i] = ldgx(rX, g[i] + (unsigned)c0 * plane, true);
-    };
-    auto store_x = [&](const float (&r)[NXE], float* Xd, int dump) {
-#pragma unroll
-        for (int i = 0; i < NXE; ++i) Xd[xl[i] >= 0 ? xl[i] : dump] = r[i];
-    };
-    auto load_a = [&](f32x4 (&au)[6], unsigned ub, int chunk) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) au[i] = ldgx4(rU, ub + (unsigned)(chunk * 6 + i) * 256u, true);
-    };
-    auto transform = [&](const float* Xc, float* Vd) {      // rows 2th, 2th+1 of V = B^t d B for (channel tc, tile tt)
-        float ra[4], rb[4], rc[4];
-        const float* px = &Xc[tc * (XR * XCP) + (2 * tty + th) * XCP + 2 * ttx];
-        {
-            const float2 a0 = *(const float2*)px, a1 = *(const float2*)(px + 2);
-            const float2 b0 = *(const float2*)(px + XCP), b1 = *(const float2*)(px + XCP + 2);
-            const float2 c0 = *(const float2*)(px + 2 * XCP), c1 = *(const float2*)(px + 2 * XCP + 2);
-            ra[0] = a0.x; ra[1] = a0.y; ra[2] = a1.x; ra[3] = a1.y;
-            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
-            rc[0] = c0.x; rc[1] = c0.y; rc[2] = c1.x; rc[3] = c1.y;
-        }
-        float u[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float t1 = ra[j] - rc[j], t2 = rb[j] - ra[j], t3 = rb[j] + rc[j];
-            u[0][j] = th ? t2 : t1;
-            u[1][j] = th ? t1 : t3;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float* pv = &Vd[(((2 * th + i) * 4) * CK + tc) * NT + tt];
-            pv[0] = u[i][0] - u[i][2];
-            pv[CK * NT] = u[i][1] + u[i][2];
-            pv[2 * CK * NT] = u[i][2] - u[i][1];
-            pv[3 * CK * NT] = u[i][1] - u[i][3];
-        }
-    };
-
-    // 8 waves: wave w owns the two positions xi = 2w, 2w+1 (row w>>1 of the 4x4 grid, columns 2(w&1), 2(w&1)+1)
-    f32x16 acc[2][3];
-    // one chunk: MFMAs on (A registers, Vs[cur]); in their shadow: A(c+1) -> registers, X(c+2) -> Xs[cur], transform
-    // X(c+1) -> Vs[nxt], load X(c+3).  One barrier per chunk.
-    auto step = [&](int c, int cur, const f32x4 (&ac)[6], f32x4 (&an)[6]) {
-        const int nxt = cur ^ 1;
-        const float* Vc = Vs + cur * VSZ;
-        float bv[2][CK / 2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) bv[j][kk] = Vc[((wave * 2 + j) * CK + 2 * kk + h) * NT + l31];
-        load_a(an, ubase, c + 1);
-        store_x(rx, Xs + cur * XSZ, 2 * XSZ - cur * XSZ);
-        load_x(rx, xg, (c + 3) * CK);
-        transform(Xs + nxt * XSZ, Vs + nxt * VSZ);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk)
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int v = (j * 4 + kk) * 3 + a;
-                    acc[j][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[v >> 2][v & 3], bv[j][kk], acc[j][a], 0, 0, 0);
-                }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-        for (int g = 0; g < 24; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (g < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 6 weight + 4 halo loads
-            if (g < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // halo stores
-            if (g >= 4 && g < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // transform: halo reads
-            if (g >= 8) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // transform: add / sub
-            if (g >= 16) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // transform: V stores
-        }
-        __syncthreads();
-    };
-
-#if MOGAN_X6
-    // Split-bf16 form (mogan_mma.h): one v_mfma_f32_32x32x16_bf16 takes 8 k-values per lane, a chunk supplies 4 (8 input
-    // channels over the two lane halves), so the MFMAs of a chunk PAIR are issued in its second (odd) step: the lane's
-    // operand is [even chunk kk = 0..3, odd chunk kk = 0..3] for A and B alike.  The even step keeps its B values and
-    // does only the staging work.
-    float bve[2][CK / 2];
-    auto step_even = [&](int c, f32x4 (&an)[6]) {
-        const float* Vc = Vs;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) bve[j][kk] = Vc[((wave * 2 + j) * CK + 2 * kk + h) * NT + l31];
-        load_a(an, ubase, c + 1);
-        store_x(rx, Xs, 2 * XSZ);
-        load_x(rx, xg, (c + 3) * CK);
-        transform(Xs + XSZ, Vs + VSZ);
-        __syncthreads();
-    };
-    auto step_odd = [&](int c, f32x4 (&ae)[6], const f32x4 (&ao)[6]) {
-        const float* Vc = Vs + VSZ;
-        // position j = 0: split + MFMAs, then j = 1 (12 fragment registers x 4 live at a time instead of x 8)
-        auto do_j = [&](int j) {
-            X6Frag fa[3], fb;
-            float b8[8];
-#pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) {
-                b8[kk] = bve[j][kk];
-                b8[4 + kk] = Vc[((wave * 2 + j) * CK + 2 * kk + h) * NT + l31];
-            }
-            fb = x6_split8(b8);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float a8[8];
-#pragma unroll
-                for (int kk = 0; kk < CK / 2; ++kk) {
-                    const int v = (j * 4 + kk) * 3 + a;
-                    a8[kk] = ae[v >> 2][v & 3]; a8[4 + kk] = ao[v >> 2][v & 3];
-                }
-                fa[a] = x6_split8(a8);
-            }
-#pragma unroll
-            for (int term = 0; term < 6; ++term)
-#pragma unroll
-                for (int a = 0; a < 3; ++a) acc[j][a] = x6_mfma(fa[a], fb, term, acc[j][a]);
-        };
-        do_j(0);
-        store_x(rx, Xs + XSZ, XSZ);
-        load_x(rx, xg, (c + 3) * CK);
-        do_j(1);
-        load_a(ae, ubase, c + 1);
-        transform(Xs, Vs);
-        __syncthreads();
-    };
-#endif
-
-    // Persistent blocks (one per CU): the first loads of the NEXT tile (X chunks 0 and 1, the weights of chunk 0) are issued
-    // before the epilogue of the current one, so no tile but the first waits for global memory before its first MFMA, and
-    // there is no block launch gap between tiles.
-    f32x4 a0[6], a1[6];
-    int tile = blockIdx.x;
-    if (tile < ntile) {
-        plan(tile, xg, ubase, m0, img, oy0, ox0);
-        load_x(rx, xg, 0); load_x(rx1, xg, CK); load_a(a0, ubase, 0);
-    }
-    for (; tile < ntile; tile += gridDim.x) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][a][r] = 0.f;
-        store_x(rx, Xs, 2 * XSZ);
-        store_x(rx1, Xs + XSZ, XSZ);
-        load_x(rx, xg, 2 * CK);
-        __syncthreads();
-        transform(Xs, Vs);
-        __syncthreads();
-        for (int c = 0; c < nchunk; c += 2) {                   // nchunk is even (host)
-#if MOGAN_X6
-            step_even(c, a1);
-            step_odd(c + 1, a0, a1);
-#else
-            step(c, 0, a0, a1);
-            step(c + 1, 1, a1, a0);
-#endif
-        }
-        const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
-        if (tile + (int)gridDim.x < ntile) {
-            plan(tile + gridDim.x, xg, ubase, m0, img, oy0, ox0);
-            load_x(rx, xg, 0); load_x(rx1, xg, CK); load_a(a0, ubase, 0);
-        }
-
-        // ---- output transform.  Row i = wave>>1 of M: T_i[b] = sum_j M[i][j] A[j][b] with A^t = [[1,1,1,0],[0,1,-1,-1]] is
-        // split over the wave pair (columns {0,1} / {2,3}): every wave writes its partial, then Y[a][b] = sum_i A^t[a][i] T_i[b].
-        float yreg[6][2][2];
-        const int wj = wave & 1;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (b) __syncthreads();
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = wj == 0 ? (b == 0 ? acc[0][a][r] + acc[1][a][r] : acc[1][a][r])
-                                            : (b == 0 ? acc[0][a][r] : -acc[0][a][r] - acc[1][a][r]);
-                    Ts[(wave * BM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * NT + l31] = p;
-                }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int idx = tid + 512 * q;
-                float tq[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tq[i] = Ts[(2 * i) * BM * NT + idx] + Ts[(2 * i + 1) * BM * NT + idx];
-                yreg[q][0][b] = tq[0] + tq[1] + tq[2];
-                yreg[q][1][b] = tq[1] - tq[2] - tq[3];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int idx = tid + 512 * q;
-            const int m = idx >> 5, tl = idx & 31;
-            const int oy = coy0 + 2 * (tl >> 4), ox = cox0 + 2 * (tl & 15);
-            if (cm0 + m < Cout && oy < OH && ox < OW) {
-                float v[2][2] = {{yreg[q][0][0], yreg[q][0][1]}, {yreg[q][1][0], yreg[q][1][1]}};
-                if (ep_scale != nullptr) {
-                    const float sc = ep_scale[cm0 + m], sh = ep_shift[cm0 + m];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            v[a][b] = fmaf(v[a][b], sc, sh);
-                            if (ep_relu) v[a][b] = fmaxf(v[a][b], 0.f);
-                        }
-                }
-                float* o = Y + ((size_t)(cimg * Cout + cm0 + m) * OH + oy) * OW + ox;
-                const bool y1 = oy + 1 < OH;
-                if ((OW & 1) == 0) {                          // ox is even: both columns inside, 8-byte aligned
-                    *(float2*)o = make_float2(v[0][0], v[0][1]);
-                    if (y1) *(float2*)(o + OW) = make_float2(v[1][0], v[1][1]);
-                } else {
-                    const bool x1 = ox + 1 < OW;
-                    o[0] = v[0][0]; if (x1) o[1] = v[0][1];
-                    if (y1) { o[OW] = v[1][0]; if (x1) o[OW + 1] = v[1][1]; }
-                }
-            }
-        }
-        // (the next tile's store_x / transform touch Xs / Vs only; Ts is rewritten after two more barriers)
-    }
 }
 
 #if MOGAN_X6
@@ -411,9 +87,6 @@ __global__ __launch_bounds__(256) void wino3_weight_kernel(const float* __restri
     for (int pc = 0; pc < 3; ++pc) U3[base + (size_t)pc * 64] = __builtin_bit_cast(uint4, f.p[pc]);
 }
 
-// DBG (lab only, MOGAN_WINO_DBG): 1 = no filter loads inside the K loop, 2 = no output transform / stores, 4 = no halo loads /
-// input transform inside the K loop -- what each part costs; results are wrong
-template <int DBG>
 __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict__ X, const uint4* __restrict__ U3,
                                                         float* __restrict__ Y, int Cin, int H, int W, int Cout, int OH, int OW,
                                                         int pad, int tiles_x, int tiles_y, int ntile, int nimg,
@@ -542,29 +215,13 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
             float* Vn = Vs + (cur ^ 1) * VSZ2;
             const float* Xn = Xs + (cur ^ 1) * XSZ2;
             mma_j(0, Vc);
-            if (!(DBG & 1)) load_a(0, ubase, p + 1);
-            if (!(DBG & 4)) {
-                store_x(rx, Xs + cur * XSZ2);               // X(p+2)
-                load_x(rx, xg, (p + 3) * CK2);
-                transform(Xn, Vn, 0);                       // X(p+1) -> V(p+1)
-            }
+            load_a(0, ubase, p + 1);
+            store_x(rx, Xs + cur * XSZ2);                   // X(p+2)
+            load_x(rx, xg, (p + 3) * CK2);
+            transform(Xn, Vn, 0);                           // X(p+1) -> V(p+1)
             mma_j(1, Vc);
-            if (!(DBG & 1)) load_a(1, ubase, p + 1);
-            if (!(DBG & 4)) transform(Xn, Vn, 8);
-#if defined(W3_SCHED) && W3_SCHED
-            // issue-order template (lab): the first group's operands (8 LDS reads, the split), then per MFMA a few of the
-            // step's other instructions
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 36, 0);
-#pragma unroll
-            for (int g = 0; g < 36; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, W3_SCHED, 0);
-                if (g < 26) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (g < 20) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (g >= 6 && g < 30) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-#endif
+            load_a(1, ubase, p + 1);
+            transform(Xn, Vn, 8);
             __syncthreads();
         }
         const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
@@ -576,16 +233,6 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
         // ---- output transform (as in wino_fwd_kernel): row i = wave>>1 of M, T_i[b] = sum_j M[i][j] A[j][b] split over the
         // wave pair; Y[a][b] = sum_i A^t[a][i] T_i[b] through Ts, one pass per output column parity b
         const int wj = wave & 1;
-        if (DBG & 2) {
-            float t = 0.f;
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[0][a][r] + acc[1][a][r];
-            if (t == 123.456f) Y[tid] = t;
-            if (more) { load_a(0, ubase, 0); load_a(1, ubase, 0); }
-            continue;
-        }
         // item = (output channel m, pair of horizontally adjacent tiles): 96 x 16 = 1536 items, three per thread; the thread
         // ends up with a 2 x 4 output patch per item and stores it as two 16-byte rows
         float yreg[3][2][2][2];                             // [item][output row a][output column b][tile of the pair]
@@ -931,52 +578,37 @@ __global__ __launch_bounds__(64) void wino_wgrad_finish(const float* __restrict_
 // ---- internal entry points (hidden visibility): 1 = handled, 0 = not eligible, < 0 = error -----------------------------
 // dgrad = 0: y (B,Cout,H,W) = conv3x3 s1 p1 (x (B,Cin,H,W), w (Cout,Cin,3,3))
 // dgrad = 1: dx (B,Cin,H,W) = conv3x3^T (dy (B,Cout,H,W), w): the same kernel over dY with the rotated / transposed filters
-// The transformed weights (ceil(Kout/96)*96 * 16 * Kin floats) are rebuilt per call at the head of the workspace: the
-// weights change every step, the transform is one thread per (co, ci).
+// The pre-split filter planes are rebuilt per call at the head of the workspace (wino3_weight_kernel: one thread per operand
+// fragment): the generator uses every weight version once per direction, and planes built behind the optimizer step instead
+// measured 0.6 % slower in the step (round 4) -- that variant, the round-2 kernel and the lab switches are gone since round 5
+// (decided by measurement: in the step this kernel beats the direct kernels on the same layers by 1 %, its weight gradient by
+// another 1.2 %, profiles/r05_ab.txt).  Split-bf16 build only: the native-fp32 build takes the direct kernels.
 static int g_wino = -1;
-
-static int wino_run(const float* in, const float* w, const void* u3_prepared, float* out, int B, int Cin, int H, int W, int Cout,
-                    int KH, int KW, int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift,
-                    int ep_relu, void* ws, size_t ws_bytes, hipStream_t st, size_t* u3_bytes_out);
 
 int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
                    int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift, int ep_relu,
                    void* ws, size_t ws_bytes, hipStream_t st) {
-    return wino_run(in, w, nullptr, out, B, Cin, H, W, Cout, KH, KW, stride, ph, pw, up, dgrad, ep_scale, ep_shift, ep_relu, ws,
-                    ws_bytes, st, nullptr);
-}
-
-// u3_bytes_out != nullptr: plan only -- *u3_bytes_out = size of the pre-split filter planes this geometry would use (0: the
-// call would not take the round-4 kernel), nothing is launched.  u3_prepared != nullptr: the planes were built by
-// mogan_wino_prep for this weight version; the per-call weight kernel is skipped.
-static int wino_run(const float* in, const float* w, const void* u3_prepared, float* out, int B, int Cin, int H, int W, int Cout,
-                    int KH, int KW, int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift,
-                    int ep_relu, void* ws, size_t ws_bytes, hipStream_t st, size_t* u3_bytes_out) {
-    const bool plan_only = u3_bytes_out != nullptr;
-    if (plan_only) *u3_bytes_out = 0;
+#if MOGAN_X6
     if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
-    // MOGAN_WINO_FWD / MOGAN_WINO_DGRAD = 0: forward / data gradient on the direct kernels, the weight gradient stays here
-    static const int fwd_on = getenv("MOGAN_WINO_FWD") ? atoi(getenv("MOGAN_WINO_FWD")) : 1;
-    static const int dg_on = getenv("MOGAN_WINO_DGRAD") ? atoi(getenv("MOGAN_WINO_DGRAD")) : 1;
-    if (!(dgrad ? dg_on : fwd_on)) return 0;
     if (!g_wino || !(KH == 3 && KW == 3 && stride == 1 && ph == pw && (ph == 0 || ph == 1) && up == 0)) return 0;
     const int Kin = dgrad ? Cout : Cin, Kout = dgrad ? Cin : Cout;       // channels the kernel reduces over / produces
     // conv: (H, W) -> (H + 2p - 2); its data gradient runs over dY (the smaller grid) with pad 2 - p and produces (H, W)
     const int cH = H + 2 * ph - 2, cW = W + 2 * pw - 2;
     const int iH = dgrad ? cH : H, iW = dgrad ? cW : W, oH = dgrad ? H : cH, oW = dgrad ? W : cW, pad = dgrad ? 2 - ph : ph;
-    if (cH < 2 || cW < 2 || (Kin % (2 * CK)) || Kin < 32 || Kout < 64) return 0;
-    if (!plan_only && ((oW & 1) == 0) && (((uintptr_t)out) & 7) != 0) return 0;
+    if (cH < 2 || cW < 2 || (Kin % CK2) || Kin < 32 || Kout < 64) return 0;
+    if ((((uintptr_t)out) & 15) != 0) return 0;
     const int tiles_x = (oW + 2 * TCOLS - 1) / (2 * TCOLS), tiles_y = (oH + 2 * TROWS - 1) / (2 * TROWS);
     // ragged grids waste part of every 4 x 32 tile: below 70 % filling the direct kernels win
     if ((double)oW * oH < 0.7 * (double)tiles_x * 2 * TCOLS * tiles_y * 2 * TROWS) return 0;
     const long long mbs = (Kout + BM - 1) / BM;
-    const size_t ubytes = (size_t)mbs * BM * 16 * Kin * sizeof(float);
     // 32-bit byte offsets: input < 2 GiB, and the "reads as zero" sentinel (0xC0000000 bytes) plus a per-image channel
     // offset must neither land inside the buffer nor wrap
     if ((long long)B * Kin * iH * iW >= (1ll << 29) || (long long)Kin * iH * iW >= (1ll << 26) ||
-        (long long)B * Kout * oH * oW >= (1ll << 30) || ubytes >= (1ull << 31))
+        (long long)B * Kout * oH * oW >= (1ll << 30))
         return 0;
-    if (!plan_only && !u3_prepared && (!ws || ws_bytes < ubytes)) return 0;
+    // (+ one step of padding: the K loop's last iteration prefetches step nstep, whose scalar offset must stay inside the buffer)
+    const size_t u3bytes = (size_t)mbs * 8 * (Kin / CK2) * 18 * 1024 + 18 * 1024;
+    if (!ws || u3bytes > ws_bytes || u3bytes >= (1ull << 31)) return 0;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
@@ -987,48 +619,15 @@ static int wino_run(const float* in, const float* w, const void* u3_prepared, fl
     if (ntile >= (1ll << 30)) return 0;
     // persistent: one 8-wave block per CU walks the tiles
     dim3 grid((unsigned)std::min<long long>(ntile, ncu));
-#if MOGAN_X6
-    // round 4: pre-split filter planes + one 16-channel K-step per barrier (MOGAN_WINO_V=2: the round-2 kernel, A/B)
-    static const int wino_v = getenv("MOGAN_WINO_V") ? atoi(getenv("MOGAN_WINO_V")) : 3;
-    // (+ one step of padding: the K loop's last iteration prefetches step nstep, whose scalar offset must stay inside the buffer)
-    const size_t u3bytes = (size_t)mbs * 8 * (Kin / CK2) * 18 * 1024 + 18 * 1024;
-    if (plan_only) {
-        if (wino_v == 3 && u3bytes < (1ull << 31) && (((uintptr_t)out) & 15) == 0) *u3_bytes_out = u3bytes;
-        return 0;
-    }
-    if (wino_v == 3 && (u3_prepared || u3bytes <= ws_bytes) && u3bytes < (1ull << 31)) {
-        if (!u3_prepared) {
-            const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
-            hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, Cout,
-                               Cin, dgrad, nfrag);
-        }
-        const uint4* const u3 = u3_prepared ? (const uint4*)u3_prepared : (const uint4*)ws;
-        static const int dbg = getenv("MOGAN_WINO_DBG") ? atoi(getenv("MOGAN_WINO_DBG")) : 0;
-#define W3_LAUNCH(D) hipLaunchKernelGGL(wino3_fwd_kernel<D>, grid, dim3(512), 0, st, in, u3, out, Kin, iH, iW, Kout, \
-                                       oH, oW, pad, tiles_x, tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu,                 \
-                                       (unsigned)(4ull * B * Kin * iH * iW), (unsigned)u3bytes)
-        switch (dbg) {
-            case 1: W3_LAUNCH(1); break;
-            case 2: W3_LAUNCH(2); break;
-            case 3: W3_LAUNCH(3); break;
-            case 4: W3_LAUNCH(4); break;
-            case 5: W3_LAUNCH(5); break;
-            case 7: W3_LAUNCH(7); break;
-            default: W3_LAUNCH(0); break;
-        }
-#undef W3_LAUNCH
-        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
-    }
-#endif
-    if (u3_prepared) return 0;          // (prepared planes belong to the round-4 kernel only)
-    float* U = (float*)ws;
-    const long long ngroups = mbs * 8 * (Kin / CK) * 6 * 64;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, w, U, Cout, Cin, dgrad,
-                       ngroups);
-    hipLaunchKernelGGL(wino_fwd_kernel, grid, dim3(512), 0, st, in, (const float*)U, out, Kin, iH, iW, Kout, oH, oW, pad,
-                       tiles_x, tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu, (unsigned)(4ull * B * Kin * iH * iW),
-                       (unsigned)ubytes);
+    const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
+    hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, Cout, Cin, dgrad,
+                       nfrag);
+    hipLaunchKernelGGL(wino3_fwd_kernel, grid, dim3(512), 0, st, in, (const uint4*)ws, out, Kin, iH, iW, Kout, oH, oW, pad, tiles_x,
+                       tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu, (unsigned)(4ull * B * Kin * iH * iW), (unsigned)u3bytes);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+#else
+    return 0;
+#endif
 }
 
 // dw (Cout,Cin,3,3) (+)= weight gradient of conv3x3 s1 p1; workspace: nsplit * 16 * Cout * Cin floats
@@ -1066,57 +665,3 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
                        Cin, nsplit, accumulate);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 }
-
-// ---- C ABI: the filter planes of a weight version prepared ONCE (behind the optimizer step) instead of per call ------------
-extern "C" {
-
-size_t mogan_wino_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up,
-                             int dgrad) {
-#if MOGAN_X6
-    size_t n = 0;
-    // (a 16-byte aligned dummy output pointer: alignment of the real one is the allocator's)
-    wino_run(nullptr, nullptr, nullptr, (float*)16, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, dgrad, nullptr, nullptr, 0, nullptr,
-             0, nullptr, &n);
-    return n;
-#else
-    return 0;
-#endif
-}
-
-int mogan_wino_prep(const float* w, void* u3, int Cout, int Cin, int dgrad, hipStream_t stream) {
-#if MOGAN_X6
-    if (!w || !u3 || Cout <= 0 || Cin <= 0) return MOGAN_ERR_SHAPE;
-    const int Kin = dgrad ? Cout : Cin, Kout = dgrad ? Cin : Cout;
-    if (Kin % CK2) return MOGAN_ERR_SHAPE;
-    const long long mbs = (Kout + BM - 1) / BM;
-    const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
-    hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, stream, w, (uint4*)u3, Cout, Cin,
-                       dgrad, nfrag);
-    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
-#else
-    return MOGAN_ERR_SHAPE;
-#endif
-}
-
-int mogan_conv2d_fwd_wp(const float* x, const void* u3, float* y, int B, int Cin, int Hs, int Ws, int Cout, int ph, int pw,
-                        hipStream_t stream) {
-    if (!u3) return MOGAN_ERR_SHAPE;
-    const int OH = Hs + 2 * ph - 2, OW = Ws + 2 * pw - 2;
-    mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * OH * OW * Cin * 9, Cout, B * OH * OW, Cin * 9, stream);
-    const int rc = wino_run(x, nullptr, u3, y, B, Cin, Hs, Ws, Cout, 3, 3, 1, ph, pw, 0, 0, nullptr, nullptr, 0, nullptr, 0, stream,
-                            nullptr);
-    mogan_prof_end(rc == 1, stream);
-    return rc == 1 ? 0 : (rc < 0 ? rc : MOGAN_ERR_SHAPE);
-}
-
-int mogan_conv2d_dgrad_wp(const float* dy, const void* u3, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int ph, int pw,
-                          hipStream_t stream) {
-    if (!u3) return MOGAN_ERR_SHAPE;
-    mogan_prof_begin(5, 1, (4.0 / 9.0) * 2.0 * Cin * (double)B * Hs * Ws * Cout * 9, Cin, B * Hs * Ws, Cout * 9, stream);
-    const int rc = wino_run(dy, nullptr, u3, dx, B, Cin, Hs, Ws, Cout, 3, 3, 1, ph, pw, 0, 1, nullptr, nullptr, 0, nullptr, 0, stream,
-                            nullptr);
-    mogan_prof_end(rc == 1, stream);
-    return rc == 1 ? 0 : (rc < 0 ? rc : MOGAN_ERR_SHAPE);
-}
-
-}  // extern "C"

@@ -81,10 +81,6 @@ SIGNATURES = {
     "mogan_softmax_bwd": [P, P, P, P, L, I, L, F, P],
     "mogan_stn_fwd": [P, P, P, I, I, I, I, I, I, I, P],
     "mogan_stn_bwd": [P, P, P, I, I, I, I, I, I, I, P],
-    "mogan_wino_prep_bytes": [I] * 12,
-    "mogan_wino_prep": [P, P, I, I, I, P],
-    "mogan_conv2d_fwd_wp": [P, P, P, I, I, I, I, I, I, I, P],
-    "mogan_conv2d_dgrad_wp": [P, P, P, I, I, I, I, I, I, I, P],
     "mogan_stn_fwd_ex": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "mogan_stn_bwd_ex": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "mogan_concat_fwd": [P, P, P, P, P, P, I, P, I, I, P],
@@ -154,7 +150,7 @@ class TailArgs(ctypes.Structure):               # MoganTailArgs
                 ("panel", P), ("CGp", I), ("cg0", I), ("B", I), ("n", I), ("H", I), ("W", I)]
 
 
-_RESTYPE = {"mogan_wino_prep_bytes": Z, "mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z}
+_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
 _lib = None
@@ -235,23 +231,15 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _reserved = []
 
 
-def in_process_group():
-    """this process is (going to be) a member of a torch.distributed group: launched by torch.distributed.run / bench.py --gpus N
-    (WORLD_SIZE > 1) or forced into a 1-rank group by the test knob"""
-    return int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("MOGAN_FORCE_DIST", "0") not in ("", "0")
-
-
 def hw_queue_defaults():
-    """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step for this process (see above).
-    Round 4 (the engines of a process share one stream table, the frozen encoder's graph has fewer nodes; tools/queue_table.sh
-    + a scan of 0..10 idle streams, two interleaved repeats on one box, img/s): one process without a group (4,0) 429.8 / 428.3,
-    (4,1) 395, (4,2) 410 / 408, (4,3) 393 / 397, (4,4) 424 / 426, (4,5) 425 / 426, (4,6..10) 416-418 on a second box; member of a
-    1-rank RCCL group (4,0) 394 / 395, (4,1) 419 / 408, (4,2) 421.0 / 420.5, (4,3) 422.2 / 420.2, (4,4) 420.7 / 419.2, (4,5) 420 --
-    a single process runs without idle streams again, a group member on the middle of its plateau (3).  torch's
-    ProcessGroupNCCL adds ONE stream per device whatever the world size; what a real multi-GPU world changes is how long that
-    stream's kernels run, not how many streams exist.  MOGAN_HW_QUEUES / MOGAN_RESERVED_STREAMS (or GPU_MAX_HW_QUEUES itself)
-    override it for a node where this turns out wrong."""
-    return (os.environ.get("MOGAN_HW_QUEUES", "4"), 3 if in_process_group() else 0)
+    """(GPU_MAX_HW_QUEUES, idle streams reserved first) of the eager multi-stream step: (4, 0) for every kind of process since
+    round 5.  Rounds 1-4 bound the step's streams to hardware queues lazily (at their first use inside the step), so the layout
+    depended on what else had created streams before -- RCCL's communicator in particular -- and the best setting differed by
+    process kind (round 4: (4, 0) single process, (4, 3) member of a process group; +-8 %).  Now every entry point creates and
+    touches the engine's streams in ONE fixed order right after torch.cuda.set_device, before torch.distributed exists
+    (attngan/trainer.create_engine_streams, ENGINE_STREAM_ORDER): 437 img/s single process, 435 as member of a 1-rank RCCL group
+    (profiles/r05_queue_table.csv).  MOGAN_HW_QUEUES / MOGAN_RESERVED_STREAMS (or GPU_MAX_HW_QUEUES itself) still override."""
+    return (os.environ.get("MOGAN_HW_QUEUES", "4"), 0)
 
 
 def configure_hw_queues():

@@ -285,11 +285,8 @@ class WeightPacks:
     def _pack(self, dgrad, slot):
         Cout, Cin, KH, KW = self.w.shape
         st = stream_ptr()
-        if isinstance(dgrad, tuple):                      # ("wino", dgrad): the Winograd kernel's pre-split filter planes
-            call("mogan_wino_prep", ptr(self.w), slot[0].data_ptr(), Cout, Cin, dgrad[1], st)
-        else:
-            stride, ph, pw = slot[3]
-            call("mogan_pk_weight_pack", ptr(self.w), slot[0].data_ptr(), Cout, Cin, KH, KW, stride, ph, pw, dgrad, st)
+        stride, ph, pw = slot[3]
+        call("mogan_pk_weight_pack", ptr(self.w), slot[0].data_ptr(), Cout, Cin, KH, KW, stride, ph, pw, dgrad, st)
         slot[1], slot[2] = self.cell[0], _PK_GLOBAL[0]
         ev = torch.cuda.Event()
         ev.record()
@@ -311,9 +308,6 @@ class WeightPacks:
             for slot in (s0, s1):
                 slot[1], slot[2], slot[4], slot[5], slot[6] = self.cell[0], _PK_GLOBAL[0], ev, st, cap
             PK_STATS["packs"] += 1
-            for key, slot in self.slots.items():
-                if isinstance(key, tuple):
-                    self._pack(key, slot)
             return
         for dgrad, slot in self.slots.items():
             self._pack(dgrad, slot)
@@ -327,23 +321,6 @@ class WeightPacks:
             # outside its capture -- and need not: the device is synchronised before a capture begins)
             torch.cuda.current_stream().wait_event(slot[4])
         return slot[0].data_ptr()
-
-    def pointer_wino(self, dgrad, B, Hs, Ws, ph, pw):
-        """device pointer of the Winograd filter planes of this weight for a 3x3 stride-1 call of this geometry (built once
-        per weight version, csrc/mogan_wino.hip), or None: the call takes mogan_conv2d_fwd / _dgrad"""
-        Cout, Cin, KH, KW = self.w.shape
-        gk = ("wino", dgrad, B, Hs, Ws, ph, pw)
-        nbytes = self.elig.get(gk)
-        if nbytes is None:
-            nbytes = self.elig[gk] = int(lib.load().mogan_wino_prep_bytes(B, Cin, Hs, Ws, Cout, KH, KW, 1, ph, pw, 0, dgrad))
-        if not nbytes:
-            return None
-        key = ("wino", dgrad)
-        slot = self.slots.get(key)
-        if slot is None:
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.w.device)
-            slot = self.slots[key] = [buf, -1, -1, None, None, None, False]
-        return self._fresh(key, slot)
 
     def pointer(self, dgrad, B, Hs, Ws, stride, ph, pw):
         """device pointer of the packed copy for this call's geometry, or None: take the unpacked kernels"""
@@ -385,30 +362,9 @@ def _packed(w, dgrad, B, Hs, Ws, stride, ph, pw, up):
     return pk.pointer(dgrad, B, Hs, Ws, stride, ph, pw)
 
 
-WINO_PREP = os.environ.get("MOGAN_WINO_PREP", "0") != "0"     # 1: the Winograd filter planes built once per weight version behind
-# the optimizer step instead of per call.  Measured in the step (same box, two interleaved pairs): 402.4 / 401.8 img/s with the
-# planes prepared behind Adam vs 404.6 / 404.9 rebuilt per call -- the per-call transform leaves the planes hot in L2 right in
-# front of their only consumer, and the generator uses every weight version exactly once per direction; off by default
-
-
-def _wino_planes(w, dgrad, B, Hs, Ws, stride, ph, pw, up):
-    if up or stride != 1 or not WINO_PREP or w.shape[2] != 3 or w.shape[3] != 3:
-        return None
-    pk = getattr(w, "_mogan_pk", None)
-    if pk is None:
-        return None
-    return pk.pointer_wino(dgrad, B, Hs, Ws, ph, pw)
-
-
 def conv2d_forward(x, w, stride, ph, pw, up):
     B, Cin, Hs, Ws = x.shape
     Cout, _, KH, KW = w.shape
-    u3 = _wino_planes(w, 0, B, Hs, Ws, stride, ph, pw, up)
-    if u3 is not None:
-        y = torch.empty((B, Cout, Hs + 2 * ph - 2, Ws + 2 * pw - 2), dtype=torch.float32, device=x.device)
-        call("mogan_conv2d_fwd_wp", ptr(x), u3, ptr(y), B, Cin, Hs, Ws, Cout, ph, pw, stream_ptr())
-        PK_STATS["wino"] = PK_STATS.get("wino", 0) + 1
-        return y
     wp = _packed(w, 0, B, Hs, Ws, stride, ph, pw, up)
     if wp is not None:
         OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, 0)
@@ -433,12 +389,6 @@ def conv2d_forward(x, w, stride, ph, pw, up):
 def conv2d_dgrad(dy, w, x_shape, stride, ph, pw, up):
     B, Cin, Hs, Ws = x_shape
     Cout, _, KH, KW = w.shape
-    u3 = _wino_planes(w, 1, B, Hs, Ws, stride, ph, pw, up)
-    if u3 is not None:
-        dx = torch.empty((B, Cin, Hs, Ws), dtype=torch.float32, device=dy.device)
-        call("mogan_conv2d_dgrad_wp", ptr(dy), u3, ptr(dx), B, Cin, Hs, Ws, Cout, ph, pw, stream_ptr())
-        PK_STATS["wino"] = PK_STATS.get("wino", 0) + 1
-        return dx
     wsp, wsn = workspace(dy.device)
     wp = _packed(w, 1, B, Hs, Ws, stride, ph, pw, up)
     if wp is not None:

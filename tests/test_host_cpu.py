@@ -202,9 +202,9 @@ def test_workspace_is_separate_for_captured_launches(monkeypatch):
 
 
 def test_hw_queue_configuration_respects_the_user(monkeypatch):
-    """hip/lib.py:configure_hw_queues -- GPU_MAX_HW_QUEUES is only defaulted (4 queues; no idle streams first in a single
-    process, 3 in a member of a process group), never overridden; reserve_hw_queues(0) and MOGAN_RESERVED_STREAMS=0 do not
-    touch the library."""
+    """hip/lib.py:configure_hw_queues -- GPU_MAX_HW_QUEUES is only defaulted (4 queues, no idle streams first: ONE default for a
+    single process and for a member of a process group since round 5, the engine's streams being created in a fixed order before
+    the group exists), never overridden; reserve_hw_queues(0) and MOGAN_RESERVED_STREAMS=0 do not touch the library."""
     from mogan_amd.hip import lib
     for k in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE", "MOGAN_FORCE_DIST", "MOGAN_RESERVED_STREAMS"):
         monkeypatch.delenv(k, raising=False)
@@ -213,12 +213,12 @@ def test_hw_queue_configuration_respects_the_user(monkeypatch):
     assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
     monkeypatch.setenv("WORLD_SIZE", "8")
-    assert lib.hw_queue_defaults() == ("4", 3)
+    assert lib.hw_queue_defaults() == ("4", 0)
     lib.configure_hw_queues()
     assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("MOGAN_FORCE_DIST", "1")
-    assert lib.hw_queue_defaults() == ("4", 3)
+    assert lib.hw_queue_defaults() == ("4", 0)
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "5")
     lib.configure_hw_queues()
     assert os.environ["GPU_MAX_HW_QUEUES"] == "5"

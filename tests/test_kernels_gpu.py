@@ -84,6 +84,15 @@ CONV_CASES = [
     (2, 256, 16, 16, 64, (3, 3), 1, (1, 1), 0),    # split over channel chunks
     (2, 64, 64, 64, 72, (4, 4), 2, (1, 1), 0),     # 4x4 s2 -> 32x32; dgrad = four 2x2 parity convs in one launch
     (2, 64, 32, 32, 256, (4, 4), 2, (1, 1), 0),    # 4x4 s2 -> 16x16; parity dgrad with channel split
+    # round 5: the pre-split direct kernel (csrc/mogan_dconv2.hip; 3x3 s1 and the 2x2 parity classes of a 4x4 s2 data gradient on
+    # grids of 8 x 32 tiles, channels % 16 == 0); 3x3 reaches it where Winograd declines or with force (-2, 0)
+    (2, 96, 32, 64, 160, (3, 3), 1, (1, 1), 0),    # 96-row channel blocks, ragged M = 160 (guarded stores), dgrad: 160 -> 96
+    (1, 32, 8, 32, 64, (3, 3), 1, (1, 1), 0),      # one tile, 64-row block; dgrad declined (32 output channels)
+    (1, 16, 8, 32, 128, (3, 3), 1, (1, 1), 0),     # 128-row block, one 16-channel stage
+    (1, 256, 8, 32, 64, (3, 3), 1, (1, 1), 0),     # one tile, 16 stages: K split over the stages + reduce
+    (3, 48, 16, 32, 80, (3, 3), 1, (1, 1), 0),     # several tiles per persistent block across images
+    (2, 96, 32, 64, 64, (4, 4), 2, (1, 1), 0),     # data gradient: four 2x2 parity classes, two 16-channel sub-chunks per stage
+    (2, 128, 16, 64, 16, (4, 4), 2, (1, 1), 0),    # data gradient with 16 input channels of dY (one stage), 128-row blocks
 ]
 
 
@@ -95,10 +104,11 @@ def _conv_ref(x, w, stride, pad, up):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("force", [(-1, 0), (0, 3), (1, 1), (2, 2), (3, 1), (4, 5), (5, 2), (6, 3)])
+@pytest.mark.parametrize("force", [(-1, 0), (-2, 0), (0, 3), (1, 1), (2, 2), (3, 1), (4, 5), (5, 2), (6, 3)])
 def test_conv2d_fwd_dgrad_wgrad(case, force):
     B, Cin, H, W, Cout, k, s, pad, up = case
-    # (-1, 0): default dispatch (small-channel / Winograd F(2,3) / direct / implicit GEMM by shape); the others force an
+    # (-1, 0): default dispatch (small-channel / Winograd F(2,3) / direct / implicit GEMM by shape); (-2, 0): the same without the
+    # Winograd kernels (3x3 shapes on the direct kernels, forward / data gradient / weight gradient); the others force an
     # implicit-GEMM tile config and split
     lib.load().mogan_gemm_debug_force(force[0], force[1])
     try:
@@ -380,38 +390,6 @@ def test_logits_head_and_conv_lrelu(B, Cin, Cout):
     z = ops.conv2d_lrelu(xid, wid, 2, 1, 0.2)
     z.backward(g.to(DEV))
     _check(z, ref, 2e-6, "conv+lrelu"); _check(xid.grad, xi.grad, 5e-6, "conv+lrelu dx"); _check(wid.grad, wi.grad, 5e-6, "conv+lrelu dw")
-
-
-def test_winograd_prepared_filter_planes_follow_the_weight_version(monkeypatch):
-    """mogan_wino_prep / mogan_conv2d_fwd_wp / _dgrad_wp: the pre-split filter planes of a ResBlock convolution (model.py:67-81)
-    built once per weight version by the weight's owner instead of per call -- same results as the per-call path, bit for
-    bit (the same kernel on the same planes), rebuilt when the owner bumps the version, and not used for geometries the
-    Winograd kernel does not take.  (Off by default, MOGAN_WINO_PREP: measured slightly slower in the step, hip/ops.py.)"""
-    monkeypatch.setattr(ops, "WINO_PREP", True)
-    B, Cin, H, W, Cout = 2, 96, 32, 64, 192
-    x, dy = T("wp.x", (B, Cin, H, W)).to(DEV), T("wp.dy", (B, Cout, H, W)).to(DEV)
-    w = (T("wp.w", (Cout, Cin, 3, 3)) * 0.1).to(DEV)
-    y0, dx0 = ops.conv2d_forward(x, w, 1, 1, 1, 0), ops.conv2d_dgrad(dy, w, x.shape, 1, 1, 1, 0)
-    cell = [0]
-    w2 = w.clone()
-    pk = ops.attach_packs(w2, cell)
-    n0 = ops.PK_STATS.get("wino", 0)
-    y1, dx1 = ops.conv2d_forward(x, w2, 1, 1, 1, 0), ops.conv2d_dgrad(dy, w2, x.shape, 1, 1, 1, 0)
-    assert ops.PK_STATS.get("wino", 0) == n0 + 2 and sorted(k for k in pk.slots if isinstance(k, tuple)) == [("wino", 0), ("wino", 1)]
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
-    _check(y1, F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1), 2e-6, "prepared fwd")
-    # the owner changes the weight: stale planes until the version moves, fresh ones after
-    w2.mul_(2.0)
-    assert torch.equal(ops.conv2d_forward(x, w2, 1, 1, 1, 0), y1)
-    cell[0] += 1
-    pk.repack()
-    _check(ops.conv2d_forward(x, w2, 1, 1, 1, 0), 2.0 * y1.double().cpu(), 2e-6, "after repack")
-    # a stride-2 / tiny-map use of a 3x3 weight does not go through the planes
-    n1 = ops.PK_STATS.get("wino", 0)
-    xs = T("wp.xs", (B, Cin, 4, 4)).to(DEV)
-    _check(ops.conv2d_forward(xs, w2, 1, 1, 1, 0), F.conv2d(xs.double().cpu(), w2.double().cpu(), None, 1, 1), 2e-6, "4x4 map")
-    assert ops.PK_STATS.get("wino", 0) == n1
-
 
 
 def test_stn_shared_source_gradient_is_order_independent_to_rounding():

@@ -404,3 +404,4 @@ int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, in
     return 0;
 #endif
 }
+

@@ -18,17 +18,17 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("gemm_kernel", "pgemm_kernel", "pgemm_group_kernel", "dconv_fwd_kernel", "dconv_wgrad_kernel", "wino3_fwd_kernel",
-        "wino_wgrad_kernel")
+KEEP = ("gemm_kernel", "pgemm_kernel", "pgemm_group_kernel", "dconv_fwd_kernel", "dconv2_fwd_kernel", "dconv_wgrad_kernel",
+        "wino3_fwd_kernel", "wino_wgrad_kernel")
 
 
 def short(name):
     if "pgemm_group_kernel" not in name:
         name = name.replace("gemm_group_kernel", "gemm_kernel")      # grouped launches of the same tile kernel
-    m = re.search(r"(pgemm_group_kernel|pgemm_kernel|gemm_kernel|dconv_fwd_kernel|dconv_wgrad_kernel|wino3_fwd_kernel)<([^>]*)>", name)
+    m = re.search(r"(pgemm_group_kernel|pgemm_kernel|gemm_kernel|dconv2_fwd_kernel|dconv_fwd_kernel|dconv_wgrad_kernel|wino3_fwd_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
-    for k in ("wino_fwd_kernel", "wino_wgrad_kernel"):
+    for k in ("wino3_fwd_kernel", "wino_wgrad_kernel"):
         if k in name:
             return k + "<>"
     return None

@@ -412,12 +412,15 @@ def _engine_stream(key):
 
 
 # first-use order of the step's streams (tokens: s<i> = branch stream of D_i / s3 = the Inception-DAMSM branch, w<i> / wm = the
-# weight-gradient streams of the branches / of the main stream, cG / cD = communication streams, x = an unused stream).
+# weight-gradient streams of the branches / of the main stream, gc = the generator graph's capture stream, cG / cD = communication
+# streams, x = an unused stream).
 # Measured (profiles/r05_queue_table.csv; 4 hardware queues, no reserved streams, img/s single process / member of a 1-rank
 # RCCL group): this order 437 / 435 (two repeats each), "s2,s3,wm,s1,s0" 438 / 435, "s0,s1,s2,s3,w2,w1,w0,wm" 411 / 409,
 # "s2,s1,s0,s3,w2,w1,w0,wm" 399 / 398, "s3,s2,s1,x,s0,wm" 407; streams bound lazily at their first use in the step (rounds 1-4):
-# 432-434 / 401.  The layout is a function of this order alone, and the two kinds of process agree to 1 %.
-ENGINE_STREAM_ORDER = "s2,s3,s1,wm,s0,w2,w1,w0,cG,cD"
+# 432-434 / 401.  The layout is a function of this order alone, and the two kinds of process agree to 1 %.  gc = the stream the
+# generator's eager backward runs on when its forward is a replayed graph (MOGAN_G_GRAPHS=2): behind s0 447.9 img/s (eager
+# generator on that box: 441.1), in front of everything 443.7, between wm and s0 422.6, behind s2 414.1.
+ENGINE_STREAM_ORDER = "s2,s3,s1,wm,s0,gc,w2,w1,w0,cG,cD"
 _KEEP_STREAMS = []
 _STREAMS_CREATED = set()
 
@@ -439,6 +442,7 @@ def create_engine_streams(n_discriminators=3, touch=True):
     table["wm"] = lambda: ops.precreate_wgrad_stream(torch.cuda.current_stream())
     table["cG"] = lambda: _engine_stream(("comm", "G"))
     table["cD"] = lambda: _engine_stream(("comm", "D256"))
+    table["gc"] = lambda: _engine_stream(("gcap",))      # capture stream of the generator's forward graph = the stream its eager backward runs on
     table["x"] = lambda: torch.cuda.Stream()              # a stream nobody uses: takes a slot of the round-robin
     order = os.environ.get("MOGAN_STREAM_ORDER") or ENGINE_STREAM_ORDER
     made = [table[k]() for k in order.split(",") if k in table]
@@ -491,13 +495,17 @@ class TrainEngine:
         if self.distributed and os.environ.get("MOGAN_BRANCH_GRAPHS_DP", "1") == "0":
             branch_graphs = False
         self.branch_graphs = bool(branch_graphs) and self.multi_stream and not use_graph
-        # Optional (MOGAN_G_GRAPHS=1, single process only): the generator too -- forward / backward + Adam + EMA as two hipGraphs
-        # of one pool on the main stream, one pair per shape of the text tensors (the padded caption length of a batch), at most
-        # MOGAN_G_GRAPH_VARIANTS (4) pairs.  Host enqueue 34.5 -> 10.0 ms per step, the forward chain 6.3 -> 5.65 ms -- and the
-        # backward 10.2 -> 12.6 ms, because its weight gradients then run in line instead of on the side stream (372-373 vs 387.5
-        # img/s; with the fork captured, MOGAN_G_WGRAD_FORK=1: 380.6-382.2; B = 4: 204 vs 213, B = 8: 290 vs 298): off by default,
-        # there for hosts whose python is slower than the GPU's 40 ms step.
-        self.g_graphs = self.branch_graphs and not self.distributed and os.environ.get("MOGAN_G_GRAPHS", "0") != "0"
+        # The generator: MOGAN_G_GRAPHS = 2 (default since round 5) replays its FORWARD as a hipGraph (one per shape of the text
+        # tensors, at most MOGAN_G_GRAPH_VARIANTS = 4; other shapes run eagerly) and keeps the backward eager -- on the autograd
+        # tape recorded during the capture (retain_graph; the static inputs are refreshed through .data so that the tape's saved
+        # tensors keep their version), so the weight gradients still overlap the data-gradient chain on their side stream and the
+        # data-parallel reducers still see every gradient as it is queued.  Host enqueue per step 29.8 -> 20.8 ms at B = 16 (12.7 ->
+        # 8.0 at B = 4, 55.6 -> 37.0 at B = 32), throughput +0.5 % at B = 16 / 32, equal at B = 4 / 8 (profiles/r05_ab.txt).
+        # 1 (round 3, single process only): forward AND backward + Adam + EMA as two hipGraphs -- host enqueue 17.6 ms, but the
+        # weight gradients then run in line: 407.7 vs 426.0 img/s (421.1 with the fork captured, MOGAN_G_WGRAD_FORK=1).  0: eager.
+        gmode = os.environ.get("MOGAN_G_GRAPHS", "2")
+        self.g_fwd_only = gmode == "2"
+        self.g_graphs = self.branch_graphs and gmode != "0" and (self.g_fwd_only or not self.distributed)
         self._bg = None
         if torch.cuda.is_available() and self.multi_stream and not use_graph:
             create_engine_streams(len(netsD))       # (a no-op when the entry point has done it before the process group came up)
@@ -967,7 +975,12 @@ class TrainEngine:
         gs["damsm_grad"] = torch.zeros_like(st["fake"][nD - 1])
         gs["w_loss"], gs["s_loss"] = torch.zeros((), device=dev), torch.zeros((), device=dev)
         if getattr(self, "_g_cap_stream", None) is None:
-            self._g_cap_stream = torch.cuda.Stream()          # capture only: the graphs replay on the main stream
+            # the capture stream: one per process (not a fresh pool stream per engine: torch's pool has 32 and cycles).  With the
+            # forward-only graph the eager backward's nodes RUN on this stream (autograd executes a node where its forward was
+            # recorded): its weight gradients use the main stream's weight-gradient side stream, as an eager generator's do
+            self._g_cap_stream = _engine_stream(("gcap",))
+            main_w = ops.precreate_wgrad_stream(torch.cuda.current_stream())
+            ops._wgrad_streams.setdefault(self._g_cap_stream.cuda_stream, main_w)
         counter, cap = self.bn_counter, self._g_cap_stream
         if os.environ.get("MOGAN_G_WGRAD_FORK", "0") != "0":      # experiment: fork the weight gradients inside the backward graph
             ops.CAPTURE_WGRAD_OK.add(cap.cuda_stream)
@@ -983,6 +996,12 @@ class TrainEngine:
             with torch.cuda.graph(gF, pool=pool, stream=cap):
                 fake_imgs, _, mu, logvar = self.netG(gs["z"], st["sent_emb"], gs["words_embs"], gs["mask"], gs["tmi"],
                                                      gs["label_one_hot"], gs["eps"])
+            if self.g_fwd_only:
+                calls = [a - c for a, c in zip(counter.calls, calls0)]
+                counter.calls = calls0
+                torch.cuda.synchronize()
+                return {"gF": gF, "gB": None, "gs": gs, "fake": [t.detach() for t in fake_imgs], "live": (list(fake_imgs), mu, logvar),
+                        "calls": calls}
             with torch.cuda.graph(gB, pool=pool, stream=cap):
                 self.optG.zero_grad()
                 parts = {"g_loss%d" % i: bg["out"][i][1] for i in range(nD)}
@@ -1066,18 +1085,23 @@ class TrainEngine:
         self._phase("text+Gfwd")
         if "words_embs" not in b:
             b["words_embs"], b["sent_emb"], b["mask"] = self._text_for(b)
-        st["sent_emb"].copy_(b["sent_emb"])                # (main stream; the branches wait for it below)
+        # (.data: the copy must not move the version counter of a tensor the forward-only generator graph's autograd tape has saved)
+        st["sent_emb"].data.copy_(b["sent_emb"])           # (main stream; the branches wait for it below)
         gg = self._g_graph_for(b)
         if gg is not None:
             gs = gg["gs"]
             for k in ("z", "words_embs", "mask", "tmi", "label_one_hot"):
-                gs[k].copy_(b[k])
+                gs[k].data.copy_(b[k])
             if b.get("eps") is not None:
-                gs["eps"].copy_(b["eps"])
+                gs["eps"].data.copy_(b["eps"])
             else:
-                gs["eps"].normal_()                         # model.py:333-338: drawn per forward
+                gs["eps"].data.normal_()                    # model.py:333-338: drawn per forward
             gg["gF"].replay()
             fake_imgs, mu, logvar = gg["fake"], None, None
+            if gg["gB"] is None:                          # forward-only graph: the live outputs carry the captured autograd graph
+                fake_imgs, mu, logvar = gg["live"]
+                for j, n in enumerate(gg["calls"]):
+                    self.bn_counter.calls[j] += n
         else:
             fake_imgs, _, mu, logvar = netG(b["z"], b["sent_emb"], b["words_embs"], b["mask"], b["tmi"], b["label_one_hot"], b.get("eps"))
         out, parts = {}, {}
@@ -1125,7 +1149,7 @@ class TrainEngine:
             errD, g_loss, _ = bg["out"][i]
             out["errD%d" % i] = errD.clone()
             parts["g_loss%d" % i] = g_loss.clone()
-        if gg is not None:
+        if gg is not None and gg["gB"] is not None:
             gs = gg["gs"]
             gs["damsm_grad"].copy_(damsm_grad)
             gs["w_loss"].copy_(parts["w_loss"])
@@ -1146,11 +1170,17 @@ class TrainEngine:
         grads = [bg["out"][i][2] for i in range(nD)]
         grads[nD - 1] = ops.add(grads[nD - 1], damsm_grad)       # d errG / d img256 = D256 path + DAMSM path
         with ops.wgrad_overlap():
-            torch.autograd.backward(list(fake_imgs) + [kl_loss], grads + [None])
+            torch.autograd.backward(list(fake_imgs) + [kl_loss], grads + [None], retain_graph=gg is not None)
+            if gg is not None:
+                # the tape of a replayed forward was recorded on the capture stream and autograd runs its nodes THERE; the gradient
+                # kernels write the parameters' .grad buffers directly (no AccumulateGrad node, hence no end-of-backward stream
+                # synchronisation by the engine): the main stream -- Adam -- has to wait for that stream itself
+                cur.wait_stream(self._g_cap_stream)
         self._phase("G adam")
         self._opt_step(self.optG, self._allreduce_async(self.optG))
         self.bn_counter.flush()
-        out.update(errG=errG_total.detach(), kl=kl_loss.detach(), fake64=fake_imgs[0].detach(), fake_last=fake_imgs[-1].detach())
+        keep = (lambda t: t.detach().clone()) if gg is not None else (lambda t: t.detach())     # (a replayed forward rewrites its outputs)
+        out.update(errG=errG_total.detach(), kl=keep(kl_loss), fake64=keep(fake_imgs[0]), fake_last=keep(fake_imgs[-1]))
         out.update({k: v.detach() for k, v in parts.items()})
         self._phase("end")
         return out

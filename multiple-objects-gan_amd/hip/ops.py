@@ -89,6 +89,7 @@ WGRAD_SIDE_STREAM = False
 CAPTURE_WGRAD_OK = set()     # raw handles of streams that may fork a wgrad stream while being captured (depth-1 forks only)
 _WGRAD_ENV = os.environ.get("MOGAN_WGRAD_STREAM", "1") != "0"
 _wgrad_streams = {}
+_wgrad_used = []         # side streams that received launches since the last join (see join_wgrad)
 _wgrad_keep = []         # operands of in-flight side-stream launches; released after the join so the caching
                          # allocator cannot hand their memory to a main-stream kernel that runs concurrently
 
@@ -114,6 +115,8 @@ def _wgrad_launch(dy, x, w_shape, geom, g):
         side.wait_stream(cur)                     # dy (and the zeroed / partly accumulated grad) are ready
         with torch.cuda.stream(side):
             conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=g, accumulate=True)
+        if side not in _wgrad_used:
+            _wgrad_used.append(side)
         _wgrad_keep.append((dy, x))               # freed only after the join (see join_wgrad)
         _grad_hit(g, side)
     else:
@@ -222,12 +225,22 @@ def precreate_wgrad_stream(stream):
 
 
 def join_wgrad():
+    """The current stream waits for the weight-gradient launches of the backward pass that just ended: for its own paired side
+    stream AND for every side stream that received launches since the last join.  The second part matters when autograd ran the
+    backward on ANOTHER stream than the caller's -- the nodes of a tape recorded on a capture stream (the generator's replayed
+    forward, trainer.TrainEngine g_fwd_only) execute on that stream, so their weight gradients went to ITS side stream; joining
+    only the caller's pair would let the optimizer read gradients that are still being written."""
     if not _wgrad_streams:
         return
     cur = torch.cuda.current_stream()
     side = _wgrad_streams.get(cur.cuda_stream)
     if side is not None:
         cur.wait_stream(side)
+    capturing = torch.cuda.is_current_stream_capturing()
+    for s_ in _wgrad_used:
+        if s_ is not side and not capturing:
+            cur.wait_stream(s_)
+    del _wgrad_used[:]
     del _wgrad_keep[:]
 
 

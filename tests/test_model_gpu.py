@@ -348,12 +348,14 @@ def test_g_net_eval_mode():
     assert all(int(v) == 0 for k, v in G.state_dict().items() if k.endswith("num_batches_tracked"))
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs", "branch_graphs_and_g", "branch_graphs_inputs_ready"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "branch_graphs", "branch_graphs_and_g", "branch_graphs_and_g_fwd",
+                                  "branch_graphs_inputs_ready"])
 def test_two_train_steps(mode):
     """the op order of the step (fake images generated once, each D updated
     before generator_loss forwards through it), Adam, EMA, BN running statistics -- eager, as one
-    replayed hipGraph, with the discriminator branches as hipGraphs beside an eager generator (the default), with the
-    generator (forward / backward + Adam) replayed as hipGraphs as well (MOGAN_G_GRAPHS=1), and -- branch_graphs_inputs_ready --
+    replayed hipGraph, with the discriminator branches as hipGraphs beside an eager generator, with the generator's forward
+    replayed as well and its backward eager on the captured tape (branch_graphs_and_g_fwd: the default, MOGAN_G_GRAPHS=2), with
+    forward / backward + Adam both replayed (MOGAN_G_GRAPHS=1), and -- branch_graphs_inputs_ready --
     the way bench.py and condGANTrainer.train() drive the engine: every batch carries an `inputs_ready` event, so D_i(real) of
     step 1 is replayed on its branch stream while the main stream is still in step 0's generator backward (no host
     synchronisation between the two steps; the branch results the main stream reads live outside the graphs' pool)."""
@@ -361,8 +363,9 @@ def test_two_train_steps(mode):
     g = golden("step")
     G, Ds, enc = _build_all()
     eng = TrainEngine(None, enc, G, Ds, use_graph=mode == "graph", branch_graphs=mode.startswith("branch_graphs"))
-    assert eng.branch_graphs == mode.startswith("branch_graphs") and not eng.g_graphs
-    eng.g_graphs = mode == "branch_graphs_and_g"
+    assert eng.branch_graphs == mode.startswith("branch_graphs")
+    eng.g_graphs = mode in ("branch_graphs_and_g", "branch_graphs_and_g_fwd")
+    eng.g_fwd_only = mode == "branch_graphs_and_g_fwd"      # only the generator's forward replayed, its backward eager on the captured tape
     early = mode == "branch_graphs_inputs_ready"
     nets = [("G", G)] + [("D%d" % i, D) for i, D in enumerate(Ds)]
     init = {n: {k: probe(v) for k, v in net.state_dict().items()} for n, net in nets}

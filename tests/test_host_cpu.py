@@ -286,3 +286,16 @@ def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
     monkeypatch.setenv("RANK", "0")
     ns["_self_launch"]()
     assert got == []
+
+
+def test_engine_stream_order_is_a_fixed_list_of_known_streams():
+    """trainer.ENGINE_STREAM_ORDER (the order in which every entry point creates and first uses the engine's streams, which alone
+    decides the stream -> hardware-queue layout): every token names a stream of the engine, the
+    streams the step actually runs on are all in it exactly once, and the D_NET256 branch comes first."""
+    from mogan_amd.attngan import trainer
+    toks = trainer.ENGINE_STREAM_ORDER.split(",")
+    known = {"s0", "s1", "s2", "s3", "w0", "w1", "w2", "wm", "gc", "cG", "cD", "x"}
+    assert all(t in known for t in toks), toks
+    for t in ("s0", "s1", "s2", "s3", "wm", "gc"):
+        assert toks.count(t) == 1, t
+    assert toks[0] == "s2"

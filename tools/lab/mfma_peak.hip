@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_lds(float* out, int iters) {
 
 // the same with addresses the compiler cannot prove loop-invariant (offset advanced by a runtime step): the reads stay in the
 // loop; PIPE = 1: fragments of group g+1 are requested before the MFMAs of group g (register double buffering)
-template <int WAVES, int PIPE, int NB32>
+template <int WAVES, int PIPE, int NB32, int ORDER = 9>
 __global__ __launch_bounds__(64 * WAVES) void k_lds2(float* out, int iters, int step, int rnd) {
     __shared__ __attribute__((aligned(16))) unsigned char L[96 * 496 + 8192];
     for (int i = threadIdx.x; i < (96 * 496 + 8192) / 4; i += blockDim.x) {
@@ -96,7 +96,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_lds2(float* out, int iters, int 
 #pragma unroll
         for (int term = 0; term < 6; ++term)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][t][term % 3], fb[buf][term / 2], acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) {
+                // piece indices (A, B) of the six partial products: ORDER 0 = mogan_mma.h today (3,1)(2,2)(1,3)(2,1)(1,2)(1,1);
+                // 1 = A piece kept as long as possible (3,1)(2,2)(2,1)(1,3)(1,2)(1,1); 2 = B piece kept (1,3)(2,2)(1,2)(3,1)(2,1)(1,1)
+                constexpr int IA0[6] = {2, 1, 0, 1, 0, 0}, IB0[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int IA1[6] = {2, 1, 1, 0, 0, 0}, IB1[6] = {0, 1, 0, 2, 1, 0};
+                constexpr int IA2[6] = {0, 1, 0, 2, 1, 0}, IB2[6] = {2, 1, 1, 0, 0, 0};
+                const int ia = ORDER == 0 ? IA0[term] : ORDER == 1 ? IA1[term] : ORDER == 2 ? IA2[term] : term % 3;
+                const int ib = ORDER == 0 ? IB0[term] : ORDER == 1 ? IB1[term] : ORDER == 2 ? IB2[term] : term / 2;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][t][ia], fb[buf][ib], acc[t], 0, 0, 0);
+            }
     };
     if (PIPE) load(0, 0);
     for (int i = 0; i < iters; ++i) {
@@ -155,5 +164,10 @@ int main() {
     }
     for (int rep = 0; rep < 2; ++rep)
         run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0>), dim3(2048), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 2048, "RANDOM data, long run (2048 blocks x 4x iterations)");
+    // order of the six partial products (random data; term-major over the three accumulator tiles as in the kernels)
+    run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0, 0>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 1024, "RANDOM, x6 order of mogan_mma.h");
+    run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0, 1>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 1024, "RANDOM, A piece kept across products");
+    run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0, 2>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 1024, "RANDOM, B piece kept across products");
+    run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0, 0>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 1024, "RANDOM, x6 order of mogan_mma.h (again)");
     return 0;
 }

@@ -121,6 +121,46 @@ __global__ __launch_bounds__(64 * WAVES) void k_lds2(float* out, int iters, int 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// int8 pipe: v_mfma_i32_32x32x32_i8 (a lane supplies 16 int8 per operand, K = 32 per instruction) with operands from LDS as in k_lds2
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_i8(float* out, int iters, int step, int rnd) {
+    __shared__ __attribute__((aligned(16))) unsigned char L[96 * 496 + 8192];
+    for (int i = threadIdx.x; i < (96 * 496 + 8192) / 4; i += blockDim.x) {
+        uint32_t hsh = (i + 1 + blockIdx.x * 7919) * 2654435761u; hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        ((uint32_t*)L)[i] = rnd ? hsh : (i & 3);
+    }
+    __syncthreads();
+    i32x16 acc[3];
+    for (int a = 0; a < 3; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned char* A = L + (lane & 31) * 496 + (lane >> 5) * 80;
+    const unsigned char* B = L + 96 * 496 + lane * 16;
+    int off = 0;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            off = (off + step) & 63;
+            const int o = off & ~15;
+            i32x4v fa[3][3], fb[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[t][p] = *(const i32x4v*)(A + t * 32 * 496 + p * 160 + o);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[p] = *(const i32x4v*)(B + p * 1024 + o);
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t][term % 3], fb[term / 2], acc[t], 0, 0, 0);
+        }
+    }
+    int s = 0;
+    for (int a = 0; a < 3; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+}
+
 template <typename F>
 static double run(F launch, double flops_per_launch, const char* name) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -169,5 +209,10 @@ int main() {
     run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0, 1>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 1024, "RANDOM, A piece kept across products");
     run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0, 2>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 1024, "RANDOM, B piece kept across products");
     run([&] { hipLaunchKernelGGL((k_lds2<4, 1, 0, 0>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mf * 18 * 4 * (double)iters * 4.0 * 1024, "RANDOM, x6 order of mogan_mma.h (again)");
+    // the int8 pipe (K = 32 per instruction: twice the multiply-adds of the bf16 instruction); "TFLOP/s bf16" column = TOP/s here
+    const double mi = 2.0 * 32 * 32 * 32;
+    run([&] { hipLaunchKernelGGL((k_i8<4>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 0); }, mi * 18 * 4 * (double)iters * 4.0 * 1024, "int8 MFMA 32x32x32, constant data (TOP/s)");
+    run([&] { hipLaunchKernelGGL((k_i8<4>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mi * 18 * 4 * (double)iters * 4.0 * 1024, "int8 MFMA 32x32x32, RANDOM data (TOP/s)");
+    run([&] { hipLaunchKernelGGL((k_i8<4>), dim3(1024), dim3(256), 0, 0, out, iters, 16, 1); }, mi * 18 * 4 * (double)iters * 4.0 * 1024, "int8 MFMA 32x32x32, RANDOM data (again)");
     return 0;
 }

@@ -752,6 +752,13 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
             if (rc2 != 0) return rc2 < 0 ? rc2 : 0;
         }
     }
+    if constexpr (S == 2 && KH == 4 && KW == 4) {     // 4x4 s2 p1: the same kernel over the space-to-depth image of the input
+        if (p.up == 0 && p.pt == 1 && p.pl == 1 && p.npar == 1 && p.ys == 1 && !p.accumulate) {
+            const int rc2 = mogan_dconv2_fwd_try(p.X, p.Wt, 3, p.Y, p.B, p.Cin, p.Cout, p.H, p.W, p.OH, p.OW, 4, 4, 1, 1, p.yH, p.yW, 1, 1,
+                                                 0, ws, ws_bytes, st);
+            if (rc2 != 0) return rc2 < 0 ? rc2 : 0;
+        }
+    }
     // tile config: 96-wide M when it pads less
     const bool m96 = cdiv(p.Cout, 96) * 96 < cdiv(p.Cout, 128) * 128;
     const int bm = m96 ? 96 : 128;

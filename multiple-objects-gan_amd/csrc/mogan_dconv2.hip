@@ -57,10 +57,12 @@ __device__ __forceinline__ f32x4 ldg4w(__amdgpu_buffer_rsrc_t r, unsigned idx) {
 
 struct D2P {
     const float* X; const void* Wp; float* Y; float* ws;
-    int B, Cin, Cout, H, W;                  // input (B, Cin, H, W)
+    int B, Cin, Cout, H, W;                  // input (B, Cin, H, W); space-to-depth form: Cin = 4 x the tensor's channels CinX
+    int CinX;                                // channels of the tensor X
     int OH, OW, pt, pl;                      // output grid of the (sub-)convolution, top / left padding
     int yH, yW, ys;                          // output plane dims and pixel stride (2: the parity classes of a stride-2 data gradient)
     int tiles_x, tiles_y, nsplit, sps, npar; // spatial tiles, K split over stages (stages per split), parity classes
+    int tiles_cw;                            // columns of a spatial tile (32 or 16; rows = 256 / columns)
     int ntiles, tpb;                         // spatial tiles in all (B * tiles_x * tiles_y), tiles per persistent block
     long long slab; int accumulate;
     unsigned x_bytes, wp_bytes;
@@ -73,7 +75,10 @@ struct D2P {
 //   1  data gradient of a 3x3 s1 convolution w (Co, Ci, 3, 3): Cout' = Ci, Cin' = Co, Wt[ci][co][tap] = w[co][ci][8 - tap]
 //      (what wflip_kernel of mogan_dconv.hip materialises);
 //   2  data gradient of a 4x4 s2 p1 convolution w (Co, Ci, 4, 4) = four 2x2 s1 convolutions, one per output parity (py, px):
-//      Wt[par * Ci + ci][co][a * 2 + b] = w[co][ci][((py + 1) & 1) + 2 (1 - a)][((px + 1) & 1) + 2 (1 - b)] (wparity_kernel).
+//      Wt[par * Ci + ci][co][a * 2 + b] = w[co][ci][((py + 1) & 1) + 2 (1 - a)][((px + 1) & 1) + 2 (1 - b)] (wparity_kernel);
+//   3  FORWARD of a 4x4 s2 p1 convolution w (Co, Ci, 4, 4) as a 2x2 s1 convolution over the space-to-depth image of the padded
+//      input (NS = 2; a stage = 8 channels x the four phases (dy, dx) = (sub, half)): unit (stage, row, sub, tap = (a, b), half)
+//      = w[row][8 stage + i][2 a + sub][2 b + half], i = 0..7.  Cout1 = Ci.
 __global__ __launch_bounds__(256) void dconv2_wprep_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int Cin,
                                                            int KHW, int NS, int wmode, int Cout1, long long total) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -90,6 +95,10 @@ __global__ __launch_bounds__(256) void dconv2_wprep_kernel(const float* __restri
     } else if (wmode == 1) {             // rows = Ci of w, Cin = Co of w
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = w[((size_t)(c0 + i) * rows + row) * 9 + (8 - tap)];
+    } else if (wmode == 3) {             // Cout1 = Ci of w
+        const int kh = 2 * (tap >> 1) + sub, kw = 2 * (tap & 1) + half;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[((size_t)row * Cout1 + stage * 8 + i) * 16 + kh * 4 + kw];
     } else {                             // Cout1 = Ci of w (rows = 4 * Ci), Cin = Co of w
         const int par = row / Cout1, ci = row - par * Cout1, py = par >> 1, px = par & 1;
         const int kh = ((py + 1) & 1) + 2 * (1 - (tap >> 1)), kw = ((px + 1) & 1) + 2 * (1 - (tap & 1));
@@ -102,9 +111,13 @@ __global__ __launch_bounds__(256) void dconv2_wprep_kernel(const float* __restri
     for (int pl = 0; pl < 3; ++pl) wp[base + pl * 2] = __builtin_bit_cast(uint4, f.p[pl]);
 }
 
-template <int KH, int KW, int TM, int NS>
+// CW = columns of the spatial tile (32: 8 rows x 32 columns, 16: 16 x 16 -- the maps with 16-pixel rows); S2D = the 2 x 2 filter
+// runs over the space-to-depth image of a stride-2 convolution's padded input: "pixel" (y, x) of sub-chunk dy, lane half dx is
+// X[c][2 y + dy - 1][2 x + dx - 1], a stage = 8 channels of X (NS = 2, KH = KW = 2)
+template <int KH, int KW, int TM, int NS, int CW, bool S2D>
 __global__ __launch_bounds__(512) void dconv2_fwd_kernel(const D2P p) {
-    constexpr int KHW = KH * KW, BM = TM * 32, R = 8, CW = 32;
+    static_assert(!S2D || (KH == 2 && KW == 2 && NS == 2), "space-to-depth form: 2 x 2 filter, two sub-chunks");
+    constexpr int KHW = KH * KW, BM = TM * 32, R = 256 / CW;
     constexpr int HH = R + KH - 1, WW = CW + KW - 1, NPIX = HH * WW;
     constexpr int NG = NS * KHW, UPR = NG * 6, WROW = (UPR + 1) * 16;       // groups per stage; 16-byte units / bytes per filter row
     constexpr int XSZ = NS * 6 * NPIX * 16;
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(512) void dconv2_fwd_kernel(const D2P p) {
     unsigned char* const Wl = smem + XSZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int prow = (wave * 32 + (lane & 31)) / CW, pcol = (wave * 32 + (lane & 31)) % CW;     // this lane's pixel of the tile
     D2_T(t_k0);
     const int m0 = blockIdx.y * BM;
     const int sp = blockIdx.z % p.nsplit, par = blockIdx.z / p.nsplit;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(512) void dconv2_fwd_kernel(const D2P p) {
         const int sh = it / NPIX, pix = it - sh * NPIX;                    // sh = sub * 2 + half
         xhy[j] = pix / WW; xhx[j] = pix - xhy[j] * WW;
         const bool in = it < NS * 2 * NPIX;
-        xc[j] = (unsigned)(sh * 8 * HWin);
+        xc[j] = S2D ? 0u : (unsigned)(sh * 8 * HWin);
         xl[j] = in ? (((sh >> 1) * 6 + (sh & 1)) * NPIX + pix) * 16 : -1;
     }
     unsigned xg[NIT];                                                       // global dword index of an item's first channel (tile dependent)
@@ -156,10 +170,14 @@ __global__ __launch_bounds__(512) void dconv2_fwd_kernel(const D2P p) {
         const int tx = t % p.tiles_x; const int r = t / p.tiles_x;
         const int ty = r % p.tiles_y; c_img = r / p.tiles_y;
         c_oy0 = ty * R; c_ox0 = tx * CW;
-        const unsigned x_img = (unsigned)c_img * p.Cin * HWin;
+        const unsigned x_img = (unsigned)c_img * p.CinX * HWin;
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            const int iy = c_oy0 - pt + xhy[j], ix = c_ox0 - pl_ + xhx[j];
+            int iy = c_oy0 - pt + xhy[j], ix = c_ox0 - pl_ + xhx[j];
+            if constexpr (S2D) {
+                const int sh = (tid + 512 * j) / NPIX;
+                iy = 2 * (c_oy0 + xhy[j]) + (sh >> 1) - 1; ix = 2 * (c_ox0 + xhx[j]) + (sh & 1) - 1;
+            }
             const bool ok = xl[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             xg[j] = ok ? x_img + xc[j] + (unsigned)(iy * p.W + ix) : D2_OOB;
         }
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(512) void dconv2_fwd_kernel(const D2P p) {
 
     float rx[NIT][8]; f32x4 rw[NWU];
     auto load_stage = [&](int s) {
-        const unsigned xb = (unsigned)s * (16 * NS) * HWin;
+        const unsigned xb = (unsigned)s * (S2D ? 8 : 16 * NS) * HWin;
 #pragma unroll
         for (int j = 0; j < NIT; ++j)
 #pragma unroll
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(512) void dconv2_fwd_kernel(const D2P p) {
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     const unsigned char* const Ab = Wl + (lane & 31) * WROW + h * 16;
-    const unsigned char* const Bb = Xh + (h * NPIX + wave * WW + (lane & 31)) * 16;
+    const unsigned char* const Bb = Xh + (h * NPIX + prow * WW + pcol) * 16;
     float* __restrict__ const Yg = (p.nsplit > 1) ? (p.ws + (size_t)sp * p.slab) : p.Y;
     const bool addc = (p.nsplit == 1) && p.accumulate;
     const size_t plane = (size_t)p.yH * p.yW;
@@ -264,8 +282,8 @@ __global__ __launch_bounds__(512) void dconv2_fwd_kernel(const D2P p) {
             D2_ADD(1, t_s0, t_s1); D2_ADD(2, t_s1, t_s2); D2_ADD(6, t_s0, t_s0 + 1);
         }
         D2_T(t_e0);
-        // ---- epilogue: Y[img][m][(oy0 + wave) * ys + y0][(ox0 + lane) * ys + x0]; the stores drain under the next tile's MFMAs ----
-        const size_t pix = (size_t)((e_oy0 + wave) * p.ys + y0) * p.yW + (size_t)(e_ox0 + (lane & 31)) * p.ys + x0;
+        // ---- epilogue: Y[img][m][(oy0 + prow) * ys + y0][(ox0 + pcol) * ys + x0]; the stores drain under the next tile's MFMAs ----
+        const size_t pix = (size_t)((e_oy0 + prow) * p.ys + y0) * p.yW + (size_t)(e_ox0 + pcol) * p.ys + x0;
         float* const ybase = Yg + ((size_t)e_img * p.Cout + m0 + 4 * h) * plane + pix;
         if (m0 + BM <= p.Cout && !addc) {          // whole channel block, plain stores: no per-element branches
 #pragma unroll
@@ -305,20 +323,24 @@ __global__ __launch_bounds__(256) void dconv2_reduce_kernel(const float* __restr
 
 static inline long long cdiv2(long long a, long long b) { return (a + b - 1) / b; }
 
-template <int KH, int KW, int TM, int NS>
-static int launch2(D2P& p, hipStream_t st) {
-    constexpr int KHW = KH * KW, NPIX = (8 + KH - 1) * (32 + KW - 1);
+template <int KH, int KW, int TM, int NS, int CW, bool S2D>
+static int launch2g(D2P& p, hipStream_t st) {
+    constexpr int KHW = KH * KW, NPIX = (256 / CW + KH - 1) * (CW + KW - 1);
     constexpr size_t lds = (size_t)NS * 6 * NPIX * 16 + (size_t)TM * 32 * ((size_t)NS * KHW * 6 + 1) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)dconv2_fwd_kernel<KH, KW, TM, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)dconv2_fwd_kernel<KH, KW, TM, NS, CW, S2D>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return MOGAN_ERR_LAUNCH;
         attr = true;
     }
     dim3 grid((unsigned)cdiv2(p.ntiles, p.tpb), (unsigned)cdiv2(p.Cout, TM * 32), (unsigned)(p.nsplit * p.npar));
-    hipLaunchKernelGGL((dconv2_fwd_kernel<KH, KW, TM, NS>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((dconv2_fwd_kernel<KH, KW, TM, NS, CW, S2D>), grid, dim3(512), lds, st, p);
     return 0;
+}
+template <int KH, int KW, int TM, int NS>
+static int launch2(D2P& p, hipStream_t st) {
+    return p.tiles_cw == 32 ? launch2g<KH, KW, TM, NS, 32, false>(p, st) : launch2g<KH, KW, TM, NS, 16, false>(p, st);
 }
 
 }  // namespace
@@ -327,24 +349,40 @@ static int launch2(D2P& p, hipStream_t st) {
 // ---- internal entry point (hidden): 1 = handled, 0 = not eligible (the caller takes dconv_fwd_kernel), < 0 = error ---------------
 // X (B, Cin, H, W); the filters of the convolution to run come out of w as wmode says (dconv2_wprep_kernel: 0 = w is
 // [npar][Cout][Cin][KH*KW] itself, 1 / 2 = w is the ORIGINAL filter tensor of a 3x3 s1 / 4x4 s2 convolution whose data gradient
-// this call computes -- no flipped / parity-split copy is materialised); output grid OH x OW per parity class written at pixel
+// this call computes -- no flipped / parity-split copy is materialised, 3 = w is the filter tensor of a 4x4 s2 p1 convolution whose
+// FORWARD this call computes: KH = KW = 4, pt = pl = 1, OH = H / 2); output grid OH x OW per parity class written at pixel
 // stride ys into planes yH x yW.
 int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, int B, int Cin, int Cout, int H, int W, int OH, int OW,
                          int KH, int KW, int pt, int pl, int yH, int yW, int ys, int npar, int accumulate, void* ws,
                          size_t ws_bytes, hipStream_t st) {
 #if MOGAN_X6
-    static const int on = getenv("MOGAN_DCONV2") ? atoi(getenv("MOGAN_DCONV2")) : 1;
-    if (!on) return 0;
+    // MOGAN_DCONV2: 0 = off, 1 = 8 x 32 tiles of stride-1 filters only (the first form of this kernel), 2 (default) = also the
+    // 16 x 16 tiles and the space-to-depth forward of the 4x4 s2 convolutions
+    static const int on = getenv("MOGAN_DCONV2") ? atoi(getenv("MOGAN_DCONV2")) : 2;
+    if (!on || (on < 2 && (wmode == 3 || (OW % 32) != 0))) return 0;
+    // wmode 3: the forward of a 4x4 s2 p1 convolution (KH = KW = 4, pt = pl = 1 on entry) = a 2 x 2 filter over the space-to-depth
+    // image of the padded input, 4 Cin channels, no padding of its own
+    const bool s2d = wmode == 3;
+    if (s2d) {
+        if (KH != 4 || KW != 4 || pt != 1 || pl != 1 || (H & 1) || (W & 1) || OH != H / 2 || OW != W / 2 || (Cin % 8) || npar != 1 ||
+            ys != 1) return 0;
+        KH = KW = 2; pt = pl = 0;
+    }
+    const int CinX = Cin;
+    if (s2d) Cin *= 4;
     const bool k33 = KH == 3 && KW == 3, k22 = KH == 2 && KW == 2;
-    if (!(k33 || k22) || (OW % 32) || (OH % 8) || (Cin % 16) || Cout < 64 || B <= 0) return 0;
-    if ((long long)B * Cin * H * W >= (1ll << 29) || (long long)B * Cout * yH * yW >= (1ll << 30)) return 0;
+    // spatial tile: 8 rows x 32 columns, or 16 x 16 on the maps with 16-pixel rows
+    const int cw = (OW % 32) == 0 ? 32 : 16, tr = 256 / cw;
+    if (!(k33 || k22) || (OW % cw) || (OH % tr) || (Cin % 16) || Cout < 64 || B <= 0) return 0;
+    if ((long long)B * CinX * H * W >= (1ll << 29) || (long long)B * Cout * yH * yW >= (1ll << 30)) return 0;
     const int KHW = KH * KW;
-    // BM: least padded rows of 64 / 96 / 128, the larger tile on a tie
+    // BM: least padded rows of 64 / 96 / 128, the larger tile on a tie (space-to-depth form: 64 / 96, its stage is two sub-chunks)
     int tm = 4; long long best = cdiv2(Cout, 128) * 128;
-    if (cdiv2(Cout, 96) * 96 < best) { best = cdiv2(Cout, 96) * 96; tm = 3; }
+    if (s2d) { tm = 3; best = cdiv2(Cout, 96) * 96; }
+    else if (cdiv2(Cout, 96) * 96 < best) { best = cdiv2(Cout, 96) * 96; tm = 3; }
     if (cdiv2(Cout, 64) * 64 < best) { best = cdiv2(Cout, 64) * 64; tm = 2; }
     // stage = NS x 16 channels: the 2 x 2 filters take two sub-chunks per stage (8 groups between barriers) where LDS allows
-    const int ns = (k22 && tm <= 3 && Cin % 32 == 0) ? 2 : 1;
+    const int ns = s2d ? 2 : (k22 && tm <= 3 && Cin % 32 == 0) ? 2 : 1;
     const int nst = Cin / (16 * ns);
     const long long rows = (long long)npar * Cout;
     const size_t wpb = (size_t)nst * rows * ns * KHW * 6 * 16;
@@ -352,13 +390,13 @@ int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, in
     {
         const long long total = (long long)nst * rows * ns * KHW * 2;
         hipLaunchKernelGGL(dconv2_wprep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, (int)rows, Cin,
-                           KHW, ns, wmode, Cout, total);
+                           KHW, ns, wmode, s2d ? CinX : Cout, total);
     }
     D2P p{};
-    p.X = X; p.Wp = ws; p.Y = Y; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pt = pt; p.pl = pl;
+    p.X = X; p.Wp = ws; p.Y = Y; p.B = B; p.Cin = Cin; p.CinX = CinX; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pt = pt; p.pl = pl;
     p.yH = yH; p.yW = yW; p.ys = ys; p.npar = npar; p.accumulate = accumulate;
-    p.tiles_x = OW / 32; p.tiles_y = OH / 8;
-    p.x_bytes = 4u * (unsigned)B * Cin * H * W; p.wp_bytes = (unsigned)wpb;
+    p.tiles_cw = cw; p.tiles_x = OW / cw; p.tiles_y = OH / tr;
+    p.x_bytes = 4u * (unsigned)B * CinX * H * W; p.wp_bytes = (unsigned)wpb;
     const size_t adv = (wpb + 255) & ~(size_t)255;
     char* ws2 = (char*)ws + adv; size_t ws2_bytes = ws_bytes - adv;
     p.ntiles = B * p.tiles_x * p.tiles_y;
@@ -388,7 +426,10 @@ int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, in
     if (tiles * p.nsplit > 0x7fffffffLL) return 0;
     mogan_prof_relabel(2);
     int rc = 0;
-    if (k33) {
+    if (s2d) {
+        if (cw == 32) rc = tm == 3 ? launch2g<2, 2, 3, 2, 32, true>(p, st) : launch2g<2, 2, 2, 2, 32, true>(p, st);
+        else rc = tm == 3 ? launch2g<2, 2, 3, 2, 16, true>(p, st) : launch2g<2, 2, 2, 2, 16, true>(p, st);
+    } else if (k33) {
         if (tm == 4) rc = launch2<3, 3, 4, 1>(p, st); else if (tm == 3) rc = launch2<3, 3, 3, 1>(p, st); else rc = launch2<3, 3, 2, 1>(p, st);
     } else if (ns == 2) {
         if (tm == 3) rc = launch2<2, 2, 3, 2>(p, st); else rc = launch2<2, 2, 2, 2>(p, st);

@@ -93,6 +93,12 @@ CONV_CASES = [
     (3, 48, 16, 32, 80, (3, 3), 1, (1, 1), 0),     # several tiles per persistent block across images
     (2, 96, 32, 64, 64, (4, 4), 2, (1, 1), 0),     # data gradient: four 2x2 parity classes, two 16-channel sub-chunks per stage
     (2, 128, 16, 64, 16, (4, 4), 2, (1, 1), 0),    # data gradient with 16 input channels of dY (one stage), 128-row blocks
+    # 16 x 16 spatial tiles (maps with 16-pixel rows) and the 4x4 s2 FORWARD as a 2x2 filter over the space-to-depth image
+    (2, 96, 64, 128, 192, (4, 4), 2, (1, 1), 0),   # forward: 8 x 32 tiles, 96-row blocks, 12 stages of 8 channels
+    (2, 192, 32, 32, 96, (4, 4), 2, (1, 1), 0),    # forward and data gradient on 16 x 16 tiles, K split
+    (3, 24, 32, 64, 100, (4, 4), 2, (1, 1), 0),    # forward: ragged M = 100, 24 channels (3 stages)
+    (1, 8, 64, 32, 64, (4, 4), 2, (1, 1), 0),      # forward: one stage, two tiles of 16 x 16
+    (2, 64, 16, 16, 128, (3, 3), 1, (1, 1), 0),    # 3x3 on one 16 x 16 tile per image
 ]
 
 

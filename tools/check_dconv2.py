@@ -11,7 +11,9 @@ dev = "cuda"
 torch.manual_seed(0)
 CASES = [  # B, Cin, H, W, Cout, k, s
     (2, 96, 64, 64, 192, 3, 1), (2, 96, 32, 64, 96, 3, 1), (3, 32, 8, 32, 64, 3, 1), (2, 64, 12, 32, 160, 3, 1), (1, 32, 4, 32, 128, 3, 1), (2, 48, 16, 32, 80, 3, 1), (1, 384, 32, 32, 384, 3, 1),
-    (2, 96, 128, 128, 192, 4, 2), (2, 192, 64, 64, 384, 4, 2), (2, 64, 16, 64, 96, 4, 2), (2, 80, 16, 64, 128, 4, 2), (1, 16, 16, 64, 768, 4, 2)]
+    (2, 96, 128, 128, 192, 4, 2), (2, 192, 64, 64, 384, 4, 2), (2, 64, 16, 64, 96, 4, 2), (2, 80, 16, 64, 128, 4, 2), (1, 16, 16, 64, 768, 4, 2),
+    # 16 x 16 tiles (maps with 16-pixel rows) and the space-to-depth forward of 4x4 s2
+    (2, 384, 32, 32, 768, 4, 2), (3, 64, 32, 32, 96, 4, 2), (2, 24, 32, 64, 100, 4, 2), (2, 64, 16, 16, 128, 3, 1), (2, 32, 32, 16, 64, 3, 1), (1, 8, 64, 32, 64, 4, 2), (16, 96, 128, 128, 192, 4, 2)]
 worst = 0.0
 for (B, Cin, H, W, Cout, k, s) in CASES:
     x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05

@@ -1,6 +1,7 @@
 """Shared entry point of the three StackGAN-style trees (code/coco/stackgan/main.py, code/clevr/main.py,
-code/multi-mnist/main.py): --cfg / --gpu / --data_dir / --manualSeed as in the reference, plus --synthetic N (train on N
-synthetic items: there are no datasets on the GPU box), --max_epoch, --batch_size, --output_dir, --graph.  Each tree's
+code/multi-mnist/main.py): --cfg / --gpu / --data_dir / --manualSeed as in the reference -- real data through ..datasets' TextDatasets when
+TRAIN.FLAG, `sample` from the checkpoint cfg.NET_G otherwise -- plus --synthetic N (train on N synthetic items: there are no
+datasets on the GPU box), --max_epoch, --batch_size, --output_dir, --graph.  Each tree's
 main.py binds its own cfg / trainer to `run`."""
 import argparse
 import datetime
@@ -10,6 +11,7 @@ import random
 
 import torch
 
+from . import datasets
 from .datasets_synth import SyntheticDataset
 
 
@@ -49,16 +51,34 @@ def run(tree, cfg, cfg_from_file, trainer_cls, argv=None):
     timestamp = datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')
     output_dir = args.output_dir or '../../../output/%s_%s_%s' % (cfg.DATASET_NAME, cfg.CONFIG_NAME, timestamp)
     stage = int(cfg.get("STAGE", 1))
-    if not cfg.TRAIN.FLAG:
-        raise SystemExit("sampling is outside the train path (SURVEY.md section 8(f)); set TRAIN.FLAG")
-    if not args.synthetic:
-        raise SystemExit("the real-data TextDataset of this tree is outside the train hot path "
-                         "(SURVEY.md section 8(f) rank 2); run with --synthetic N")
+    if not cfg.TRAIN.FLAG:                                             # sampling from a checkpoint (cfg.NET_G)
+        algo = trainer_cls(output_dir, use_graph=False)
+        if tree == "coco":                                             # S/main.py:98-100
+            algo.sample('%s/test/' % cfg.DATA_DIR, num_samples=25, stage=stage, draw_bbox=True)
+        elif tree == "clevr":                                          # C/main.py:91-101
+            ds = datasets.ClevrTextDataset(cfg.DATA_DIR, split="test", imsize=64, transform=datasets.image_transform())
+            dl = torch.utils.data.DataLoader(ds, batch_size=1, drop_last=True, shuffle=True, num_workers=int(cfg.WORKERS))
+            algo.sample(dl, num_samples=25, draw_bbox=True)
+        else:                                                          # M/main.py:91-93
+            algo.sample(os.path.join(cfg.DATA_DIR, "test"), num_samples=25, draw_bbox=True)
+        return algo
     os.makedirs(output_dir, exist_ok=True)
-    dataset = SyntheticDataset(tree, stage, args.synthetic, seed=args.manualSeed,
-                               text_dim=cfg.TEXT.DIMENSION if "TEXT" in cfg else 0)
+    if args.synthetic:
+        dataset = SyntheticDataset(tree, stage, args.synthetic, seed=args.manualSeed,
+                                   text_dim=cfg.TEXT.DIMENSION if "TEXT" in cfg else 0)
+    elif tree == "coco":                                               # S/main.py:77-90
+        resize, imsize = (76, 64) if stage == 1 else (268, 256)
+        dataset = datasets.CocoTextDataset(cfg.DATA_DIR, cfg.IMG_DIR, split="train", imsize=imsize,
+                                           transform=datasets.image_transform(resize), crop=True, stage=stage)
+    elif tree == "clevr":                                              # C/main.py:80-85
+        dataset = datasets.ClevrTextDataset(cfg.DATA_DIR, split="train", imsize=64, transform=datasets.image_transform())
+    else:                                                              # M/main.py:77-83
+        dataset = datasets.MnistTextDataset(cfg.DATA_DIR, split="train", imsize=64, transform=datasets.image_transform(),
+                                            crop=True)
+    assert len(dataset) > 0
+    workers = 0 if args.synthetic else int(cfg.get("WORKERS", 0))
     dataloader = torch.utils.data.DataLoader(dataset, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True, shuffle=True,
-                                             num_workers=0)
+                                             num_workers=workers)
     algo = trainer_cls(output_dir, use_graph=args.graph)
     algo.train(dataloader, stage)
     return algo

@@ -20,3 +20,9 @@ def compute_discriminator_loss(netD, real_imgs, fake_imgs, real_labels, fake_lab
 def compute_generator_loss(netD, fake_imgs, real_labels, local_label, transf_matrices, transf_matrices_inv, gpus=None):
     cond = _losses.label_condition(local_label.detach(), _CLAMP)
     return _losses.generator_loss(netD, fake_imgs, local_label, transf_matrices, transf_matrices_inv, cond)
+
+
+def load_validation_data(datapath):
+    """M/miscc/utils.py:59-68: labels, boxes of <datapath>/normal/{labels,bboxes}.pickle as tensors."""
+    from ...datasets import load_validation_data as _lvd
+    return _lvd(datapath, tree="mnist")

@@ -185,3 +185,14 @@ class GANTrainerBase(object):
             save_model(netG, netD, engine.optG, engine.optD, epoch, self.model_dir)
         if writer is not None:
             writer.close()
+
+    # ----------------------------------------------------------------------------- sample
+    def sample(self, data, num_samples=25, stage=1, draw_bbox=True, **kw):
+        """The tree's `sample` (S/trainer.py:287, C/trainer.py:198, M/trainer.py:208): `data` is the test split's path (coco,
+        mnist) or a data loader over it (clevr); see ..sampling."""
+        from . import sampling
+        if self.tree == "coco":
+            return sampling.sample_coco(self, data, num_samples, stage, draw_bbox, **kw)
+        if self.tree == "clevr":
+            return sampling.sample_clevr(self, data, num_samples, draw_bbox, **kw)
+        return sampling.sample_mnist(self, data, num_samples, draw_bbox, **kw)

@@ -3,6 +3,8 @@ vectors captured from the reference (tests/golden/stackgan_*.npz) -- forward, gr
 losses and the two-step train trajectory (eager and hipGraph).  Tolerances follow SURVEY.md §8(c): generated
 tensors max-abs <= 1e-4-ish, scalar losses rel 1e-5 (first step), D grads 1e-4, G grads 1e-2 (fp32 through the
 stacked BN generator is ill-conditioned), post-Adam parameters through abs-sum-relative checksums."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -222,3 +224,78 @@ def test_family_train_loops_and_checkpoints(tmp_path):
     # the frozen stage-I generator inside STAGE2_G still holds the stage-I checkpoint's weights
     assert torch.equal(g2["STAGE1_G.fc.0.weight"], g1["fc.0.weight"])
     assert not torch.equal(g2["STAGE1_G.fc.1.running_mean"], g1["fc.1.running_mean"])     # its BN buffers keep running
+
+
+def test_family_real_data_training_and_sampling(tmp_path):
+    """`main.py --cfg ... --data_dir ...` on tiny real-data trees (the file formats of the three reference TextDatasets,
+    tests/stackgan_data_cases.py): one epoch through DataLoader -> prepare_batch -> the engine, then TRAIN.FLAG: False ->
+    `GANTrainer.sample` from the written checkpoint (S/trainer.py:287-419, C/trainer.py:198-295, M/trainer.py:208-343): the
+    PNG grids exist, have the reference's layout (10 columns; clevr / mnist: a second row with the label text) and hold
+    finite, non-constant samples."""
+    import glob
+    import importlib
+    from PIL import Image
+    import stackgan_data_cases as C
+    from mogan_amd.stackgan import t7
+
+    def run(pkg, yml_text, name, extra=()):
+        entry = importlib.import_module("mogan_amd.stackgan.%s.main" % pkg)
+        yml = tmp_path / (name + ".yml")
+        yml.write_text(yml_text)
+        out = tmp_path / name
+        entry.main(["--cfg", str(yml), "--manualSeed", "3", "--output_dir", str(out)] + list(extra))
+        return sorted(glob.glob(str(out / "Model" / "checkpoint_*.pth")))
+
+    def check_grid(path, rows, imsize, channels_equal):
+        im = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32)
+        assert im.shape[:2] == (rows * (imsize + 2) + 2, 10 * (imsize + 2) + 2), (path, im.shape)
+        tiles = [im[2:2 + imsize, 2 + k * (imsize + 2): 2 + k * (imsize + 2) + imsize] for k in range(10)]
+        # tile 0 = the real image (random pixels), tiles 1..9 = the samples (a one-epoch generator of width 4: near-grey)
+        assert tiles[0].std() > 20.0 and all(t.std() < tiles[0].std() for t in tiles[1:]), path
+        if rows == 2:                                                                       # the text strip: mostly white
+            strip = im[2 + imsize + 2: 2 + imsize + 2 + imsize]
+            assert (strip > 250).mean() > 0.8 and (strip < 200).any()     # (black text sits at mid-grey: global min / max)
+
+    common = "GPU_ID: '0'\nZ_DIM: 100\nWORKERS: 0\nUSE_BBOX_LAYOUT: True\n"
+    train = "TRAIN: {FLAG: True, BATCH_SIZE: 3, MAX_EPOCH: 1, LR_DECAY_EPOCH: 1, SNAPSHOT_INTERVAL: 1}\n"
+    off = "TRAIN: {FLAG: False, BATCH_SIZE: 1}\n"
+    # ---- clevr
+    gan = "GAN: {CONDITION_DIM: 16, DF_DIM: 4, GF_DIM: 4}\n"
+    d = C.build_clevr_tree(str(tmp_path))
+    ck = run("clevr", common + train + gan, "clevr", ["--data_dir", d])[-1]
+    run("clevr", common + off + gan + "NET_G: '%s'\n" % ck, "clevr_sample", ["--data_dir", d])
+    files = sorted(glob.glob(ck[:-4] + "_samples_4_objects/vis_*.png"))
+    assert len(files) == C.N_ITEMS                                     # the test split's six scenes (num_samples = 25 > 6)
+    for f in files:
+        check_grid(f, 2, 64, False)
+    # ---- multi-mnist
+    gan = "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 4}\n"
+    d = C.build_mnist_tree(str(tmp_path))
+    ck = run("multi_mnist", common + train + gan, "mnist", ["--data_dir", d])[-1]
+    run("multi_mnist", common + off + gan + "NET_G: '%s'\n" % ck, "mnist_sample", ["--data_dir", d])
+    files = sorted(glob.glob(ck[:-4] + "_samples_3_digits/vis_*.png"))
+    assert len(files) == 25
+    check_grid(files[0], 2, 64, True)
+    check_grid(files[-1], 2, 64, True)
+    # ---- coco stage I, stage II
+    d, img_dir, raw = C.build_coco_tree(str(tmp_path))
+    caps = ["caption number %d / of the test split" % i for i in range(C.N_ITEMS)]
+    t7.save(os.path.join(d, "test", "val_captions.t7"),
+            {"raw_txt": caps, "fea_txt": [raw["emb"][i, :1].copy() for i in range(C.N_ITEMS)]})
+    coco = common + "IMG_DIR: '%s'\nTEXT: {DIMENSION: 16}\n" % img_dir
+    gan1 = "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 192}\n"
+    gan2 = "GAN: {CONDITION_DIM: 128, DF_DIM: 4, GF_DIM: 192, R_NUM: 1}\n"
+    tr1 = train.replace("}", ", COEFF: {KL: 2.0}}")
+    s1 = run("coco", coco + "STAGE: 1\nIMSIZE: 64\n" + tr1 + gan1, "s1", ["--data_dir", d])[-1]
+    run("coco", coco + "STAGE: 1\nIMSIZE: 64\n" + off + gan1 + "NET_G: '%s'\n" % s1, "s1_sample", ["--data_dir", d])
+    files = sorted(glob.glob(s1[:-4] + "_visualize_bbox/*.png"))
+    assert 1 <= len(files) <= C.N_ITEMS and all("caption number" in os.path.basename(f) for f in files)
+    for f in files:
+        check_grid(f, 1, 64, False)
+    tr2 = tr1.replace("BATCH_SIZE: 3", "BATCH_SIZE: 2")
+    # (NET_G: '' -- the tree's cfg is one global per process, and the sampling run above has set it)
+    s2 = run("coco", coco + "STAGE: 2\nIMSIZE: 256\nNET_G: ''\nSTAGE1_G: '%s'\n" % s1 + tr2 + gan2, "s2", ["--data_dir", d])[-1]
+    run("coco", coco + "STAGE: 2\nIMSIZE: 256\n" + off + gan2 + "NET_G: '%s'\n" % s2, "s2_sample", ["--data_dir", d])
+    files = sorted(glob.glob(s2[:-4] + "_visualize_bbox/*.png"))
+    assert 1 <= len(files) <= C.N_ITEMS
+    check_grid(files[0], 1, 256, False)

@@ -516,8 +516,7 @@ class TrainEngine:
         bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
         if bmap:
             ids = [int(v) for v in bmap.split(",")]
-            pool = {k: torch.cuda.Stream() for k in sorted(set(ids))}
-            self.side = [pool[k] for k in ids]
+            self.side = [self.side[k] for k in ids]           # (the engine's own branch streams: their queue layout stays)
         # stream creation order fixes the stream -> hardware-queue map (see ops.precreate_wgrad_stream): branch streams,
         # then the weight-gradient streams in the order the branches run (D256, D128, D64, generator), communication
         # streams last -- measured: with the communication streams created in between, the generator's wgrad stream landed

@@ -1082,6 +1082,10 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
         rc = mogan_smallc_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
+    if (g_force_cfg < 0 && up == 0) {   // 3 input channels, 4x4 s2: the discriminators' first layer as a streaming kernel (mogan_stem.hip)
+        rc = mogan_stem_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 1.f, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     if (g_force_cfg == -1) {        // 3x3 s1 p1 at >= 32 channels: fused Winograd F(2x2,3x3), 2.25x fewer multiplies (-2: test hook, off)
         // (recorded flops = the multiplies the kernel executes: 16 per 2x2 outputs instead of 36)
         mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
@@ -1112,6 +1116,10 @@ int mogan_conv2d_lrelu_fwd(const float* x, const float* w, float* z, int B, int 
     if (!(slope > 0.f)) return MOGAN_ERR_SHAPE;
     // only layers the dispatch of mogan_conv2d_fwd would hand to the implicit-GEMM kernel anyway: few input channels
     if (Cin > 16 || Cout <= 4) return 1;
+    if (g_force_cfg < 0) {
+        rc = mogan_stem_fwd_try(x, w, z, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, slope, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     p.A = w; p.B = x; p.C = z; p.M = Cout; p.N = B * p.OH * p.OW; p.K = Cin * KH * KW; p.accumulate = 0;
     p.a_bytes = 4u * Cout * Cin * KH * KW; p.b_bytes = 4u * B * Cin * Hs * Ws;
     p.avec = (p.K % 4 == 0) && (((uintptr_t)w & 15) == 0);

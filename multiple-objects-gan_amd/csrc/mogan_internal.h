@@ -39,6 +39,9 @@ MOGAN_HIDDEN int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw
 MOGAN_HIDDEN void mogan_splitk_reduce_dense(const float* ws, float* out, long long n, int nsplit, int accumulate, hipStream_t st);
 // split-K block target of a launch on `st` (mogan_gemm_set_split_target / mogan_stream_set_split_target)
 MOGAN_HIDDEN int mogan_split_target(hipStream_t st);
+// mogan_stem.hip: conv4x4 s2 p1 from 3 input channels + LeakyReLU(slope) (slope = 1: none) as one streaming kernel; 1 = handled
+MOGAN_HIDDEN int mogan_stem_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                                    int stride, int ph, int pw, float slope, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_begin(int mode, int cfg, double flops, int M, int N, int K, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_end(int taken, hipStream_t st);
 MOGAN_HIDDEN void mogan_prof_relabel(int cfg);     // the open launch record's kernel id (2 = dconv2_fwd_kernel)

@@ -398,6 +398,32 @@ def test_logits_head_and_conv_lrelu(B, Cin, Cout):
     _check(z, ref, 2e-6, "conv+lrelu"); _check(xid.grad, xi.grad, 5e-6, "conv+lrelu dx"); _check(wid.grad, wi.grad, 5e-6, "conv+lrelu dw")
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 64, 64, 96), (3, 16, 128, 48), (1, 2, 64, 32), (2, 66, 192, 128), (2, 64, 64, 40)])
+def test_first_discriminator_layer_streaming_kernel(B, H, W, Cout):
+    """csrc/mogan_stem.hip (round 5): Conv2d(3, ndf, 4, 2, 1) [+ LeakyReLU(0.2)] of model.py:597-598, 660-661 on output rows that are
+    multiples of 32 pixels -- one wave = 32 pixels x all channels, both image borders, a one-row output, 1-4 row tiles, the register
+    sets alternating over several groups per wave -- against torch in fp64 and against the implicit-GEMM kernel it replaces
+    (mogan_gemm_debug_force(0, 0) keeps every convolution on that kernel); input / weight gradients of the fused Function."""
+    x = T("st.x%d" % H, (B, 3, H, W)).requires_grad_(True)
+    w = T("st.w%d" % Cout, (Cout, 3, 4, 4), 0.2).requires_grad_(True)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), None, 2, 1), 0.2)
+    g = T("st.g%d%d" % (H, Cout), ref.shape)
+    ref.backward(g.double())
+    xd, wd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w))
+    z = ops.conv2d_lrelu(xd, wd, 2, 1, 0.2)
+    z.backward(g.to(DEV))
+    _check(z, ref, 2e-6, "stem"); _check(xd.grad, x.grad, 5e-6, "stem dx"); _check(wd.grad, w.grad, 5e-6, "stem dw")
+    y = ops.conv2d_forward(xd.detach(), wd.detach(), 2, 1, 1, 0)
+    _check(y, F.conv2d(x.double(), w.double(), None, 2, 1), 2e-6, "stem, plain convolution")
+    lib.load().mogan_gemm_debug_force(0, 0)
+    try:
+        z0 = ops.conv2d_lrelu(xd.detach(), wd.detach(), 2, 1, 0.2)
+    finally:
+        lib.load().mogan_gemm_debug_force(-1, 0)
+    assert float((z.detach() - z0).abs().max()) <= 2e-6 * float(z0.abs().max())
+    assert torch.equal(z.detach() > 0, z0 > 0) or float((z.detach() - z0).abs().max()) < 1e-6      # same side of the kink
+
+
 def test_stn_shared_source_gradient_is_order_independent_to_rounding():
     """mogan_stn_bwd_ex adds every object's contribution to the ONE image-batch gradient with fp32 atomics (include/mogan_hip.h,
     "Determinism"): two runs agree to the rounding of a short sum, and both agree with the fixed-order sum of the per-object

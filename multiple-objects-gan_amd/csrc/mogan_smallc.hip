@@ -11,6 +11,7 @@
 // as scalar loads.  fp32 FMA order: ci (or co) outer, taps inner -- sums of <= 27*Cin terms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mogan_hip.h"
 #include "mogan_internal.h"
 
@@ -94,6 +95,95 @@ __global__ __launch_bounds__(256) void sc_fwd3x3(const float* __restrict__ x, co
     if (oy < H && ox < W) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co) y[((size_t)b * COUT + co) * plane + (size_t)oy * W + ox] = acc[co];
+    }
+}
+
+// The same convolution on maps whose rows are multiples of 128 pixels (the 128 x 128 and 256 x 256 image heads): a thread owns FOUR
+// consecutive pixels of a row, a block 8 rows x 128 columns.  Per channel and thread 9 LDS reads (a scalar, an aligned 16-byte
+// quad, a scalar per halo row) feed 108 FMAs -- the one-pixel form issues 36 reads for them and is bound by instruction issue
+// (141 us at B = 16, 256 x 256, where the 201 MB of input are a 45 us read); the halo is staged as aligned 16-byte quads (columns
+// x0 - 4 .. x0 + 131), a quarter of the load / store instructions per byte.
+template <int COUT>
+__global__ __launch_bounds__(256) void sc_fwd3x3_w4(const float* __restrict__ x, const float* __restrict__ w,
+                                                    float* __restrict__ y, int Cin, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int CK = 8, HH = TR + 2, TW = 128, NQ = TW / 4 + 2, WP = NQ * 4 + 4;      // 34 quads per halo row, padded pitch
+    constexpr int NL = (CK * HH * NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float Xs[CK][HH][WP];
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int tid = threadIdx.x, ly = tid >> 5, lx = tid & 31;
+    const int oy = ty * TR + ly, x0 = tx * TW;
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * Cin * plane;
+    float4 pre[NL];
+    auto halo_load4 = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + 256 * j;
+            const int c = e / (HH * NQ), r = e - c * (HH * NQ);
+            const int hy = r / NQ, q = r - hy * NQ;
+            const int iy = ty * TR - 1 + hy, ix = x0 - 4 + 4 * q;
+            const bool ok = e < CK * HH * NQ && c0 + c < Cin && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const float4 v = *(const float4*)(xb + (ok ? (size_t)(c0 + c) * plane + (size_t)iy * W + ix : 0));
+            pre[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto halo_store4 = [&]() {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + 256 * j;
+            const int c = e / (HH * NQ), r = e - c * (HH * NQ);
+            const int hy = r / NQ, q = r - hy * NQ;
+            if (e < CK * HH * NQ) *(float4*)&Xs[c][hy][4 * q] = pre[j];
+        }
+    };
+    float acc[COUT][4];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+    float wcur[COUT * 9];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wcur[co * 9 + k] = w[(size_t)co * Cin * 9 + k];
+    halo_load4(0);
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        halo_store4();
+        __syncthreads();
+        if (c0 + CK < Cin) halo_load4(c0 + CK);
+        const int nc = min(CK, Cin - c0);
+        for (int c = 0; c < nc; ++c) {
+            float wn[COUT * 9];
+            const int cn = min(c0 + c + 1, Cin - 1);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wn[co * 9 + k] = w[((size_t)co * Cin + cn) * 9 + k];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                // pixel p of this thread is halo column 4 lx + 4 + p; its taps are columns 4 lx + 3 + p + kw
+                const float* row = &Xs[c][ly + kh][4 * lx];
+                const float4 m = *(const float4*)(row + 4);
+                const float v[6] = {row[3], m.x, m.y, m.z, m.w, row[8]};
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(v[p + kw], wcur[co * 9 + kh * 3 + kw], acc[co][p]);
+            }
+#pragma unroll
+            for (int k = 0; k < COUT * 9; ++k) wcur[k] = wn[k];
+        }
+        __syncthreads();
+    }
+    if (oy < H) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+            *(float4*)(y + ((size_t)b * COUT + co) * plane + (size_t)oy * W + x0 + 4 * lx) =
+                make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
     }
 }
 
@@ -467,6 +557,21 @@ int mogan_smallc_fwd_try(const float* x, const float* w, float* y, int B, int Ci
         return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
     }
     if (!(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0 && Cout >= 1 && Cout <= 4)) return 0;
+    static const int w4 = getenv("MOGAN_SC_W4") ? atoi(getenv("MOGAN_SC_W4")) : 1;
+    if (w4 && (Ws % 128) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {          // four pixels per thread, 8 x 128 tiles
+        const int txs = Ws / 128, tys = cdiv(Hs, TR);
+        const long long nb4 = (long long)B * txs * tys;
+        if (nb4 <= 0x7fffffffLL) {
+            dim3 grid4((unsigned)nb4);
+            switch (Cout) {
+                case 1: hipLaunchKernelGGL(sc_fwd3x3_w4<1>, grid4, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, txs, tys); break;
+                case 2: hipLaunchKernelGGL(sc_fwd3x3_w4<2>, grid4, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, txs, tys); break;
+                case 3: hipLaunchKernelGGL(sc_fwd3x3_w4<3>, grid4, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, txs, tys); break;
+                default: hipLaunchKernelGGL(sc_fwd3x3_w4<4>, grid4, dim3(256), 0, st, x, w, y, Cin, Hs, Ws, txs, tys); break;
+            }
+            return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+        }
+    }
     const int tiles_x = cdiv(Ws, TC), tiles_y = cdiv(Hs, TR);
     const long long nb = (long long)B * tiles_x * tiles_y;
     if (nb > 0x7fffffffLL) return 0;

@@ -52,6 +52,9 @@ CONV_CASES = [
     (2, 3, 32, 32, 96, (4, 4), 2, (1, 1), 0),      # first D conv (Cin=3)
     (2, 48, 16, 16, 3, (3, 3), 1, (1, 1), 0),      # img head (Cout=3)
     (3, 13, 37, 70, 3, (3, 3), 1, (1, 1), 0),      # img head, ragged sizes (direct small-channel kernels)
+    (2, 20, 13, 128, 3, (3, 3), 1, (1, 1), 0),     # img head on 128-pixel rows: four pixels per thread (sc_fwd3x3_w4), ragged height / channels
+    (1, 8, 16, 256, 4, (3, 3), 1, (1, 1), 0),      # the same with two tiles per row, four output channels, one channel chunk
+    (2, 17, 9, 128, 1, (3, 3), 1, (1, 1), 0),      # one output channel, 17 input channels (a chunk of one)
     (2, 20, 64, 64, 1, (3, 3), 1, (1, 1), 0),      # multi-mnist img head (Cout=1)
     (2, 3, 64, 96, 40, (4, 4), 2, (1, 1), 0),      # first D conv, non-square (dgrad = 2x2-block kernel)
     (2, 1, 32, 32, 24, (4, 4), 2, (1, 1), 0),      # multi-mnist first D conv (Cin=1)

@@ -89,9 +89,20 @@ WGRAD_SIDE_STREAM = False
 CAPTURE_WGRAD_OK = set()     # raw handles of streams that may fork a wgrad stream while being captured (depth-1 forks only)
 _WGRAD_ENV = os.environ.get("MOGAN_WGRAD_STREAM", "1") != "0"
 _wgrad_streams = {}
-_wgrad_used = []         # side streams that received launches since the last join (see join_wgrad)
-_wgrad_keep = []         # operands of in-flight side-stream launches; released after the join so the caching
-                         # allocator cannot hand their memory to a main-stream kernel that runs concurrently
+
+
+class _WgradFrame:
+    """What ONE `with wgrad_overlap():` (one backward pass) owns: `used` = side streams that received its launches, `keep` =
+    operands of its in-flight side-stream launches (released after the join so the caching allocator cannot hand their memory to
+    a main-stream kernel that runs concurrently), `parked` = keys of the contributions it parked in _wgrad_pending.  A join
+    waits for and clears only its own frame -- a nested or interleaved context on another stream keeps its waits and operands."""
+    __slots__ = ("used", "keep", "parked")
+
+    def __init__(self):
+        self.used, self.keep, self.parked = [], [], []
+
+
+_wgrad_frames = [_WgradFrame()]      # [0] = launches outside any context (joined by a bare join_wgrad())
 
 
 # Merged weight gradients: a D update back-propagates through the same discriminator twice (real, fake).  For the deep
@@ -115,9 +126,10 @@ def _wgrad_launch(dy, x, w_shape, geom, g):
         side.wait_stream(cur)                     # dy (and the zeroed / partly accumulated grad) are ready
         with torch.cuda.stream(side):
             conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=g, accumulate=True)
-        if side not in _wgrad_used:
-            _wgrad_used.append(side)
-        _wgrad_keep.append((dy, x))               # freed only after the join (see join_wgrad)
+        fr = _wgrad_frames[-1]
+        if side not in fr.used:
+            fr.used.append(side)
+        fr.keep.append((dy, x))                   # freed only after the join (see join_wgrad)
         _grad_hit(g, side)
     else:
         conv2d_wgrad(dy, x, w_shape, stride, ph, pw, up, out=g, accumulate=True)
@@ -131,12 +143,17 @@ def _wgrad_accumulate(dy, x, w, geom, g):
             or (torch.cuda.is_current_stream_capturing() and not MERGE_WGRAD_CAPTURED):
         _wgrad_launch(dy, x, w.shape, geom, g)
         return
-    key = (g.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    cur = torch.cuda.current_stream()
+    key = (g.data_ptr(), cur.cuda_stream)
     prev = _wgrad_pending.pop(key, None)
     if prev is None:
-        _wgrad_pending[key] = (dy, x, tuple(w.shape), geom, g)
+        # parked on THIS stream: autograd may be running the node on another stream than the one the context was entered on (the
+        # tape of a replayed generator forward executes on its capture stream), so the flush goes by the context's own list of
+        # keys and launches each leftover on the stream it was parked on
+        _wgrad_pending[key] = (dy, x, tuple(w.shape), geom, g, cur)
+        _wgrad_frames[-1].parked.append(key)
         return
-    pdy, px, _, pgeom, _ = prev
+    pdy, px, _, pgeom = prev[:4]
     if pgeom == geom and pdy.shape[1:] == dy.shape[1:] and px.shape[1:] == x.shape[1:]:
         _wgrad_launch(_cat_batch(pdy, dy), _cat_batch(px, x), w.shape, geom, g)
     else:
@@ -181,10 +198,26 @@ def split_batch(x, B):
 
 
 def _wgrad_flush():
-    cur = torch.cuda.current_stream().cuda_stream
-    for key in [k for k in _wgrad_pending if k[1] == cur]:
-        dy, x, w_shape, geom, g = _wgrad_pending.pop(key)
-        _wgrad_launch(dy, x, w_shape, geom, g)
+    """launch the single contributions the innermost context parked and nobody merged -- each on the stream it was parked on; the
+    current stream then waits for every such stream that is not itself (the optimizer reads .grad behind the context)"""
+    cur = torch.cuda.current_stream()
+    fr = _wgrad_frames[-1]
+    keys, fr.parked = fr.parked, []
+    if len(_wgrad_frames) == 1:                      # a bare flush outside any context: everything that is still parked
+        keys = list(_wgrad_pending)
+    capturing = torch.cuda.is_current_stream_capturing()
+    for key in keys:
+        item = _wgrad_pending.pop(key, None)
+        if item is None:
+            continue                                  # merged with a second contribution meanwhile
+        dy, x, w_shape, geom, g, st = item
+        if st.cuda_stream == cur.cuda_stream:
+            _wgrad_launch(dy, x, w_shape, geom, g)
+        else:
+            with torch.cuda.stream(st):
+                _wgrad_launch(dy, x, w_shape, geom, g)
+            if not capturing:
+                cur.wait_stream(st)
 
 
 @contextlib.contextmanager
@@ -197,13 +230,17 @@ def wgrad_overlap():
         ok = torch.cuda.current_stream().cuda_stream in CAPTURE_WGRAD_OK
     prev, WGRAD_SIDE_STREAM = WGRAD_SIDE_STREAM, ok
     _wgrad_ctx_depth += 1
+    _wgrad_frames.append(_WgradFrame())
     try:
         yield
     finally:
-        _wgrad_flush()                    # parked single contributions (still under this context's stream policy)
-        _wgrad_ctx_depth -= 1
-        WGRAD_SIDE_STREAM = prev
-        join_wgrad()
+        try:
+            _wgrad_flush()                # parked single contributions (still under this context's stream policy)
+        finally:
+            _wgrad_ctx_depth -= 1
+            WGRAD_SIDE_STREAM = prev
+            join_wgrad()
+            _wgrad_frames.pop()
 
 
 def _wgrad_stream():
@@ -230,18 +267,20 @@ def join_wgrad():
     backward on ANOTHER stream than the caller's -- the nodes of a tape recorded on a capture stream (the generator's replayed
     forward, trainer.TrainEngine g_fwd_only) execute on that stream, so their weight gradients went to ITS side stream; joining
     only the caller's pair would let the optimizer read gradients that are still being written."""
+    fr = _wgrad_frames[-1]
     if not _wgrad_streams:
+        del fr.keep[:]
         return
     cur = torch.cuda.current_stream()
     side = _wgrad_streams.get(cur.cuda_stream)
     if side is not None:
         cur.wait_stream(side)
     capturing = torch.cuda.is_current_stream_capturing()
-    for s_ in _wgrad_used:
+    for s_ in fr.used:
         if s_ is not side and not capturing:
             cur.wait_stream(s_)
-    del _wgrad_used[:]
-    del _wgrad_keep[:]
+    del fr.used[:]
+    del fr.keep[:]
 
 
 def _c(t):

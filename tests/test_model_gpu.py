@@ -414,6 +414,43 @@ def test_two_train_steps(mode):
         assert len(eng._bg.get("G", {})) == (1 if eng.g_graphs else 0)      # one generator graph pair, replayed twice
 
 
+def test_parked_weight_gradients_on_the_generator_tape(monkeypatch):
+    """with the generator's forward replayed (MOGAN_G_GRAPHS=2, the default) autograd runs the eager backward
+    on the CAPTURE stream; a weight gradient parked there for merging (ops._wgrad_accumulate: K <= MOGAN_MERGE_WGRAD_K and a weight
+    tensor >= MOGAN_MERGE_WGRAD_W -- at coco_train.yml widths INIT_STAGE_G.upsample1, 5.3 M weights, K = 1024) was flushed by
+    stream key on the MAIN stream, i.e. never: the layer alternated between no and stale gradients.  The threshold is lowered so
+    that the reduced-width generator parks too; three steps of the replayed-forward engine must equal the eager-generator engine
+    parameter for parameter, and nothing may stay parked behind a step."""
+    from mogan_amd.attngan.trainer import TrainEngine
+    from mogan_amd.hip import ops
+    monkeypatch.setattr(ops, "_MERGE_W", 1)
+    bts = [synthetic.to_device(synthetic.make_batch(4, words_num=5, nef=16, seed=300 + s_), DEV) for s_ in range(3)]
+    runs = []
+    for fwd_graph in (False, True):
+        G, Ds, enc = _build_all()
+        eng = TrainEngine(None, enc, G, Ds, use_graph=False, branch_graphs=True)
+        eng.g_graphs, eng.g_fwd_only = fwd_graph, fwd_graph
+        traj = []
+        for bt in bts:
+            eng.step(dict(bt))
+            torch.cuda.synchronize()
+            assert not ops._wgrad_pending, "parked weight gradients left behind a step: %d" % len(ops._wgrad_pending)
+            assert len(ops._wgrad_frames) == 1 and not ops._wgrad_frames[0].keep
+            traj.append({k: v.detach().clone() for k, v in G.named_parameters()})
+        runs.append(traj)
+        if fwd_graph:
+            assert len(eng._bg.get("G", {})) == 1
+    lr = 2e-4
+    for st_, (a, b) in enumerate(zip(*runs)):
+        for k in a:
+            # same kernels, same operands, same order of the sums: the two engines differ in WHERE the launches are queued only
+            # (atomics in the transformer's backward leave last-bit noise, and Adam turns a noise-level gradient's sign into +-lr:
+            # a missing or stale gradient moves EVERY element of its tensor by ~lr)
+            off = float(((a[k] - b[k]).abs() > 0.25 * lr).float().mean())
+            assert off <= 0.02, "step %d, %s: %.1f %% of the parameters differ by > lr/4 between the eager and the " \
+                                "replayed-forward generator" % (st_, k, 100 * off)
+
+
 @pytest.mark.parametrize("B", [4, 20])
 def test_object_pathways_batched_equal_looped(B):
     """The reference's loops over the objects (model.py:105-114, 395-407, 662-672) run as ONE batch of 3*B samples with per-object

@@ -4,7 +4,7 @@ f = glob.glob(sys.argv[1] + "/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"]
-    m = re.search(r"(dconv_\w+|gemm_kernel|sc_\w+|wino_\w+)(<[^>]*>)?", name)
+    m = re.search(r"(dconv_\w+|gemm_kernel|sc_\w+|wino\w+)(<[^>]*>)?", name)
     if not m:
         continue
     k = m.group(0)

@@ -54,7 +54,7 @@ class BasicConv2d(nn.Module):
 _BRANCH_STREAMS = []
 # measured: alone, the captured encoder runs 10 % faster with parallel branches (fwd 5.2 -> 4.7 ms, bwd 6.5 -> 5.8 ms);
 # inside the train step, whose other streams already fill the GPU, it is 2.5 % SLOWER (251.6 vs 257.9 img/s) -> off
-PARALLEL_BRANCHES = os.environ.get("MOGAN_INCEPTION_STREAMS", "0") != "0"
+PARALLEL_BRANCHES = False
 
 
 def _parallel(fns):
@@ -235,7 +235,7 @@ def init_trunk(module):
 #     where that input is 0 (mogan_conv2d_dgrad_ex relu_of), so a gradient buffer is always "already masked";
 #   * eval-mode BN: y = relu(scale * conv(x; W) + shift) forward; backward uses W' = scale * W (precomputed once).
 # Same arithmetic as the modules above up to the rounding of W' (checked against the module path and the CPU restatement).
-FAST_TRUNK = os.environ.get("MOGAN_INCEPTION_FAST", "1") != "0"
+FAST_TRUNK = True
 
 
 class _Slice:
@@ -266,7 +266,7 @@ class _Slice:
         return self.c0 == 0 and self.C == self.t.shape[1] and self.t.is_contiguous()
 
 
-FLIPPED_DGRAD = os.environ.get("MOGAN_INCEPTION_FLIPPED_DGRAD", "1") != "0"
+FLIPPED_DGRAD = True
 
 
 class _FrozenConv:
@@ -304,7 +304,7 @@ class _Op:
         self.k, self.s, self.pad, self.idx = k, s, pad, None
 
 
-GROUPED = os.environ.get("MOGAN_INCEPTION_GROUPED", "1") != "0"      # 0: one launch per convolution (A/B measurements)
+GROUPED = True      # 0: one launch per convolution (A/B measurements)
 
 
 class _Tape:
@@ -638,10 +638,10 @@ class FrozenTrunk:
 #     max-pools keep the kernels FrozenTrunk uses, on the fp32 copies.
 # Same arithmetic as FrozenTrunk up to fp32 reassociation (pool/conv order, K-split order); checked against it and the CPU
 # restatement in tests/.
-PANEL_TRUNK = os.environ.get("MOGAN_INCEPTION_PANELS", "1") != "0"
+PANEL_TRUNK = True
 # blocks a grouped GEMM launch aims at (K-split).  Measured in the B = 16 step: 256 / 128 / none 407 img/s, 512 404-405, 768 402 (alone
 # on the GPU the launches are fastest at 512: 3.0 vs 3.5 ms per step at 128)
-PANEL_TARGET = int(os.environ.get("MOGAN_PT_TARGET", "256"))
+PANEL_TARGET = 256
 
 
 def _up32(n):

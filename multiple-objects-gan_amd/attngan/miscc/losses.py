@@ -108,9 +108,10 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
 # half (round 5): the reference makes two calls (losses.py:146,152), i.e. two sets of batch statistics and two running-
 # statistics updates, real first -- the grouped BatchNorm / deep-block kernels (groups = 2) compute exactly those, while every
 # convolution sees 2B images: the deep layers' weights (up to 300 MB per layer of D_NET256) stream once per direction instead
-# of twice and their GEMMs have twice the columns.  MOGAN_D_PAIR=0: the two calls.  Networks without the PAIRED attribute
-# (D_NET64: the object pathway already runs as a 3-group batch) keep the two calls.
-D_PAIR = os.environ.get("MOGAN_D_PAIR", "0") != "0"
+# of twice and their GEMMs have twice the columns.  OPT-IN and off by default (module attribute, no environment switch; the
+# benchmarked step makes the reference's two calls): measured neutral in the step, profiles/r05_ab.txt; kept under test.  Networks
+# without the PAIRED attribute (D_NET64: the object pathway already runs as a 3-group batch) always keep the two calls.
+D_PAIR = False
 
 
 def paired(netD):
@@ -140,8 +141,8 @@ def _paired_features(netD, real_imgs, fake_imgs):
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels, gpus=None,
                        local_labels=None, transf_matrices=None, transf_matrices_inv=None, real_features=None):
     """losses.py:136-174.  D(real) and D(fake.detach()) are two separate calls in the reference (separate BN batch
-    statistics) -- here one pass over [real; fake] with per-half statistics where the network supports it and MOGAN_D_PAIR=1
-    (see D_PAIR); real_labels/fake_labels are the constant 1/0 vectors of prepare_labels."""
+    statistics) -- and so they are here by default; with losses.D_PAIR = True (opt-in) one pass over [real; fake] with per-half
+    statistics where the network supports it; real_labels/fake_labels are the constant 1/0 vectors of prepare_labels."""
     if real_features is None and local_labels is None and paired(netD) and real_imgs.shape == fake_imgs.shape:
         real_features, fake_features = _paired_features(netD, real_imgs, fake_imgs)
     else:
@@ -205,7 +206,8 @@ def discriminator_loss_fake(netD, fake_imgs, conditions, pending, local_labels=N
     return ops.scalar_sum([cond_fake_errD], [0.5])
 
 
-D_SPLIT = os.environ.get("MOGAN_D_SPLIT", "0") != "0"
+# The discriminator loss in two halves (round 5): OPT-IN and off by default (module attribute; -1 % in the step, profiles/r05_ab.txt).
+D_SPLIT = False
 
 
 def split_d_loss():

@@ -24,7 +24,7 @@ from . import inception
 MAX_OBJECTS = 3
 # The reference's python loops over the objects as ONE batch of MAX_OBJECTS*B samples (object-major) with per-object BatchNorm
 # statistics (FusedSeq(..., groups=G)); 0 = the literal loops (same results; A/B switch)
-BATCH_OBJECTS = os.environ.get("MOGAN_OBJ_BATCH", "1") != "0"
+BATCH_OBJECTS = True     # (module attribute: False = the reference's literal per-object loops; tests compare both)
 
 
 def stn(image, transformation_matrix, size):

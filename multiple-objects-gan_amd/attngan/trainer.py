@@ -21,6 +21,7 @@ MI355X-first differences (results identical to the reference's single-GPU step o
     step is a few thousand short launches at 4x4..16x16 resolution that are otherwise launch-bound.
 """
 import glob
+import logging
 import os
 import time
 
@@ -460,6 +461,8 @@ def create_engine_streams(n_discriminators=3, touch=True):
 
 
 class TrainEngine:
+    G_GRAPH_VARIANTS = 4       # generator forward graphs kept per engine, one per shape of the text tensors (see _g_graph_for)
+
     """Device-side state of one rank: networks, flat optimizers, DP communicator, optional hipGraph."""
 
     def __init__(self, text_encoder, image_encoder, netG, netsD, distributed=False, use_graph=False, branch_graphs=None):
@@ -478,7 +481,7 @@ class TrainEngine:
         # Inception/DAMSM branch) run on side streams so that their many small launches overlap; captured, they
         # become parallel branches of the hipGraph.  MOGAN_STREAMS=0 keeps everything on one stream.
         self.graph_encoder = os.environ.get("MOGAN_GRAPH_ENCODER", "1") != "0" and not use_graph
-        self.early_damsm_bwd = os.environ.get("MOGAN_EARLY_DAMSM_BWD", "1") != "0"
+        self.early_damsm_bwd = True      # the DAMSM / Inception data gradient does not wait for errG_total.backward()
         self._enc_graphs = {}
         self.multi_stream = os.environ.get("MOGAN_STREAMS", "1") != "0"
         # Branch graphs (single process, multi-stream, not the whole-step graph): every discriminator branch -- D_i(real);
@@ -496,27 +499,24 @@ class TrainEngine:
             branch_graphs = False
         self.branch_graphs = bool(branch_graphs) and self.multi_stream and not use_graph
         # The generator: MOGAN_G_GRAPHS = 2 (default since round 5) replays its FORWARD as a hipGraph (one per shape of the text
-        # tensors, at most MOGAN_G_GRAPH_VARIANTS = 4; other shapes run eagerly) and keeps the backward eager -- on the autograd
+        # tensors, at most TrainEngine.G_GRAPH_VARIANTS = 4; further shapes run eagerly, with a logged warning) and keeps the backward eager -- on the autograd
         # tape recorded during the capture (retain_graph; the static inputs are refreshed through .data so that the tape's saved
         # tensors keep their version), so the weight gradients still overlap the data-gradient chain on their side stream and the
         # data-parallel reducers still see every gradient as it is queued.  Host enqueue per step 29.8 -> 20.8 ms at B = 16 (12.7 ->
         # 8.0 at B = 4, 55.6 -> 37.0 at B = 32), throughput +0.5 % at B = 16 / 32, equal at B = 4 / 8 (profiles/r05_ab.txt).
         # 1 (round 3, single process only): forward AND backward + Adam + EMA as two hipGraphs -- host enqueue 17.6 ms, but the
-        # weight gradients then run in line: 407.7 vs 426.0 img/s (421.1 with the fork captured, MOGAN_G_WGRAD_FORK=1).  0: eager.
+        # weight gradients then run in line: 407.7 vs 426.0 img/s.  0: eager.
         gmode = os.environ.get("MOGAN_G_GRAPHS", "2")
         self.g_fwd_only = gmode == "2"
         self.g_graphs = self.branch_graphs and gmode != "0" and (self.g_fwd_only or not self.distributed)
         self._bg = None
+        self._g_refused = set()
         if torch.cuda.is_available() and self.multi_stream and not use_graph:
             create_engine_streams(len(netsD))       # (a no-op when the entry point has done it before the process group came up)
         # the discriminator loss in two halves: the real-image terms evaluated and back-propagated ahead of the generator's
-        # forward (miscc/losses.py: discriminator_loss_real / _fake; MOGAN_D_SPLIT=0: one loss, one backward after the forward)
+        # forward (miscc/losses.py: discriminator_loss_real / _fake) -- opt-in, losses.D_SPLIT; the default is one loss, one backward after the forward
         self.split_d = self.multi_stream and split_d_loss()
         self.side = [_engine_stream(("side", i)) for i in range(len(netsD) + 1)]
-        bmap = os.environ.get("MOGAN_BRANCH_MAP")          # experiment: "0,0,1,0" = branches (D64, D128, D256, Inception) -> stream
-        if bmap:
-            ids = [int(v) for v in bmap.split(",")]
-            self.side = [self.side[k] for k in ids]           # (the engine's own branch streams: their queue layout stays)
         # stream creation order fixes the stream -> hardware-queue map (see ops.precreate_wgrad_stream): branch streams,
         # then the weight-gradient streams in the order the branches run (D256, D128, D64, generator), communication
         # streams last -- measured: with the communication streams created in between, the generator's wgrad stream landed
@@ -623,9 +623,6 @@ class TrainEngine:
             sample = torch.zeros(key, dtype=torch.float32, device=fake_img.device, requires_grad=True)
             # a plain function, not the module: make_graphed_callables would otherwise patch enc.forward in place
             from ..hip import lib
-            t = os.environ.get("MOGAN_ENC_SPLIT_TARGET")
-            if t:
-                lib.call("mogan_stream_set_split_target", lib.stream_ptr(), int(t))
             with lib.capture_guard():
                 g = torch.cuda.make_graphed_callables(lambda x: enc(x), (sample,))
             self._enc_graphs[key] = g
@@ -636,7 +633,7 @@ class TrainEngine:
 
     def _d_real(self, i, b, sent_emb=None):
         """zero_grad + the real-image half of D_i's update: independent of the generator, so it runs beside the G forward (and the
-        tail of the previous step).  Split form (miscc/losses.split_d_loss, the default): the real-image terms of the loss are
+        tail of the previous step).  Split form (miscc/losses.split_d_loss; opt-in, off by default): the real-image terms of the loss are
         evaluated AND back-propagated here -- returns ("split", R, pending running-statistics updates); otherwise only D_i(real)
         is evaluated and its features are returned (None with the paired pass)."""
         from .miscc.losses import _call_d, paired
@@ -690,7 +687,7 @@ class TrainEngine:
             self._chain = getattr(self, "_chain", [])
             self._chain.append((name, ev))
             return
-        if not os.environ.get("MOGAN_PHASE_TIMES"):
+        if not getattr(self, "phase_times", False):       # (diagnostic attribute, tools/phase_times.py: host-synchronised phase times)
             return
         torch.cuda.synchronize()
         now = time.perf_counter()
@@ -734,9 +731,6 @@ class TrainEngine:
             from ..hip import ops as _ops
             streams = [torch.cuda.current_stream()] + list(self.side)
             streams += [_ops._wgrad_streams[s.cuda_stream] for s in streams if s.cuda_stream in _ops._wgrad_streams]
-            if os.environ.get("MOGAN_SPLIT_PER_STREAM", "0") != "0":      # (measured 1.4 % slower than the plain default)
-                for s in streams:
-                    lib.call("mogan_stream_set_split_target", s.cuda_stream, target)
             # streams this engine does not own (torch's internal capture stream of the encoder graph) follow the default
             lib.call("mogan_gemm_set_split_target", target)
         real_labels = b["z"].new_ones(B)
@@ -909,8 +903,7 @@ class TrainEngine:
             self.reducers[id(o)].active = False
         for i in range(nD):
             s = self.side[i]
-            if os.environ.get("MOGAN_BG_WGRAD", "0") != "0":      # 1: fork the weight gradients inside the branch graphs (measured: a forked graph replays slowly, 47.1 vs 42.1 ms per step)
-                ops.CAPTURE_WGRAD_OK.add(s.cuda_stream)
+            # (weight gradients stay in line inside the branch graphs: a forked graph replays slowly, 47.1 vs 42.1 ms per step, round 3)
             kw = dict(local_labels=st["label_one_hot"], transf_matrices=st["tm"], transf_matrices_inv=st["tmi"]) if i == 0 else {}
             pool = torch.cuda.graph_pool_handle()
             calls0 = list(counter.calls)
@@ -981,8 +974,6 @@ class TrainEngine:
             main_w = ops.precreate_wgrad_stream(torch.cuda.current_stream())
             ops._wgrad_streams.setdefault(self._g_cap_stream.cuda_stream, main_w)
         counter, cap = self.bn_counter, self._g_cap_stream
-        if os.environ.get("MOGAN_G_WGRAD_FORK", "0") != "0":      # experiment: fork the weight gradients inside the backward graph
-            ops.CAPTURE_WGRAD_OK.add(cap.cuda_stream)
         calls0 = list(counter.calls)
         pool = torch.cuda.graph_pool_handle()
         gF, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -1025,8 +1016,18 @@ class TrainEngine:
         key = (tuple(b["words_embs"].shape), tuple(b["mask"].shape))
         table = self._bg.setdefault("G", {})
         g = table.get(key)
-        if g is None and len(table) < int(os.environ.get("MOGAN_G_GRAPH_VARIANTS", "4")):
-            g = table[key] = self._g_capture(b)
+        if g is None:
+            if len(table) < self.G_GRAPH_VARIANTS:
+                # (a variant keeps the autograd tape of one generator forward -- all activations of a B = 16 256x256 pass,
+                # ~1.7 GB at coco_train.yml widths -- alive for the life of the engine, and its capture synchronises the device)
+                logging.getLogger("mogan").info("generator forward graph: capturing variant %d of at most %d for text shapes %r",
+                                                len(table) + 1, self.G_GRAPH_VARIANTS, key)
+                g = table[key] = self._g_capture(b)
+            elif key not in self._g_refused:
+                self._g_refused.add(key)
+                logging.getLogger("mogan").warning("generator forward graph: text shapes %r run eagerly (%d variants captured already; "
+                                                   "pad the captions to fewer lengths or raise TrainEngine.G_GRAPH_VARIANTS)",
+                                                   key, len(table))
         return g
 
     def _branch_graph_step(self, b, real_labels, fake_labels, match_labels):
@@ -1109,8 +1110,6 @@ class TrainEngine:
         def branch(i):
             s = self.side[i]
             s.wait_stream(cur)
-            if os.environ.get("MOGAN_EXP_SKIP") == "d%d" % i:      # experiment only: the step without this D's update
-                return
             with torch.cuda.stream(s):
                 st["fake"][i].copy_(fake_imgs[i].detach())
                 bg["gU"][i].replay()
@@ -1129,13 +1128,9 @@ class TrainEngine:
         s.wait_stream(cur)
         with torch.cuda.stream(s):
             img = fake_imgs[nD - 1].detach().requires_grad_(True)
-            if os.environ.get("MOGAN_EXP_SKIP") == "damsm":       # experiment only: the step without its Inception/DAMSM branch
-                w_loss = s_loss = kl_zero = torch.zeros((), device=img.device)
-                damsm_grad = torch.zeros_like(img)
-            else:
-                w_loss, s_loss = generator_damsm_branch(self._encoder(img), img, b["words_embs"], b["sent_emb"], match_labels,
-                                                        b["cap_lens"], b.get("class_ids"), B)
-                damsm_grad, = torch.autograd.grad(ops.scalar_sum([w_loss, s_loss]), img)
+            w_loss, s_loss = generator_damsm_branch(self._encoder(img), img, b["words_embs"], b["sent_emb"], match_labels,
+                                                    b["cap_lens"], b.get("class_ids"), B)
+            damsm_grad, = torch.autograd.grad(ops.scalar_sum([w_loss, s_loss]), img)
             parts["w_loss"], parts["s_loss"] = w_loss.detach(), s_loss.detach()
         for i in range(nD - 1)[::-1]:
             branch(i)
@@ -1312,14 +1307,6 @@ class TrainEngine:
         for dst, src in zip(st["imgs"], b["imgs"]):
             dst.copy_(src)
         self._graph.replay()
-        if os.environ.get("MOGAN_GRAPH_SYNC"):
-            torch.cuda.synchronize()
-        if os.environ.get("MOGAN_GRAPH_NANCHECK"):
-            flags = [torch.isnan(o.p).any() for o in [self.optG] + self.optDs]
-            flags += [torch.isnan(o.g).any() for o in [self.optG] + self.optDs]
-            flags += [torch.isnan(st[k]).any() for k in ("z", "eps", "words_embs", "sent_emb", "tm", "tmi")]
-            flags += [torch.isnan(self._graph_out[k]).any() for k in ("fake64", "errD0", "g_loss0", "kl")]
-            self._nan_log = getattr(self, "_nan_log", []) + [torch.stack(flags)]
         self.last = self._graph_out
         return self.last
 

@@ -767,7 +767,7 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     const long long tiles = (long long)p.B * p.tiles_x * p.tiles_y * cdiv(p.Cout, bm) * p.npar;
     const int nchunk = p.Cin / CK;
     int nsplit = 1;
-    static const int fwd_target = getenv("MOGAN_DSPLIT_FWD") ? atoi(getenv("MOGAN_DSPLIT_FWD")) : 512;
+    constexpr int fwd_target = 512;
     if (tiles < 384 && nchunk >= 8) nsplit = (int)std::min<long long>(cdiv(fwd_target, tiles), nchunk / 4);
     const long long y_numel = (long long)p.B * p.Cout * p.yH * p.yW;
 #if MOGAN_X6
@@ -828,7 +828,7 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     // block target of the pixel-tile split.  640 was the isolated optimum; in the step these launches run on the weight-gradient side
     // stream beside the generator's data-gradient chain, and fewer, longer blocks leave it more of the chip: 384 -> 402.1 / 400.3 /
     // 409.8 against 398.0 / 398.8 / 407.3 img/s (448: 401.2 / 401.1, 320: 398.2 / 400.1, 256: 394.6 / 395.1; tools/split_probe.sh)
-    static const int wg_target = getenv("MOGAN_DSPLIT_WG") ? atoi(getenv("MOGAN_DSPLIT_WG")) : 384;
+    constexpr int wg_target = 384;
     int nsplit = (int)std::min<long long>(cdiv(wg_target, blocks), std::max(1, p.ntiles / 2));
     if (nsplit > 1) {
         const long long fit = ws ? (long long)(ws_bytes / (sizeof(float) * (size_t)w_numel)) : 0;
@@ -885,7 +885,7 @@ int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin
     // 4x4 s2: round 1 (native fp32 MFMA) took it only at >= 64-pixel rows (124 vs 98 TF against the implicit GEMM at 64x64 output,
     // 98 vs 98 at 32x32, 90 vs 98 at 16x16: more M-blocks re-reading the same halo tile); with the pre-split filters of the
     // split-bf16 build it wins down to 16-pixel rows in the step (339.2 / 337.1 vs 337.8 / 335.6 img/s; MOGAN_DCONV_K44_MINOW)
-    static const int k44_min_ow = getenv("MOGAN_DCONV_K44_MINOW") ? atoi(getenv("MOGAN_DCONV_K44_MINOW")) : 16;
+    constexpr int k44_min_ow = 16;
     if (k44 && OW < k44_min_ow) return 0;
     // 4x4 s2: chunks of 4 channels (32 k-steps, like the 36 of a 3x3 chunk of 8) keep the staging registers and the
     // double-buffered LDS images (2 x 36 KB) within two blocks per CU

@@ -358,7 +358,7 @@ int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, in
 #if MOGAN_X6
     // MOGAN_DCONV2: 0 = off, 1 = 8 x 32 tiles of stride-1 filters only (the first form of this kernel), 2 (default) = also the
     // 16 x 16 tiles and the space-to-depth forward of the 4x4 s2 convolutions
-    static const int on = getenv("MOGAN_DCONV2") ? atoi(getenv("MOGAN_DCONV2")) : 2;
+    constexpr int on = 2;
     if (!on || (on < 2 && (wmode == 3 || (OW % 32) != 0))) return 0;
     // wmode 3: the forward of a 4x4 s2 p1 convolution (KH = KW = 4, pt = pl = 1 on entry) = a 2 x 2 filter over the space-to-depth
     // image of the padded input, 4 Cin channels, no padding of its own

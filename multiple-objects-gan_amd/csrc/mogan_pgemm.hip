@@ -1010,7 +1010,7 @@ int mogan_conv2d_wgrad_pk(const float* dy, const float* x, float* dw, int B, int
 }
 
 int mogan_pk_group(int n, MoganPkArgs* args, hipStream_t stream) {
-    static const int env_tile = [] { const char* e = getenv("MOGAN_PK_GROUP_TILE"); return e ? atoi(e) : -1; }();
+    constexpr int env_tile = -1;
     g_pk_group_tile = env_tile;
     if (n <= 0 || n > PK_MAXG || !args) return MOGAN_ERR_SHAPE;
     PkGroup g{};

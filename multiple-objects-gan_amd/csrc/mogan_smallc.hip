@@ -557,7 +557,7 @@ int mogan_smallc_fwd_try(const float* x, const float* w, float* y, int B, int Ci
         return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
     }
     if (!(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0 && Cout >= 1 && Cout <= 4)) return 0;
-    static const int w4 = getenv("MOGAN_SC_W4") ? atoi(getenv("MOGAN_SC_W4")) : 1;
+    constexpr int w4 = 1;
     if (w4 && (Ws % 128) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {          // four pixels per thread, 8 x 128 tiles
         const int txs = Ws / 128, tys = cdiv(Hs, TR);
         const long long nb4 = (long long)B * txs * tys;

@@ -1062,7 +1062,7 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
                          int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
     // MOGAN_WINO_WGRAD=0 falls back to the direct kernel (2 = timing aid: main kernel without the finish pass)
-    static const int wg_on = getenv("MOGAN_WINO_WGRAD") ? atoi(getenv("MOGAN_WINO_WGRAD")) : 1;
+    constexpr int wg_on = 1;
     if (!g_wino || !wg_on || !(KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1 && up == 0)) return 0;
     if (Cin < 32 || Cout < 64 || (H % 2) || (W % (2 * WCT)) || (W % 2)) return 0;
     if ((((uintptr_t)dy) & 7) != 0) return 0;
@@ -1074,7 +1074,7 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
     // this kernel runs on the weight-gradient side stream BESIDE the generator's data-gradient chain: with 256 persistent blocks it
     // holds every CU for ~240 us and the chain's short kernels queue behind it; 192 blocks leave a quarter of the CUs to the chain:
     // 405.0 / 406.6 vs 402.3 / 399.3 img/s (224: 404.4, 160: 403.6; tools/wino_wg_blocks_probe.sh) -- the default since round 3
-    static const int wg_blocks = getenv("MOGAN_WINO_WG_BLOCKS") ? atoi(getenv("MOGAN_WINO_WG_BLOCKS")) : 192;
+    constexpr int wg_blocks = 192;
     int nsplit = wg_blocks / tiles_mn;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nchunk / 8) nsplit = nchunk / 8 > 0 ? nchunk / 8 : 1;

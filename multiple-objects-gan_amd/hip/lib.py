@@ -177,13 +177,10 @@ def load():
             fn.restype = _RESTYPE.get(name, I)
         _lib = lib
         _register_tuned(lib)
-        if os.environ.get("MOGAN_GROUP_MIN_TILES"):
-            lib.mogan_gemm_group_min_tiles(int(os.environ["MOGAN_GROUP_MIN_TILES"]))
     return _lib
 
 
-TUNED_CSV = os.environ.get("MOGAN_TUNED_CSV") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                                                            "tuned_gemm_gfx950.csv")
+TUNED_CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemm_gfx950.csv")
 
 
 def _register_tuned(lib):
@@ -238,7 +235,7 @@ def hw_queue_defaults():
     process kind (round 4: (4, 0) single process, (4, 3) member of a process group; +-8 %).  Now every entry point creates and
     touches the engine's streams in ONE fixed order right after torch.cuda.set_device, before torch.distributed exists
     (attngan/trainer.create_engine_streams, ENGINE_STREAM_ORDER): 437 img/s single process, 435 as member of a 1-rank RCCL group
-    (profiles/r05_queue_table.csv).  MOGAN_HW_QUEUES / MOGAN_RESERVED_STREAMS (or GPU_MAX_HW_QUEUES itself) still override."""
+    (profiles/r05_queue_table.csv).  MOGAN_HW_QUEUES (or GPU_MAX_HW_QUEUES itself) still overrides the queue count."""
     return (os.environ.get("MOGAN_HW_QUEUES", "4"), 0)
 
 
@@ -250,9 +247,9 @@ def configure_hw_queues():
 
 def reserve_hw_queues(n=None):
     """Call right after torch.cuda.set_device and before any other stream exists: n idle non-blocking HIP streams that
-    take the first round of queue slots (MOGAN_RESERVED_STREAMS overrides n; 0 disables)."""
+    take the first round of queue slots (0, the default of every kind of process since round 5, disables)."""
     if n is None:
-        n = int(os.environ.get("MOGAN_RESERVED_STREAMS", str(hw_queue_defaults()[1])))
+        n = int(hw_queue_defaults()[1])
     if _reserved or n <= 0:
         return
     # through libmogan_hip.so, i.e. in the HIP runtime instance torch itself uses (a second copy of libamdhip64 loaded by

@@ -113,10 +113,10 @@ MERGE_WGRAD = os.environ.get("MOGAN_MERGE_WGRAD", "1") != "0"
 _wgrad_pending = {}
 # under hipGraph capture too (the branch graphs of trainer.TrainEngine replay the merged launches): the parked contribution and
 # the concatenated operands live in the graph's memory pool
-MERGE_WGRAD_CAPTURED = os.environ.get("MOGAN_MERGE_WGRAD_CAPTURED", "1") != "0"
+MERGE_WGRAD_CAPTURED = True
 _wgrad_ctx_depth = 0         # parking needs somebody to flush: only inside `with wgrad_overlap():`
-_MERGE_K = int(os.environ.get("MOGAN_MERGE_WGRAD_K", "2048"))
-_MERGE_W = int(os.environ.get("MOGAN_MERGE_WGRAD_W", str(1 << 21)))
+_MERGE_K = 2048
+_MERGE_W = 1 << 21
 
 
 def _wgrad_launch(dy, x, w_shape, geom, g):
@@ -297,7 +297,7 @@ def conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, up):
 
 # nearest-x2 upsample + conv3x3(p1) runs as the transposed 4x4-s2 convolution (include/mogan_hip.h: mogan_upconv3x3_*):
 # 2.25x fewer FLOPs.  MOGAN_UPCONV4=0 keeps the fused-upsample 3x3 kernels (the kernel tests compare both).
-UPCONV4 = os.environ.get("MOGAN_UPCONV4", "1") != "0"
+UPCONV4 = True
 
 
 def _is_upconv(w_shape, stride, ph, pw, up):
@@ -311,9 +311,9 @@ def _is_upconv(w_shape, stride, ph, pw, up):
 # copies in use right after each optimizer step (one pack per weight version, used by the real, the fake and the generator
 # pass); anything else that writes weights calls FlatAdam.touch() / invalidate_all_packs().  A parameter without the
 # attribute (plain modules, the kernel tests' default) takes the unpacked kernels.
-PK_ENABLED = os.environ.get("MOGAN_PK", "1") != "0"
+PK_ENABLED = True
 PK_STATS = {"fwd": 0, "dgrad": 0, "wgrad": 0, "packs": 0}      # launches through the packed path (tests, diagnostics)
-PK_WGRAD = os.environ.get("MOGAN_PK_WGRAD", "1") != "0"          # the deep layers' weight gradients on the packed kernels too
+PK_WGRAD = True          # the deep layers' weight gradients on the packed kernels too
 _pk_wgrad_elig = {}
 _PK_GLOBAL = [0]
 
@@ -677,7 +677,7 @@ def conv2d(x, w, bias=None, stride=1, padding=0, up=False):
 
 # ------------------------------------------------------------------------------- deep block: conv + BN + activation
 DEEP_STATS = {"fwd": 0, "bwd": 0, "panel_hits": 0}
-DEEP_ENABLED = os.environ.get("MOGAN_DEEP", "1") != "0"       # 0: packed GEMMs, but BatchNorm / activation as separate launches
+DEEP_ENABLED = True       # 0: packed GEMMs, but BatchNorm / activation as separate launches
 _deep_elig = {}
 
 

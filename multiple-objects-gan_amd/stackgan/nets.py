@@ -118,7 +118,7 @@ class D_GET_LOGITS(nn.Module):
 
 # The reference's python loops over the objects as ONE batch of K*B samples (object-major) with per-object BatchNorm statistics
 # (FusedSeq(..., groups=K): SURVEY F11), as in attngan/model.py; MOGAN_OBJ_BATCH=0 = the literal loops (same results; A/B switch)
-BATCH_OBJECTS = os.environ.get("MOGAN_OBJ_BATCH", "1") != "0"
+BATCH_OBJECTS = True     # (module attribute: False = the literal per-object loops; tests compare both)
 
 
 def _objects_first(t, K):

@@ -114,25 +114,89 @@ class AdamDeltaCheck:
     lr=2e-4 Adam step was applied, so the update is judged on parameter DELTAS at the probe's 32 sampled
     elements: delta = post - initial (initial weights are deterministic, helpers.det_fill_state).  Adam's
     first steps move every element by ~lr*sign(g); where |g| sits at the fp32 noise floor the sign is not
-    reproducible, so a small fraction of mismatching elements is tolerated per network --
-    but a missing, doubled or mis-scaled step fails every element."""
+    reproducible.  Round 6: instead of tolerating a blanket fraction of
+    mismatches, an element is JUDGED only where the fp64 oracle's gradient exceeds the measured fp32 noise
+    floor in every step so far (`add(..., judged=mask)`, helpers.oracle_gradient_noise) -- and of the judged
+    elements at least 99 % must lie within lr/4 of the reference's delta.  Without a mask every element is
+    judged (the CPU oracle tests, whose arithmetic is the reference's own)."""
 
     def __init__(self, lr=2e-4):
-        self.lr, self.n, self.bad, self.moved = lr, 0, 0, 0
+        self.lr, self.n, self.bad, self.moved, self.total = lr, 0, 0, 0, 0
 
-    def add(self, init_probe, got_probe, want_probe):
+    def add(self, init_probe, got_probe, want_probe, judged=None):
         d_got = np.asarray(got_probe[3:], np.float64) - np.asarray(init_probe[3:], np.float64)
         d_want = np.asarray(want_probe[3:], np.float64) - np.asarray(init_probe[3:], np.float64)
-        self.n += d_want.size
-        self.bad += int((np.abs(d_got - d_want) > 0.25 * self.lr).sum())
-        self.moved += int((np.abs(d_want) > 0.5 * self.lr).sum())
+        self.total += d_want.size
+        if judged is None:
+            judged = np.ones(d_want.shape, bool)
+        self.n += int(judged.sum())
+        self.bad += int(((np.abs(d_got - d_want) > 0.25 * self.lr) & judged).sum())
+        self.moved += int(((np.abs(d_want) > 0.5 * self.lr) & judged).sum())
 
-    def check(self, max_bad_frac, what=""):
-        assert self.moved > 0.5 * self.n, "%s: the reference moved only %d of %d sampled elements" % (
+    def check(self, max_bad_frac, what="", min_judged_frac=0.0):
+        assert self.n >= min_judged_frac * self.total and self.n > 0, "%s: only %d of %d sampled elements lie above the noise floor" % (
+            what, self.n, self.total)
+        assert self.moved > 0.5 * self.n, "%s: the reference moved only %d of %d judged elements" % (
             what, self.moved, self.n)
         frac = self.bad / max(1, self.n)
-        assert frac <= max_bad_frac, "%s: %d of %d sampled parameter deltas differ by > lr/4 (%.1f%% > %.1f%%)" % (
+        assert frac <= max_bad_frac, "%s: %d of %d judged parameter deltas differ by > lr/4 (%.1f%% > %.1f%%)" % (
             what, self.bad, self.n, 100 * frac, 100 * max_bad_frac)
+
+
+_NOISE_CACHE = {}
+
+
+def oracle_gradient_noise(ocfg, build, batches, margin=8.0):
+    """Which sampled parameter elements have a REPRODUCIBLE Adam update?  Runs the oracle's train trajectory (oracle/
+    attngan_oracle.train_step) twice on the given batches -- in fp32 and in fp64 -- and records, right before every Adam
+    step, the gradient at the probe's sample positions.  Per tensor and step the fp32 noise floor is the rms of (g32 - g64)
+    over the samples; an element is judged at step s if |g64| > margin * floor in every step <= s (the second Adam step
+    depends on both gradients).  Returns {(step, net name, key): bool mask over the 32 probe samples} and the distance of
+    the two runs' losses per step ({step: {loss name: relative difference}}) -- the arithmetic's own noise envelope.
+    `build(dtype)` -> (G, [D0, D1, D2], encoder) of oracle nets at that precision; names are "G", "D0", ..."""
+    import copy
+    import torch
+    from oracle import attngan_oracle as O
+    key = (id(build), len(batches), margin)
+    if key in _NOISE_CACHE:
+        return _NOISE_CACHE[key]
+    runs = {}
+    for dt in (torch.float32, torch.float64):
+        G, Ds, enc = build(dt)
+        names = {id(G): "G"}
+        names.update({id(d): "D%d" % i for i, d in enumerate(Ds)})
+        st = O.TrainState(G, Ds, ocfg)
+        rec, losses = {}, {}
+        orig = O.adam_step
+
+        def spy(net, ast, lr, *a, _rec=rec, **kw):
+            for k, p_ in O.parameters(net):
+                if p_.grad is not None:
+                    _rec[(ast["step"], names[id(net)], k)] = probe(p_.grad)[3:]
+            return orig(net, ast, lr, *a, **kw)
+        O.adam_step = spy
+        try:
+            for s_, bt in enumerate(batches):
+                b = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else copy.copy(v)) for k, v in bt.items()}
+                b["imgs"] = [t.to(dt) for t in bt["imgs"]]
+                logs = O.train_step(st, b, enc)
+                losses[s_] = {k: float(v) for k, v in logs.items() if not torch.is_tensor(v)}
+        finally:
+            O.adam_step = orig
+        runs[dt] = (rec, losses)
+    r32, r64 = runs[torch.float32][0], runs[torch.float64][0]
+    masks = {}
+    for (s_, n, k), g64 in r64.items():
+        ok = np.ones(g64.shape, bool)
+        for t in range(s_ + 1):
+            a, b = r64[(t, n, k)], r32[(t, n, k)]
+            floor = float(np.sqrt(np.mean((a - b) ** 2))) + 1e-300
+            ok &= np.abs(a) > margin * floor
+        masks[(s_, n, k)] = ok
+    l32, l64 = runs[torch.float32][1], runs[torch.float64][1]
+    envelope = {s_: {k: abs(l32[s_][k] - v) / (abs(v) + 1e-30) for k, v in l64[s_].items()} for s_ in l64}
+    _NOISE_CACHE[key] = (masks, envelope)
+    return masks, envelope
 
 
 # ---------------------------------------------------------------------- full-width fixtures

@@ -204,9 +204,9 @@ def test_workspace_is_separate_for_captured_launches(monkeypatch):
 def test_hw_queue_configuration_respects_the_user(monkeypatch):
     """hip/lib.py:configure_hw_queues -- GPU_MAX_HW_QUEUES is only defaulted (4 queues, no idle streams first: ONE default for a
     single process and for a member of a process group since round 5, the engine's streams being created in a fixed order before
-    the group exists), never overridden; reserve_hw_queues(0) and MOGAN_RESERVED_STREAMS=0 do not touch the library."""
+    the group exists), never overridden; reserve_hw_queues(0) and the default reserve_hw_queues() do not touch the library."""
     from mogan_amd.hip import lib
-    for k in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE", "MOGAN_FORCE_DIST", "MOGAN_RESERVED_STREAMS"):
+    for k in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE", "MOGAN_FORCE_DIST"):
         monkeypatch.delenv(k, raising=False)
     assert lib.hw_queue_defaults() == ("4", 0)
     lib.configure_hw_queues()
@@ -225,7 +225,6 @@ def test_hw_queue_configuration_respects_the_user(monkeypatch):
     monkeypatch.setattr(lib, "load", lambda: (_ for _ in ()).throw(AssertionError("library touched")))
     monkeypatch.setattr(lib, "_reserved", [])
     lib.reserve_hw_queues(0)
-    monkeypatch.setenv("MOGAN_RESERVED_STREAMS", "0")
     lib.reserve_hw_queues()
     assert lib._reserved == []
 

@@ -172,6 +172,20 @@ def _build_all():
     return G.to(DEV).train(), Ds, enc.to(DEV).eval()
 
 
+def _noise_masks():
+    """helpers.oracle_gradient_noise for the two-step trajectory of test_two_train_steps (CPU oracle in fp32 and fp64, cached)."""
+    import test_oracle_golden as tog
+    from helpers import oracle_gradient_noise
+    ocfg = tog.SMALL
+    bts = [synthetic.make_batch(4, words_num=5, nef=16, seed=100 + s_) for s_ in range(2)]
+    return oracle_gradient_noise(ocfg, _oracle_build, bts)
+
+
+def _oracle_build(dt):
+    import test_oracle_golden as tog
+    return tog._build_all(tog.SMALL, dt)
+
+
 def test_losses():
     from mogan_amd.attngan.miscc import losses as L
     g = golden("losses")
@@ -383,10 +397,12 @@ def test_two_train_steps(mode):
             continue                                   # straight into step 1: its D_i(real) replays overlap step 0's tail
         torch.cuda.synchronize()
         for st_, lg in enumerate(all_logs):
+            # step 1 gets twice step 0's tolerance (round 5: ten times): the fp32 and the fp64 run of the oracle's own trajectory
+            # differ by <= 4.2e-6 relative in every loss of step 1 (helpers.oracle_gradient_noise: the arithmetic's envelope)
             for k in ("errD0", "errD1", "errD2", "kl"):
-                np.testing.assert_allclose(float(lg[k]), float(g["s%d_" % st_ + k]), rtol=1e-4 * (1 + 9 * st_), err_msg=k)
-            np.testing.assert_allclose(float(lg["errG"]), float(g["s%d_errG" % st_]), rtol=2e-4 * (1 + 9 * st_))
-            close(lg["fake64"], g["s%d_fake64" % st_], 2e-4 * (1 + 9 * st_), 1e-3)
+                np.testing.assert_allclose(float(lg[k]), float(g["s%d_" % st_ + k]), rtol=1e-4 * (1 + st_), err_msg=k)
+            np.testing.assert_allclose(float(lg["errG"]), float(g["s%d_errG" % st_]), rtol=2e-4 * (1 + st_))
+            close(lg["fake64"], g["s%d_fake64" % st_], 2e-4 * (1 + st_), 1e-3)
         p = "s%d_" % step
         # Adam's first steps move every element by ~lr*sign(g): where |g| is at the fp32 noise floor the
         # sign is not reproducible, which shows on the tiny 1-D tensors (a 12-element BN
@@ -404,12 +420,15 @@ def test_two_train_steps(mode):
                                 what="D%d %s" % (i, k))
         for (k, _), a in zip(G.named_parameters(), eng.optG.ema_params()):
             probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], 1e-4, what="ema " + k)
-        # the Adam update itself, judged on parameter deltas (see helpers.AdamDeltaCheck)
+        # the Adam update itself, judged on parameter deltas (see helpers.AdamDeltaCheck): every sampled element whose fp64-oracle
+        # gradient lies above the measured fp32 noise floor in all steps so far, 99 % of those within lr/4 of the reference's delta
+        # (round 5 allowed a blanket 15 % / 5 % of all elements)
+        masks, _ = _noise_masks()
         for n, net in nets:
             deltas = AdamDeltaCheck(lr=2e-4)
             for k, v in net.named_parameters():
-                deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))])
-            deltas.check(0.15 if n == "G" else 0.05, what="%s step %d" % (n, step))
+                deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))], judged=masks[(step, n, k)])
+            deltas.check(0.01, what="%s step %d" % (n, step), min_judged_frac=0.5)
     if mode.startswith("branch_graphs"):
         assert len(eng._bg.get("G", {})) == (1 if eng.g_graphs else 0)      # one generator graph pair, replayed twice
 

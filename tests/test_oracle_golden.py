@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import AdamDeltaCheck, GOLDEN, det_array, det_state, load_pkg, probe, probe_close
+from helpers import AdamDeltaCheck, oracle_gradient_noise, GOLDEN, det_array, det_state, load_pkg, probe, probe_close
 from oracle import attngan_oracle as O
 from standin import StandInEncoder
 
@@ -209,9 +209,9 @@ def test_g_net_eval_mode():
             assert int(v) == 0
 
 
-def _build_all(cfg):
-    G = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."))
-    Ds = [O.from_state_dict(det_state(O.d_net_spec(i, cfg), "D%d." % i)) for i in range(3)]
+def _build_all(cfg, dtype=torch.float32):
+    G = O.from_state_dict(det_state(O.g_net_spec(cfg), "G."), dtype=dtype)
+    Ds = [O.from_state_dict(det_state(O.d_net_spec(i, cfg), "D%d." % i), dtype=dtype) for i in range(3)]
     enc = StandInEncoder(cfg.emb_dim)
     sd = {k: torch.from_numpy(det_array("ENC." + k, v.shape,
                                         0.1 if v.dim() == 1 else 1.0 / np.sqrt(int(np.prod(v.shape[1:])))))
@@ -219,7 +219,7 @@ def _build_all(cfg):
     enc.load_state_dict(sd)
     for p in enc.parameters():
         p.requires_grad = False
-    return G, Ds, enc.eval()
+    return G, Ds, enc.to(dtype).eval()
 
 
 def test_losses():
@@ -286,11 +286,15 @@ def test_two_train_steps():
                                 what="D%d %s" % (i, k))
         for (k, _), a in zip(O.parameters(G), st.ema):
             probe_close(probe(a), g[p + "ema_" + k.replace(".", "__")], tol, what="ema " + k)
-        for n, net in nets:                       # the Adam update itself (helpers.AdamDeltaCheck)
+        # the Adam update itself (helpers.AdamDeltaCheck): every element whose gradient lies above the fp32 noise floor
+        # (fp32 vs fp64 run of this very trajectory) must reproduce the reference's delta -- 99 % of them within lr/4
+        masks, _ = oracle_gradient_noise(cfg, lambda dt: _build_all(cfg, dt),
+                                         [synthetic.make_batch(4, words_num=cfg.words_num, nef=cfg.emb_dim, seed=100 + s_) for s_ in range(2)])
+        for n, net in nets:
             deltas = AdamDeltaCheck(lr=2e-4)
             for k, v in O.parameters(net):
-                deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))])
-            deltas.check(0.02, what="%s step %d" % (n, step))
+                deltas.add(init[n][k], probe(v), g["%s%s_%s" % (p, n, k.replace(".", "__"))], judged=masks[(step, n, k)])
+            deltas.check(0.01, what="%s step %d" % (n, step), min_judged_frac=0.5)
 
 
 # ------------------------------------------------------------------ full-width fixtures (make_golden_fullwidth.py)

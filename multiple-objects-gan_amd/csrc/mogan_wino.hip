@@ -17,6 +17,10 @@
 #include "mogan_internal.h"
 #include "mogan_mma.h"
 
+#ifndef MOGAN_WINO5
+#define MOGAN_WINO5 1
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,15 +49,6 @@ __device__ __forceinline__ f32x4 ldgx4(__amdgpu_buffer_rsrc_t r, unsigned idx, b
 //    have been issued).
 // U3[mb][wave][step][j][a][piece][lane] x 16 bytes.
 constexpr int CK2 = 16, XSZ2 = CK2 * XR * XCP, VSZ2 = 16 * CK2 * NT;
-#ifndef WINO_ORDER
-#define WINO_ORDER 1
-#endif
-#ifndef WINO_ROLE
-#define WINO_ROLE 1
-#endif
-#ifndef WINO_SLEEP
-#define WINO_SLEEP 8
-#endif
 
 __global__ __launch_bounds__(256) void wino3_weight_kernel(const float* __restrict__ w, uint4* __restrict__ U3, int Cout,
                                                            int Cin, int flip, long long nfrag) {
@@ -129,11 +124,6 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
     // and rides in the scalar offset of the buffer instruction (no vector address arithmetic in the K loop)
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int mbs = (Cout + BM - 1) / BM;
-#if WINO_ROLE == 1
-    const bool roleB = (wave_s & 4) != 0;       // waves w and w + 4 share a SIMD (round-robin placement)
-#elif WINO_ROLE == 2
-    const bool roleB = (wave_s & 1) != 0;
-#endif
     const unsigned ulane = (unsigned)lane * 16u;
     unsigned xg, ubase; int m0, img, oy0, ox0;
     // work item = (spatial tile, output-channel block) with the channel block INNERMOST, a block walks a contiguous range of
@@ -141,16 +131,10 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
     // input leaves HBM once per layer), and vertically adjacent tiles -- which share two halo rows -- stay on the CU as well
     auto plan = [&](int tile, unsigned& g, unsigned& ub, int& m0_, int& img_, int& oy_, int& ox_) {
         int t = tile;
-#if WINO_ORDER
         const int mb = t % mbs; t /= mbs;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y; t /= tiles_y;
         img_ = t;
-#else
-        const int tx = t % tiles_x; t /= tiles_x;
-        const int ty = t % tiles_y; t /= tiles_y;
-        img_ = t % nimg; const int mb = t / nimg;
-#endif
         m0_ = mb * BM; oy_ = ty * 2 * TROWS; ox_ = tx * 2 * TCOLS;
         const int iy = oy_ + shy - pad, ix = ox_ + shx - pad;
         const bool ok = sact && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
@@ -215,14 +199,9 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
             for (int a = 0; a < 3; ++a) acc[j][a] = x6_mfma(fa[j][a], fb, term, acc[j][a]);
     };
 
-#if WINO_ORDER
     const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
     int tile = blockIdx.x * per;
     const int tile_end = min(ntile, tile + per), tstep = 1;
-#else
-    int tile = blockIdx.x;
-    const int tile_end = ntile, tstep = gridDim.x;
-#endif
     if (tile < tile_end) {
         plan(tile, xg, ubase, m0, img, oy0, ox0);
         load_x(rx, xg, 0); load_x(rx1, xg, CK2); load_a(0, ubase, 0); load_a(1, ubase, 0);
@@ -246,12 +225,6 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
             const float* Vc = Vs + cur * VSZ2;
             float* Vn = Vs + (cur ^ 1) * VSZ2;
             const float* Xn = Xs + (cur ^ 1) * XSZ2;
-#if WINO_ROLE
-            // the two waves of a SIMD in lockstep sit in their vector / LDS phases at the same time and the matrix pipe idles;
-            // one of them starts every step late by about one MFMA group, so that its MFMAs fall into the other's staging /
-            // transform phases (same instruction stream for both: no second loop body, no extra registers)
-            if (roleB) __builtin_amdgcn_s_sleep(WINO_SLEEP);
-#endif
             mma_j(0, Vc);
             load_a(0, ubase, p + 1);
             store_x(rx, Xs + cur * XSZ2);                   // X(p+2)
@@ -336,368 +309,175 @@ __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------ round 6: forward, fourth form
-// wino3_fwd_kernel is bound by the vector-memory path, not by the matrix pipe (MFMA busy 0.23): with 32 tiles per block every
-// 1 KB filter fragment feeds six MFMAs (0.5 KB per MFMA, 147 KB per K step and CU -- the L1's whole 64 B/clk at the full matrix
-// rate, ~12 TB/s out of the L2s over the chip), and the output transform moves all 16 transform positions of every (channel,
-// tile) through LDS (16 values x 4 B, written at 64 B/clk) because a wave holds two positions only.  This form changes both:
-//   * a block = 4 waves (one per SIMD, the accumulators in the AGPR half of the 512-entry file) owns MT*32 output channels x 64
-//     tiles (4 tile rows x 16 tile columns = 8 x 32 output pixels) of one image; wave j owns COLUMN j of the 4 x 4 transform
-//     positions, all four rows i, as 4 x MT x 2 accumulator tiles: a filter fragment feeds 12 MFMAs (0.25 KB per MFMA);
-//   * the row half of the output transform (Y = A^t M A: P[a][j] = sum_i A^t[a][i] M[i][j]) is done in registers; only the two
-//     P values per (channel, tile) and wave cross waves, once, through LDS -- 8 values instead of 16, one pass, two barriers;
-//   * the halo arrives as 16-byte quads (9 per row and channel, loaded at the halo's own 4-byte alignment) and is staged with
-//     16-byte LDS stores; a transform thread owns (tile, 4 channels) and writes V channel-innermost, so that a B fragment is two
-//     ds_read_b128 (the 16-byte slots of a tile's 16 channels are XOR-swizzled with (tile >> 2) & 3: conflict-free in the
-//     instruction's 16-lane groups);
-//   * work items = (tile group, channel block) with the channel block innermost over a contiguous range per persistent block:
-//     the second / third channel block of a group reads its halo out of L1 / L2, the input leaves HBM once per layer.
-// LDS: V 2 x 64 KB (fp32, split at the fragment read as before: every V element is read by exactly one wave) + X 22.5 KB.
-// Filters: U4[m-tile][K step][j][i][piece][lane] x 16 bytes (wino4_weight_kernel), 12 KB contiguous per (m-tile, step, wave).
-// Cout % 64 == 32 (the 96-channel layers): the last 32 channels run as a second launch of the MT = 1 instantiation.
-// issue order of a phase: per MFMA `nv` vector-ALU instructions, `nd` LDS instructions and `nm` vector-memory instructions (the
-// wave is alone on its SIMD: what is not issued between two MFMAs does not overlap with the matrix pipe at all)
-#ifndef W4_SCHED
-#define W4_SCHED 1
-#endif
-#ifndef W4_LAB
-#define W4_LAB 0      // lab builds (wrong results): 1 no halo loads, 2 no filter loads, 4 no input transform, 8 no MFMAs in the K loop
-#endif
-#if W4_SCHED
-#define W4_PIPE(nmfma, nv, nd, nm)                                         \
-    _Pragma("unroll") for (int m_ = 0; m_ < (nmfma); ++m_) {               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
-        __builtin_amdgcn_sched_group_barrier(0x002, (nv), 0);              \
-        __builtin_amdgcn_sched_group_barrier(0x080, (nd), 0);              \
-        __builtin_amdgcn_sched_group_barrier(0x010, (nm), 0);              \
-    }
-#else
-#define W4_PIPE(nmfma, nv, nd, nm)
-#endif
-#ifndef W4_V01
-#define W4_V01 6
-#endif
-#ifndef W4_V2
-#define W4_V2 6
-#endif
-#ifndef W4_V3
-#define W4_V3 3
-#endif
-constexpr int W4_TY = 4, W4_TX = 16, W4_NT = W4_TY * W4_TX, W4_XR = 2 * W4_TY + 2, W4_XQ = 9, W4_XW = 4 * W4_XQ;
-constexpr int W4_XSZ = CK2 * W4_XR * W4_XW, W4_VSZ = 16 * W4_NT * CK2, W4_NXL = (CK2 * W4_XR * W4_XQ + 255) / 256;
-
-__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, uint4* __restrict__ U4, int Cout,
-                                                           int Cin, int flip, long long nfrag) {
-    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gidx >= nfrag) return;
-    const int Kin = flip ? Cout : Cin, Kout = flip ? Cin : Cout;
-    const int nstep = Kin / CK2;
-    const int lane = (int)(gidx & 63); long long rr = gidx >> 6;
-    const int i = (int)(rr & 3); rr >>= 2;
-    const int j = (int)(rr & 3); rr >>= 2;
-    const int step = (int)(rr % nstep); const int mt = (int)(rr / nstep);
-    const int h = lane >> 5, l31 = lane & 31;
-    const int kout = mt * 32 + l31;
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-    float u8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int kin = step * CK2 + 8 * h + e;
-        float u = 0.f;
-        if (kout < Kout) {
-            const int co = flip ? kin : kout, ci = flip ? kout : kin;
-            const float* g = w + ((size_t)co * Cin + ci) * 9;
-            float t[3];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                float tt = 0.f;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) tt += G[i][a] * (flip ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b]);
-                t[b] = tt;
-            }
-            u = G[j][0] * t[0] + G[j][1] * t[1] + G[j][2] * t[2];
-        }
-        u8[e] = u;
-    }
-    const X6Frag f = x6_split8(u8);
-    const size_t base = ((((size_t)mt * nstep + step) * 4 + j) * 4 + i) * 3 * 64 + lane;
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc) U4[base + (size_t)pc * 64] = __builtin_bit_cast(uint4, f.p[pc]);
-}
-
-template <int MT>
-__global__ __launch_bounds__(256) void wino4_fwd_kernel(const float* __restrict__ X, const uint4* __restrict__ U4,
-                                                        float* __restrict__ Y, int Cin, int H, int W, int Cout, int gx, int gy,
-                                                        int nitem, int mbs, int mt0, unsigned x_bytes, unsigned u_bytes) {
-    __shared__ __attribute__((aligned(16))) float Vs[2 * W4_VSZ];      // V of the K loop; the epilogue's exchange buffer
-    __shared__ __attribute__((aligned(16))) float Xs[W4_XSZ + 4 * 256];   // (+ a dump quad per thread: the idle lanes of the last staging slot store unconditionally)
+// ------------------------------------------------------------------------------------------ round 6: forward, 16 waves per block
+// wino3_fwd_kernel is bound by latency, not by a unit: counters of the layer alone (profiles/r06_wino_pmc.txt) show the matrix
+// pipe 23 % busy, the texture-address unit ~50 %, LDS 17 %, vector ALU 13 % -- and the waves waiting 47 % of their cycles, two per
+// SIMD.  Same tile (96 output channels x 32 tiles of one image), same LDS images and filter layout here, but 16 waves of ONE
+// transform position each (48 accumulator registers instead of 96, one position's 9 filter fragments instead of two's), i.e. four
+// waves per SIMD at <= 128 registers: twice the waves to hide every load and LDS round trip behind.  The output transform moves
+// one 32-channel block of all 16 positions through LDS per pass (three passes, 64 KB each -- the V buffers' own size).
+// Full tiles only (OW % 32 == 0, OH % 4 == 0, Kout % 96 == 0), no fused affine epilogue: everything else stays on wino3_fwd_kernel.
+__global__ __launch_bounds__(1024) void wino5_fwd_kernel(const float* __restrict__ X, const uint4* __restrict__ U3,
+                                                         float* __restrict__ Y, int Cin, int H, int W, int Cout, int OH, int OW,
+                                                         int pad, int tiles_x, int tiles_y, int ntile, unsigned x_bytes,
+                                                         unsigned u_bytes) {
+    __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ2];
+    __shared__ __attribute__((aligned(16))) float VTs[2 * VSZ2];     // V of the K loop; the epilogue's exchange buffer
+    float* const Vs = VTs;
+    float* const Ts = VTs;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
-    const int wj = __builtin_amdgcn_readfirstlane(tid >> 6);         // this wave's column of transform positions
+    const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);            // this wave's transform position
     const int plane = H * W;
     const int nstep = Cin / CK2;
+    const int mbs = Cout / BM;
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U4, (short)0, (int)u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U3, (short)0, (int)u_bytes, 0x00020000);
 
-    // halo staging role: slot s = tid + 256 k -> (channel, halo row, quad) of a K step; quad q holds columns ox0 - 1 + 4 q .. + 3
-    int xs_l[W4_NXL];
-#pragma unroll
-    for (int k = 0; k < W4_NXL; ++k) {
-        const int sl = tid + 256 * k;
-        const int c = sl / (W4_XR * W4_XQ), rem = sl - c * (W4_XR * W4_XQ);
-        const int r = rem / W4_XQ, q = rem - r * W4_XQ;
-        xs_l[k] = sl < CK2 * W4_XR * W4_XQ ? (c * W4_XR + r) * W4_XW + 4 * q : W4_XSZ + 4 * tid;
-    }
-    // transform role: tile tt (row tty, column ttx), channel pair 2 cq, 2 cq + 1 and 2 cq + 8, 2 cq + 9 of a step
-    const int tt = tid & 63, tty = tt >> 4, ttx = tt & 15, cq = tid >> 6;
-    const int tsw = (tt >> 2) & 3;
-    const int tx0 = (2 * tty) * W4_XW + 2 * ttx;
-    // B fragment of tile block tb: tile tb * 32 + l31, channels 8 h .. 8 h + 7 = slots 2 h, 2 h + 1 (swizzled)
-    int bsl[2][2];
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int tile = tb * 32 + l31, sw = (tile >> 2) & 3;
-        bsl[tb][0] = tile * CK2 + ((2 * h) ^ sw) * 4;
-        bsl[tb][1] = tile * CK2 + ((2 * h + 1) ^ sw) * 4;
-    }
+    // halo staging role: position (row, column) sr of the 6 x 34 halo, channels 4 i + sg of a step (i < 4)
+    const int sg = tid >> 8, sr = tid & 255;
+    const bool sact = sr < XR * XC;
+    const int shy = sr / XC, shx = sr - shy * XC;
+    const int xl0 = sact ? sg * (XR * XCP) + shy * XCP + shx : sg * (XR * XCP) + (sr % XR) * XCP + XC + ((sr / XR) & 1);
+    // transform role: rows 2 th, 2 th + 1 of V = B^t d B for tile tt of channel tc
+    const int th = tid >> 9, tc = (tid >> 5) & 15, tt = tid & 31, tty = tt >> 4, ttx = tt & 15;
+    const int tx0 = tc * (XR * XCP) + (2 * tty + th) * XCP + 2 * ttx;
+    const int tv0 = ((2 * th) * 4 * CK2 + tc) * NT + tt;
+    const int bv0 = (xi * CK2 + 8 * h) * NT + l31;
     const unsigned ulane = (unsigned)lane * 16u;
-
-    unsigned xg[W4_NXL]; unsigned xedge = 0, xedge_cur = 0;      // bit k: slot k is the left-edge quad, bit 8 + k: the right-edge quad
-    unsigned ubase; int m0, img, oy0, ox0;
-    auto plan = [&](int item) {
-        int t = item;
+    unsigned xg, ubase; int m0, img, oy0, ox0;
+    auto plan = [&](int tile) {
+        int t = tile;
         const int mb = t % mbs; t /= mbs;
-        const int gxi = t % gx; t /= gx;
-        const int gyi = t % gy; t /= gy;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y; t /= tiles_y;
         img = t;
-        m0 = (mt0 + mb * MT) * 32; oy0 = gyi * 2 * W4_TY; ox0 = gxi * 2 * W4_TX;
-        xedge = 0;
-#pragma unroll
-        for (int k = 0; k < W4_NXL; ++k) {
-            const int sl = tid + 256 * k;
-            const int c = sl / (W4_XR * W4_XQ), rem = sl - c * (W4_XR * W4_XQ);
-            const int r = rem / W4_XQ, q = rem - r * W4_XQ;
-            const int iy = oy0 - 1 + r, ix = ox0 - 1 + 4 * q;
-            const bool ok = sl < CK2 * W4_XR * W4_XQ && (unsigned)iy < (unsigned)H;
-            // a quad that sticks out of its row is loaded from inside the row and shifted (load_x): column -1 of the leftmost
-            // group, columns W .. W + 2 of the rightmost one read as zeros, and no load leaves the tensor
-            const bool el = ix < 0, er = ix + 4 > W;
-            const int ixa = el ? 0 : er ? ix - 3 : ix;
-            xg[k] = ok ? ((unsigned)(img * Cin + c) * plane + (unsigned)(iy * W + ixa)) * 4u : 0xC0000000u;     // reads 0
-            xedge |= (el ? 1u : 0u) << k | (er ? 256u : 0u) << k;
-        }
-        ubase = (unsigned)((((mt0 + mb * MT) * nstep) * 4 + wj) * 4) * 3072u;
+        m0 = mb * BM; oy0 = ty * 2 * TROWS; ox0 = tx * 2 * TCOLS;
+        const int iy = oy0 + shy - pad, ix = ox0 + shx - pad;
+        const bool ok = sact && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        xg = ok ? (unsigned)(img * Cin + sg) * plane + (unsigned)(iy * W + ix) : 0x30000000u;     // reads 0
+        ubase = (unsigned)((mb * 8 + (xi >> 1)) * nstep) * (18u * 1024u) + (unsigned)(xi & 1) * (9u * 1024u);
     };
-    f32x4 rx[W4_NXL];
+    float rx[4];
     auto load_x = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < W4_NXL; ++k)
-            rx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, xg[k] + (unsigned)c0 * (unsigned)plane * 4u, 0, 0));
+        for (int i = 0; i < 4; ++i) rx[i] = ldgx(rX, xg + (unsigned)(c0 + 4 * i) * plane, true);
     };
-    auto store_x = [&]() {                                  // (the edge shift happens here, not at the load: the loads stay in flight)
+    auto store_x = [&](float* Xd) {
 #pragma unroll
-        for (int k = 0; k < W4_NXL; ++k) {
-            const f32x4 v = rx[k];
-            const bool el = (xedge_cur >> k) & 1u, er = (xedge_cur >> (8 + k)) & 1u;
-            f32x4 o;
-            o[0] = el ? 0.f : er ? v[3] : v[0];
-            o[1] = el ? v[0] : er ? 0.f : v[1];
-            o[2] = el ? v[1] : er ? 0.f : v[2];
-            o[3] = el ? v[2] : er ? 0.f : v[3];
-            *(f32x4*)&Xs[xs_l[k]] = o;
-        }
+        for (int i = 0; i < 4; ++i) Xd[xl0 + 4 * i * (XR * XCP)] = rx[i];
     };
-    // filter fragments of position row i, K step `step`: MT m-tiles x 3 pieces
-    auto load_a = [&](X6Frag (&fa)[MT], int i, int step) {
+    X6Frag fa[3];
+    auto load_a = [&](int step) {
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
                 fa[a].p[pc] = __builtin_bit_cast(mma_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                    rU, ulane, ubase + (unsigned)((a * nstep + step) * 16 + i) * 3072u + (unsigned)pc * 1024u, 0));
+                    rU, ulane, ubase + (unsigned)(step * 18 + a * 3 + pc) * 1024u, 0));
     };
-    // input transform of channels c, c + 1 (c = 2 cq + c8) of the staged K step: V = B^t d B, all 16 positions, 8-byte stores
-    auto transform = [&](float* Vd, int c8) {
-        float v[2][4][4];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float* px = &Xs[(2 * cq + c8 + e) * (W4_XR * W4_XW) + tx0];
-            float d[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float2 lo = *(const float2*)(px + r * W4_XW), hi = *(const float2*)(px + r * W4_XW + 2);
-                d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = hi.x; d[r][3] = hi.y;
-            }
-            float t[4][4];                                   // t = B^t d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                t[0][c] = d[0][c] - d[2][c]; t[1][c] = d[1][c] + d[2][c];
-                t[2][c] = d[2][c] - d[1][c]; t[3][c] = d[1][c] - d[3][c];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[e][r][0] = t[r][0] - t[r][2]; v[e][r][1] = t[r][1] + t[r][2];
-                v[e][r][2] = t[r][2] - t[r][1]; v[e][r][3] = t[r][1] - t[r][3];
-            }
+    auto transform = [&](const float* Xc, float* Vd) {
+        float ra[4], rb[4], rc[4];
+        const float* px = &Xc[tx0];
+        {
+            const float2 a0 = *(const float2*)px, a1 = *(const float2*)(px + 2);
+            const float2 b0 = *(const float2*)(px + XCP), b1 = *(const float2*)(px + XCP + 2);
+            const float2 c0 = *(const float2*)(px + 2 * XCP), c1 = *(const float2*)(px + 2 * XCP + 2);
+            ra[0] = a0.x; ra[1] = a0.y; ra[2] = a1.x; ra[3] = a1.y;
+            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
+            rc[0] = c0.x; rc[1] = c0.y; rc[2] = c1.x; rc[3] = c1.y;
         }
-        const int c = 2 * cq + c8;
-        float* pv = &Vd[tt * CK2 + (((c >> 2) ^ tsw) * 4) + (c & 3)];
+        float u[2][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int j = 0; j < 4; ++j) {
+            const float t1 = ra[j] - rc[j], t2 = rb[j] - ra[j], t3 = rb[j] + rc[j];
+            u[0][j] = th ? t2 : t1;
+            u[1][j] = th ? t1 : t3;
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *(float2*)(pv + (r * 4 + q) * (W4_NT * CK2)) = make_float2(v[0][r][q], v[1][r][q]);
-    };
-
-    f32x16 acc[4][MT][2];
-    // B operand of position (i, wj): raw fp32 fragment reads, split one phase ahead of the MFMAs that consume it
-    struct RawB { f32x4 lo[2], hi[2]; };
-    auto read_b = [&](int i, const float* Vc) {
-        const float* pb = Vc + (i * 4 + wj) * (W4_NT * CK2);
-        RawB r;
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) { r.lo[tb] = *(const f32x4*)(pb + bsl[tb][0]); r.hi[tb] = *(const f32x4*)(pb + bsl[tb][1]); }
-        return r;
-    };
-    auto split_b = [&](const RawB& r, X6Frag (&fb)[2]) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            const float b8[8] = {r.lo[tb][0], r.lo[tb][1], r.lo[tb][2], r.lo[tb][3], r.hi[tb][0], r.hi[tb][1], r.hi[tb][2], r.hi[tb][3]};
-            fb[tb] = x6_split8(b8);
+        for (int i = 0; i < 2; ++i) {
+            float* pv = &Vd[tv0 + (i * 4 * CK2) * NT];
+            pv[0] = u[i][0] - u[i][2];
+            pv[CK2 * NT] = u[i][1] + u[i][2];
+            pv[2 * CK2 * NT] = u[i][2] - u[i][1];
+            pv[3 * CK2 * NT] = u[i][1] - u[i][3];
         }
     };
-    auto mma_i = [&](int i, const X6Frag (&fa)[MT], const X6Frag (&fb)[2]) {
-#if W4_LAB & 8
-        acc[i][0][0][0] += __builtin_bit_cast(float, (int)fb[0].p[0][0] + (int)fb[1].p[2][1] + (int)fa[0].p[1][0] + (int)fa[MT - 1].p[2][3]);
-        return;
-#endif
+    f32x16 acc[3];
+    float b8[8];
+    auto read_b = [&](const float* Vc) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = Vc[bv0 + e * NT];
+    };
+    auto mma = [&]() {
+        const X6Frag fb = x6_split8(b8);
 #pragma unroll
         for (int term = 0; term < 6; ++term)
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) acc[i][a][tb] = x6_mfma(fa[a], fb[tb], term, acc[i][a][tb]);
+            for (int a = 0; a < 3; ++a) acc[a] = x6_mfma(fa[a], fb, term, acc[a]);
     };
 
-    const int per = (nitem + (int)gridDim.x - 1) / (int)gridDim.x;
-    int item = blockIdx.x * per;
-    const int item_end = min(nitem, item + per);
-    X6Frag fa0[MT], fa1[MT], fb0[2], fb1[2];
-    if (item < item_end) { plan(item); load_x(0); }
-    for (; item < item_end; ++item) {
-        xedge_cur = xedge;                                  // (the registers hold this item's first halo from here on)
+    const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = blockIdx.x * per;
+    const int tile_end = min(ntile, tile + per);
+    if (tile < tile_end) { plan(tile); load_x(0); }
+    for (; tile < tile_end; ++tile) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][a][tb][r] = 0.f;
-        load_a(fa0, 0, 0); load_a(fa1, 1, 0);
-        store_x();                                          // X(0)   (Xs is not part of the exchange buffer)
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        load_a(0);
+        store_x(Xs);                                        // X(0)
         load_x(CK2);
-        __syncthreads();                                    // X(0) staged; every thread is done with the previous item's exchange buffer
-        transform(Vs, 0); transform(Vs, 8);
-        __syncthreads();                                    // V(0) complete; Xs free
-        store_x();                                          // X(1)
+        __syncthreads();                                    // (also: every thread is done with the previous tile's Ts)
+        transform(Xs, Vs);
+        store_x(Xs + XSZ2);                                 // X(1)
         load_x(2 * CK2);
-        { const RawB rb = read_b(0, Vs); split_b(rb, fb0); }
         __syncthreads();
-        // One K step = four phases, one per position row i: the 12 MT MFMAs of row i run beside the split of row i + 1's B operand
-        // and a slice of the staging work.  Two barriers: B1 -- V(p+1) complete (phase 3 already reads it for row 0 of the next
-        // step), all transform reads of X(p+1) done; B2 -- X(p+2) staged, all reads of V(p) done.
         for (int p = 0; p < nstep; ++p) {
-            const float* Vc = Vs + (p & 1) * W4_VSZ;
-            float* Vn = Vs + ((p & 1) ^ 1) * W4_VSZ;
-            {   // phase 0
-                const RawB rb = read_b(1, Vc);
-                mma_i(0, fa0, fb0);
-                split_b(rb, fb1);
-#if !(W4_LAB & 4)
-                transform(Vn, 0);                           // X(p+1) -> V(p+1)
-#endif
-#if !(W4_LAB & 2)
-                load_a(fa0, 2, p);
-#endif
-                W4_PIPE(12 * MT, W4_V01, 2, 1);
-            }
-            {   // phase 1
-                const RawB rb = read_b(2, Vc);
-                mma_i(1, fa1, fb1);
-                split_b(rb, fb0);
-#if !(W4_LAB & 4)
-                transform(Vn, 8);
-#endif
-#if !(W4_LAB & 2)
-                load_a(fa1, 3, p);
-#endif
-                W4_PIPE(12 * MT, W4_V01, 2, 1);
-            }
-            __syncthreads();
-            {   // phase 2
-                const RawB rb = read_b(3, Vc);
-                mma_i(2, fa0, fb0);
-                split_b(rb, fb1);
-                store_x();                                  // X(p+2)
-#if !(W4_LAB & 1)
-                load_x((p + 3) * CK2);
-#endif
-#if !(W4_LAB & 2)
-                load_a(fa0, 0, p + 1);
-#endif
-                W4_PIPE(12 * MT, W4_V2, 1, 1);
-            }
-            {   // phase 3
-                const RawB rb = read_b(0, Vn);
-                mma_i(3, fa1, fb1);
-                split_b(rb, fb0);
-#if !(W4_LAB & 2)
-                load_a(fa1, 1, p + 1);
-#endif
-                W4_PIPE(12 * MT, W4_V3, 1, 1);
-            }
+            const int cur = p & 1;
+            const float* Vc = Vs + cur * VSZ2;
+            read_b(Vc);
+            mma();
+            load_a(p + 1);
+            transform(Xs + (cur ^ 1) * XSZ2, Vs + (cur ^ 1) * VSZ2);   // X(p+1) -> V(p+1)
+            store_x(Xs + cur * XSZ2);                       // X(p+2)   (X(p) was transformed one step ago)
+            load_x((p + 3) * CK2);
             __syncthreads();
         }
         const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
-        if (item + 1 < item_end) { plan(item + 1); load_x(0); }
-        // ---- output transform: rows in registers, columns across the four waves through LDS
-        //      P[a][j]: a = 0: M0 + M1 + M2, a = 1: M1 - M2 - M3;  Ts[j][a][co][tile]
-        float* const Ts = Vs;
+        if (tile + 1 < tile_end) { plan(tile + 1); load_x(0); }
+        // ---- output transform, one 32-channel block (a) of all 16 positions per pass: Ts[position][channel 32][tile 32]
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < 3; ++a) {
+            if (a) __syncthreads();
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
+            for (int r = 0; r < 16; ++r) Ts[(xi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * NT + l31] = acc[a][r];
+            __syncthreads();
+            if (tid < 512) {
+                // item = (channel, pair of horizontally adjacent tiles): a 2 x 4 pixel patch
+                const int co = tid >> 4, tp = tid & 15;
+                float2 m[4][4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float m1 = acc[1][a][tb][r], m2 = acc[2][a][tb][r];
-                    const float p0 = acc[0][a][tb][r] + m1 + m2, p1 = m1 - m2 - acc[3][a][tb][r];
-                    const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float* q = &Ts[((wj * 2) * (MT * 32) + co) * W4_NT + tb * 32 + l31];
-                    q[0] = p0;
-                    q[(MT * 32) * W4_NT] = p1;
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[i][j] = *(const float2*)&Ts[((i * 4 + j) * 32 + co) * NT + 2 * tp];
+                float2 t0[4], t1[4];                        // rows: A^t M
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t0[j] = make_float2(m[0][j].x + m[1][j].x + m[2][j].x, m[0][j].y + m[1][j].y + m[2][j].y);
+                    t1[j] = make_float2(m[1][j].x - m[2][j].x - m[3][j].x, m[1][j].y - m[2][j].y - m[3][j].y);
                 }
-        __syncthreads();
-        // item = (output channel, pair of horizontally adjacent tiles): MT*32 x 32 items, MT*4 per thread; a 2 x 4 pixel patch each
-#pragma unroll
-        for (int k = 0; k < MT * 4; ++k) {
-            const int it = tid + 256 * k;
-            const int pr = it & 31, co = it >> 5;
-            float2 pj[4][2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int a = 0; a < 2; ++a) pj[j][a] = *(const float2*)&Ts[((j * 2 + a) * (MT * 32) + co) * W4_NT + 2 * pr];
-            const int ty = pr >> 3, px = pr & 7;
-            float* o = Y + ((size_t)(cimg * Cout + cm0 + co) * H + coy0 + 2 * ty) * W + cox0 + 4 * px;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                // Y[a][0] = P0 + P1 + P2, Y[a][1] = P1 - P2 - P3 (columns), for the two tiles of the pair
-                const float y00 = pj[0][a].x + pj[1][a].x + pj[2][a].x, y01 = pj[1][a].x - pj[2][a].x - pj[3][a].x;
-                const float y10 = pj[0][a].y + pj[1][a].y + pj[2][a].y, y11 = pj[1][a].y - pj[2][a].y - pj[3][a].y;
-                *(float4*)(o + (size_t)a * W) = make_float4(y00, y01, y10, y11);
+                const int oy = coy0 + 2 * (tp >> 3), ox = cox0 + 4 * (tp & 7);
+                float* o = Y + ((size_t)(cimg * Cout + cm0 + a * 32 + co) * OH + oy) * OW + ox;
+                *(float4*)o = make_float4(t0[0].x + t0[1].x + t0[2].x, t0[1].x - t0[2].x - t0[3].x,
+                                          t0[0].y + t0[1].y + t0[2].y, t0[1].y - t0[2].y - t0[3].y);
+                *(float4*)(o + OW) = make_float4(t1[0].x + t1[1].x + t1[2].x, t1[1].x - t1[2].x - t1[3].x,
+                                                 t1[0].y + t1[1].y + t1[2].y, t1[1].y - t1[2].y - t1[3].y);
             }
         }
     }
 }
+
 #endif  // MOGAN_X6
 
 // ------------------------------------------------------------------------------------------ weight gradient
@@ -1016,31 +796,16 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     }
-    // fourth form (wino4_fwd_kernel): well-filled 8 x 32 pixel groups, pad 1, no fused affine epilogue
-    static const int w4_on = getenv("MOGAN_WINO4") ? atoi(getenv("MOGAN_WINO4")) : 1;
-    if (w4_on && pad == 1 && ph == 1 && ep_scale == nullptr && (oH % (2 * W4_TY)) == 0 && (oW % (2 * W4_TX)) == 0 && (Kout % 32) == 0 &&
-        (((uintptr_t)in) & 3) == 0) {
-        const int Mt = Kout / 32, nstep = Kin / CK2;
-        const size_t u4bytes = (size_t)Mt * nstep * 16 * 3072;
-        if (u4bytes <= ws_bytes && u4bytes < (1ull << 31)) {
-            const int gx = oW / (2 * W4_TX), gy = oH / (2 * W4_TY);
-            const long long nfrag4 = (long long)Mt * nstep * 16 * 64;
-            hipLaunchKernelGGL(wino4_weight_kernel, dim3((unsigned)((nfrag4 + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, Cout, Cin,
-                               dgrad, nfrag4);
-            const unsigned xb = (unsigned)(4ull * B * Kin * iH * iW);
-            const int mb2 = Mt / 2;                              // channel blocks of 64; a last one of 32 goes out as a second launch
-            if (mb2 > 0) {
-                const long long nitem = (long long)B * gx * gy * mb2;
-                hipLaunchKernelGGL(wino4_fwd_kernel<2>, dim3((unsigned)std::min<long long>(nitem, ncu)), dim3(256), 0, st, in,
-                                   (const uint4*)ws, out, Kin, iH, iW, Kout, gx, gy, (int)nitem, mb2, 0, xb, (unsigned)u4bytes);
-            }
-            if (Mt & 1) {
-                const long long nitem = (long long)B * gx * gy;
-                hipLaunchKernelGGL(wino4_fwd_kernel<1>, dim3((unsigned)std::min<long long>(nitem, ncu)), dim3(256), 0, st, in,
-                                   (const uint4*)ws, out, Kin, iH, iW, Kout, gx, gy, (int)nitem, 1, Mt - 1, xb, (unsigned)u4bytes);
-            }
-            return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
-        }
+    // the 16-wave form where it applies: full 4 x 32 pixel tiles, 96-channel blocks, no fused affine epilogue
+    // (-DMOGAN_WINO5=0 builds the library without it: the A/B reference of profiles/r06_ab.txt)
+    if (MOGAN_WINO5 && ep_scale == nullptr && (oH % (2 * TROWS)) == 0 && (oW % (2 * TCOLS)) == 0 && (Kout % BM) == 0 && u3bytes <= ws_bytes) {
+        const long long nt5 = (long long)B * tiles_x * tiles_y * mbs;
+        hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((mbs * 8 * (Kin / CK2) * 2 * 3 * 64 + 255) / 256)), dim3(256), 0, st, w,
+                           (uint4*)ws, Cout, Cin, dgrad, mbs * 8 * (Kin / CK2) * 2 * 3 * 64);
+        hipLaunchKernelGGL(wino5_fwd_kernel, dim3((unsigned)std::min<long long>(nt5, ncu)), dim3(1024), 0, st, in, (const uint4*)ws, out,
+                           Kin, iH, iW, Kout, oH, oW, pad, tiles_x, tiles_y, (int)nt5, (unsigned)(4ull * B * Kin * iH * iW),
+                           (unsigned)u3bytes);
+        return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
     }
     const long long ntile = (long long)B * tiles_x * tiles_y * mbs;
     if (ntile >= (1ll << 30)) return 0;

@@ -424,8 +424,13 @@ struct WGradP {
 // WIDE (3x3 s1 p1, no fused upsample, W % 4 == 0): the halo rows are fetched as aligned 16-byte quads covering the
 // columns [ox0-4, ox0+CW+4) -- 10 loads per row instead of 34 dword loads; every quad is entirely inside or outside
 // the image.  LDS column c of a row then holds image column ox0-4+c.
+#ifndef DCONV_WG_OCC
+#define DCONV_WG_OCC 2
+#endif
+// (two blocks per CU asked for: left alone, the allocator takes 264 registers for the 2 x 2-tile instantiations -- ONE wave per
+// SIMD -- where 256 are enough without a spill; these kernels wait on loads and LDS round trips, more waves is what they lack)
 template <int KH, int KW, int S, int CW, int WM, int WN, int TM, int TN, bool DBW, bool WIDE>
-__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const WGradP p) {
+__global__ __launch_bounds__(256, DCONV_WG_OCC) void dconv_wgrad_kernel(const WGradP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, KHW = KH * KW, PXK = 64, RT = PXK / CW;
     constexpr int QPR = (CW + 8) / 4;                                      // quads per halo row (WIDE)
     constexpr int HHW = (RT - 1) * S + KH, WW = (CW - 1) * S + KW, WWP = WIDE ? 4 * QPR + 4 : ((WW + 3) & ~3);

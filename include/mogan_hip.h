@@ -178,6 +178,24 @@ int mogan_conv2d_dgrad_ex(const float* dy, long long dy_bstride, const float* w,
                           hipStream_t stream);
 int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
+/* ---- Prepared filter images for the Winograd convolutions (round 6; csrc/mogan_wino.hip).  The 3x3 stride-1 convolutions of the
+ * generator's ResBlocks (code/coco/attngan/model.py:67-81) run as fused Winograd F(2x2,3x3); their filters enter the kernel
+ * transformed (G g G^t) and pre-split into bf16 pieces.  mogan_conv2d_fwd / mogan_conv2d_dgrad build that image per call at the
+ * head of the workspace -- one more launch on the convolution's own chain, per use.  A caller that owns the weights (the
+ * optimizer) keeps the image instead, one per weight and direction, rebuilds ALL images of a network in one launch right after
+ * its optimizer step, and hands it to the *_wp entry points; the library keeps no weight state.
+ *   mogan_wino_prep_bytes   size of the image for this convolution geometry and direction (dgrad = 0 forward, 1 data gradient);
+ *                           0 = this convolution does not take the Winograd kernels (no image is needed, wprep stays NULL)
+ *   mogan_wino_prep_group   images of n (weight, direction) pairs in one launch (32 per launch beyond that); prep[i] 16-byte aligned
+ *   mogan_conv2d_fwd_wp /   mogan_conv2d_fwd / mogan_conv2d_dgrad with the caller's image of w for that direction (wprep NULL: the
+ *   mogan_conv2d_dgrad_wp   plain entry points' behaviour).  The image must have been built from the current values of w. */
+size_t mogan_wino_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up, int dgrad);
+int mogan_wino_prep_group(int n, const float* const* w, void* const* prep, const int* Cout, const int* Cin, const int* dgrad,
+                          hipStream_t stream);
+int mogan_conv2d_fwd_wp(const float* x, const float* w, const void* wprep, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
+int mogan_conv2d_dgrad_wp(const float* dy, const float* w, const void* wprep, float* dx, int B, int Cin, int Hs, int Ws, int Cout,
+                          int KH, int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
 /* dw (Cout,Cin,KH,KW); accumulate != 0 adds into dw */
 int mogan_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, int accumulate, void* ws, size_t ws_bytes,

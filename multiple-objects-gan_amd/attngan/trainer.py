@@ -98,15 +98,13 @@ class FlatAdam:
         WeightPacks.pointer(), so a lazily rebuilt copy would be a stale one until the graph's own post-Adam pack node ran)"""
         self._pk_cell[0] += 1
         if self.repack_on_touch:
-            for pk in self.packs:
-                pk.repack()
+            ops.repack_all(self.packs)
 
     def repack(self):
         """the same, but the copies in use are rebuilt NOW on the current stream -- after the optimizer step (one pack per
         weight version) and wherever a replayed hipGraph will use the copies without a pack node of its own"""
         self._pk_cell[0] += 1
-        for pk in self.packs:
-            pk.repack()
+        ops.repack_all(self.packs)           # (packed panels pack by pack; every Winograd filter image of the bucket in ONE launch)
 
     on_zero = None          # set by ChunkedReducer: a new accumulation round of this bucket begins
 

@@ -1077,6 +1077,11 @@ int mogan_conv2d_out_dims(int Hs, int Ws, int KH, int KW, int stride, int ph, in
 
 int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                      int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return mogan_conv2d_fwd_wp(x, w, nullptr, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+}
+
+int mogan_conv2d_fwd_wp(const float* x, const float* w, const void* wprep, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
+                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     if (g_force_cfg < 0) {          // <= 4 output channels: HBM streaming work, direct VALU kernel
         rc = mogan_smallc_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
@@ -1089,7 +1094,7 @@ int mogan_conv2d_fwd(const float* x, const float* w, float* y, int B, int Cin, i
     if (g_force_cfg == -1) {        // 3x3 s1 p1 at >= 32 channels: fused Winograd F(2x2,3x3), 2.25x fewer multiplies (-2: test hook, off)
         // (recorded flops = the multiplies the kernel executes: 16 per 2x2 outputs instead of 36)
         mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
-        rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 0, nullptr, nullptr, 0, ws, ws_bytes, stream);
+        rc = mogan_wino_try(x, w, wprep, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 0, nullptr, nullptr, 0, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
@@ -1155,7 +1160,7 @@ int mogan_conv2d_affine_fwd_ex(const float* x, long long x_bstride, const float*
     if (x_bstride < xd || (long long)(B - 1) * x_bstride + xd >= (1ll << 30)) return MOGAN_ERR_SHAPE;
     if (plain && g_force_cfg < 0) {          // the trunk's 3x3 s1 layers on well-filled grids (147x147, 71x71): fused Winograd
         mogan_prof_begin(4, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
-        rc = mogan_wino_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0, 0, scale, shift, relu, ws, ws_bytes, stream);
+        rc = mogan_wino_try(x, w, nullptr, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, 0, 0, scale, shift, relu, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
@@ -1261,6 +1266,11 @@ int mogan_conv2d_dgrad_group(int n, const MoganConvDgradArgs* args, void* ws, si
 
 int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                        int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return mogan_conv2d_dgrad_wp(dy, w, nullptr, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+}
+
+int mogan_conv2d_dgrad_wp(const float* dy, const float* w, const void* wprep, float* dx, int B, int Cin, int Hs, int Ws, int Cout,
+                          int KH, int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream) {
     GemmP p{}; int rc = conv_geom(p, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up); if (rc) return rc;
     if (g_force_cfg < 0) {          // <= 4 channels on one side (image heads, first D convolution)
         rc = mogan_smallc_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, stream);
@@ -1268,7 +1278,7 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
     }
     if (g_force_cfg == -1) {
         mogan_prof_begin(5, 1, (4.0 / 9.0) * 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
-        rc = mogan_wino_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 1, nullptr, nullptr, 0, ws, ws_bytes, stream);
+        rc = mogan_wino_try(dy, w, wprep, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, 1, nullptr, nullptr, 0, ws, ws_bytes, stream);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }

@@ -29,8 +29,9 @@ MOGAN_HIDDEN int mogan_smallc_wgrad_try(const float* dy, const float* x, float* 
                                         int Cout, int KH, int KW, int stride, int ph, int pw, int up, int accumulate,
                                         void* ws, size_t ws_bytes, hipStream_t st);
 // fused Winograd F(2x2,3x3) for the 3x3 s1 p1 convolutions (mogan_wino.hip): dgrad = 0 forward, 1 data gradient
-MOGAN_HIDDEN int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, int H, int W, int Cout, int KH,
-                                int KW, int stride, int ph, int pw, int up, int dgrad, const float* ep_scale,
+// (prep: the caller's prepared filter image of this weight version / direction, or nullptr: transformed per call into ws)
+MOGAN_HIDDEN int mogan_wino_try(const float* in, const float* w, const void* prep, float* out, int B, int Cin, int H, int W, int Cout,
+                                int KH, int KW, int stride, int ph, int pw, int up, int dgrad, const float* ep_scale,
                                 const float* ep_shift, int ep_relu, void* ws, size_t ws_bytes, hipStream_t st);
 MOGAN_HIDDEN int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
                                       int KH, int KW, int stride, int ph, int pw, int up, int accumulate, void* ws,

@@ -50,45 +50,98 @@ __device__ __forceinline__ f32x4 ldgx4(__amdgpu_buffer_rsrc_t r, unsigned idx, b
 // U3[mb][wave][step][j][a][piece][lane] x 16 bytes.
 constexpr int CK2 = 16, XSZ2 = CK2 * XR * XCP, VSZ2 = 16 * CK2 * NT;
 
-__global__ __launch_bounds__(256) void wino3_weight_kernel(const float* __restrict__ w, uint4* __restrict__ U3, int Cout,
-                                                           int Cin, int flip, long long nfrag) {
-    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gidx >= nfrag) return;
+// Filter transform, one wave per unit = (32 output channels) x (16 input channels = one K step): the 32 x 16 x 9 filter values
+// come in as contiguous rows (576 / 1152 bytes each; the round-4 form had every lane walk its own filter row -- 32 cache lines per
+// load instruction, 10 us per layer for 2 MB of output), go through LDS, and lane (h, l31) -- output channel l31, input channels
+// 8 h .. 8 h + 7 -- transforms its 8 filters for ALL 16 positions from registers (G g G^t once per filter) and stores the 48
+// fragments of the unit, 1 KB per (position, piece) across the wave.
+constexpr int WU_ROW = 16 * 9 + 1;      // LDS floats per output channel (odd: conflict-free lane-per-row reads)
+
+__device__ __forceinline__ void wino3_weight_unit(const float* __restrict__ w, uint4* __restrict__ U3, int Cout, int Cin, int flip,
+                                                  int unit, float* __restrict__ T) {
     const int Kin = flip ? Cout : Cin, Kout = flip ? Cin : Cout;
     const int nstep = Kin / CK2;
-    const int lane = (int)(gidx & 63); long long rr = gidx >> 6;
-    const int a3 = (int)(rr % 3); rr /= 3;
-    const int j = (int)(rr & 1); rr >>= 1;
-    const int step = (int)(rr % nstep); rr /= nstep;
-    const int wv = (int)(rr & 7); const int mb = (int)(rr >> 3);
-    const int h = lane >> 5, l31 = lane & 31;
-    const int xi = 2 * wv + j, r = xi >> 2, q = xi & 3;
-    const int kout = mb * BM + a3 * 32 + l31;
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-    float u8[8];
+    const int step = unit % nstep, mt = unit / nstep;            // mt: 32-channel block = (mb, a3)
+    const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+    const int k0 = mt * 32, c0 = step * CK2;
+    // stage T[kout 32][kin 16][9]: thread i copies 72 consecutive floats of one contiguous source row
+    if (!flip) {                                                 // kout = co, kin = ci: row = co, 144 floats from ci = c0
+        const int row = lane >> 1, half = lane & 1;
+        const bool ok = k0 + row < Kout;
+        const float* src = w + ((size_t)(k0 + row) * Cin + c0) * 9 + half * 72;
+        float* dst = T + row * WU_ROW + half * 72;
+#pragma unroll
+        for (int i = 0; i < 72; ++i) dst[i] = ok ? src[i] : 0.f;
+    } else {                                                     // kout = ci, kin = co: row = co (16), 288 floats from ci = k0
+        const int row = lane >> 2, qt = lane & 3;
+        const float* src = w + ((size_t)(c0 + row) * Cin + k0 + qt * 8) * 9;
+#pragma unroll
+        for (int i = 0; i < 72; ++i) {
+            const int ko = qt * 8 + i / 9, t = i - (i / 9) * 9;
+            T[ko * WU_ROW + row * 9 + t] = k0 + ko < Kout ? src[i] : 0.f;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    float u[16][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int kin = step * CK2 + 8 * h + e;
-        float u = 0.f;
-        if (kout < Kout) {
-            const int co = flip ? kin : kout, ci = flip ? kout : kin;
-            const float* g = w + ((size_t)co * Cin + ci) * 9;
-            float t[3];
+        const float* gp = T + l31 * WU_ROW + (8 * h + e) * 9;
+        float g[3][3];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                float tt = 0.f;
+        for (int a_ = 0; a_ < 3; ++a_)
 #pragma unroll
-                for (int a = 0; a < 3; ++a) tt += G[r][a] * (flip ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b]);
-                t[b] = tt;
-            }
-            u = G[q][0] * t[0] + G[q][1] * t[1] + G[q][2] * t[2];
+            for (int b_ = 0; b_ < 3; ++b_) g[a_][b_] = flip ? gp[(2 - a_) * 3 + (2 - b_)] : gp[a_ * 3 + b_];
+        float t[4][3];                                           // G g: rows (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2)
+#pragma unroll
+        for (int b_ = 0; b_ < 3; ++b_) {
+            t[0][b_] = g[0][b_];
+            t[1][b_] = 0.5f * g[0][b_] + 0.5f * g[1][b_] + 0.5f * g[2][b_];
+            t[2][b_] = 0.5f * g[0][b_] - 0.5f * g[1][b_] + 0.5f * g[2][b_];
+            t[3][b_] = g[2][b_];
         }
-        u8[e] = u;
-    }
-    const X6Frag f = x6_split8(u8);
-    const size_t base = ((((size_t)(mb * 8 + wv) * nstep + step) * 2 + j) * 3 + a3) * 3 * 64 + lane;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) U3[base + (size_t)pc * 64] = __builtin_bit_cast(uint4, f.p[pc]);
+        for (int r = 0; r < 4; ++r) {
+            u[r * 4 + 0][e] = t[r][0];
+            u[r * 4 + 1][e] = 0.5f * t[r][0] + 0.5f * t[r][1] + 0.5f * t[r][2];
+            u[r * 4 + 2][e] = 0.5f * t[r][0] - 0.5f * t[r][1] + 0.5f * t[r][2];
+            u[r * 4 + 3][e] = t[r][2];
+        }
+    }
+    const int mb = mt / 3, a3 = mt - mb * 3;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        const X6Frag f = x6_split8(u[xi]);
+        const size_t base = ((((size_t)(mb * 8 + (xi >> 1)) * nstep + step) * 2 + (xi & 1)) * 3 + a3) * 3 * 64 + lane;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) U3[base + (size_t)pc * 64] = __builtin_bit_cast(uint4, f.p[pc]);
+    }
+}
+
+// units = ceil(Kout / 96) * 3 * (Kin / 16); four units (waves) per block
+__global__ __launch_bounds__(256) void wino3_weight_kernel(const float* __restrict__ w, uint4* __restrict__ U3, int Cout,
+                                                           int Cin, int flip, int nunit) {
+    __shared__ float T[4][32 * WU_ROW];
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit < nunit) wino3_weight_unit(w, U3, Cout, Cin, flip, unit, T[threadIdx.x >> 6]);
+}
+
+// The same transform for up to 32 (weight, direction) pairs in ONE launch: the owner of the weights (trainer.FlatAdam) rebuilds
+// every prepared image of its bucket right behind the optimizer step (mogan_wino_prep_group), so that no convolution of the
+// step transforms filters on its own chain.  Blocks of the members lie end to end on the grid.
+constexpr int WPG_MAX = 32;
+struct WinoPrepGroup { const float* w[WPG_MAX]; uint4* u3[WPG_MAX]; int Cout[WPG_MAX], Cin[WPG_MAX], flip[WPG_MAX]; unsigned end[WPG_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void wino3_weight_group_kernel(const WinoPrepGroup g) {
+    __shared__ float T[4][32 * WU_ROW];
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < WPG_MAX - 1; ++i) if (i + 1 < g.n && blockIdx.x >= g.end[i]) m = i + 1;
+    const unsigned start = m ? g.end[m - 1] : 0u;
+    const int Kin = g.flip[m] ? g.Cout[m] : g.Cin[m], Kout = g.flip[m] ? g.Cin[m] : g.Cout[m];
+    const int nunit = ((Kout + BM - 1) / BM) * 3 * (Kin / CK2);
+    const int unit = (int)(blockIdx.x - start) * 4 + (threadIdx.x >> 6);
+    if (unit < nunit) wino3_weight_unit(g.w[m], g.u3[m], g.Cout[m], g.Cin[m], g.flip[m], unit, T[threadIdx.x >> 6]);
 }
 
 __global__ __launch_bounds__(512) void wino3_fwd_kernel(const float* __restrict__ X, const uint4* __restrict__ U3,
@@ -766,8 +819,10 @@ __global__ __launch_bounds__(64) void wino_wgrad_finish(const float* __restrict_
 // another 1.2 %, profiles/r05_ab.txt).  Split-bf16 build only: the native-fp32 build takes the direct kernels.
 static int g_wino = -1;
 
-int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, int H, int W, int Cout, int KH, int KW,
-                   int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift, int ep_relu,
+// prep != nullptr: the caller's prepared filter image of THIS weight version and direction (mogan_wino_prep_group): no per-call
+// weight transform, the workspace is not touched.
+int mogan_wino_try(const float* in, const float* w, const void* prep, float* out, int B, int Cin, int H, int W, int Cout, int KH,
+                   int KW, int stride, int ph, int pw, int up, int dgrad, const float* ep_scale, const float* ep_shift, int ep_relu,
                    void* ws, size_t ws_bytes, hipStream_t st) {
 #if MOGAN_X6
     if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
@@ -789,7 +844,9 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
         return 0;
     // (+ one step of padding: the K loop's last iteration prefetches step nstep, whose scalar offset must stay inside the buffer)
     const size_t u3bytes = (size_t)mbs * 8 * (Kin / CK2) * 18 * 1024 + 18 * 1024;
-    if (!ws || u3bytes > ws_bytes || u3bytes >= (1ull << 31)) return 0;
+    if (u3bytes >= (1ull << 31)) return 0;
+    if (prep == nullptr && (!ws || u3bytes > ws_bytes)) return 0;
+    const uint4* U = prep ? (const uint4*)prep : (const uint4*)ws;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
@@ -798,11 +855,12 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     }
     // the 16-wave form where it applies: full 4 x 32 pixel tiles, 96-channel blocks, no fused affine epilogue
     // (-DMOGAN_WINO5=0 builds the library without it: the A/B reference of profiles/r06_ab.txt)
-    if (MOGAN_WINO5 && ep_scale == nullptr && (oH % (2 * TROWS)) == 0 && (oW % (2 * TCOLS)) == 0 && (Kout % BM) == 0 && u3bytes <= ws_bytes) {
+    const int nunit = (int)mbs * 3 * (Kin / CK2);
+    if (prep == nullptr)
+        hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nunit + 3) / 4)), dim3(256), 0, st, w, (uint4*)ws, Cout, Cin, dgrad, nunit);
+    if (MOGAN_WINO5 && ep_scale == nullptr && (oH % (2 * TROWS)) == 0 && (oW % (2 * TCOLS)) == 0 && (Kout % BM) == 0) {
         const long long nt5 = (long long)B * tiles_x * tiles_y * mbs;
-        hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((mbs * 8 * (Kin / CK2) * 2 * 3 * 64 + 255) / 256)), dim3(256), 0, st, w,
-                           (uint4*)ws, Cout, Cin, dgrad, mbs * 8 * (Kin / CK2) * 2 * 3 * 64);
-        hipLaunchKernelGGL(wino5_fwd_kernel, dim3((unsigned)std::min<long long>(nt5, ncu)), dim3(1024), 0, st, in, (const uint4*)ws, out,
+        hipLaunchKernelGGL(wino5_fwd_kernel, dim3((unsigned)std::min<long long>(nt5, ncu)), dim3(1024), 0, st, in, U, out,
                            Kin, iH, iW, Kout, oH, oW, pad, tiles_x, tiles_y, (int)nt5, (unsigned)(4ull * B * Kin * iH * iW),
                            (unsigned)u3bytes);
         return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
@@ -811,10 +869,7 @@ int mogan_wino_try(const float* in, const float* w, float* out, int B, int Cin, 
     if (ntile >= (1ll << 30)) return 0;
     // persistent: one 8-wave block per CU walks the tiles
     dim3 grid((unsigned)std::min<long long>(ntile, ncu));
-    const long long nfrag = mbs * 8 * (Kin / CK2) * 2 * 3 * 64;
-    hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, Cout, Cin, dgrad,
-                       nfrag);
-    hipLaunchKernelGGL(wino3_fwd_kernel, grid, dim3(512), 0, st, in, (const uint4*)ws, out, Kin, iH, iW, Kout, oH, oW, pad, tiles_x,
+    hipLaunchKernelGGL(wino3_fwd_kernel, grid, dim3(512), 0, st, in, U, out, Kin, iH, iW, Kout, oH, oW, pad, tiles_x,
                        tiles_y, (int)ntile, B, ep_scale, ep_shift, ep_relu, (unsigned)(4ull * B * Kin * iH * iW), (unsigned)u3bytes);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
 #else
@@ -856,4 +911,50 @@ int mogan_wino_wgrad_try(const float* dy, const float* x, float* dw, int B, int 
     hipLaunchKernelGGL(wino_wgrad_finish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const float*)ws, dw, Cout,
                        Cin, nsplit, accumulate);
     return hipGetLastError() == hipSuccess ? 1 : MOGAN_ERR_LAUNCH;
+}
+
+// ---- prepared filter images owned by the caller (include/mogan_hip.h: mogan_wino_prep_bytes / mogan_wino_prep_group) ---------
+size_t mogan_wino_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up, int dgrad) {
+#if MOGAN_X6
+    if (g_wino < 0) { const char* e = getenv("MOGAN_WINO"); g_wino = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_wino || !(KH == 3 && KW == 3 && stride == 1 && ph == pw && (ph == 0 || ph == 1) && up == 0)) return 0;
+    const int Kin = dgrad ? Cout : Cin, Kout = dgrad ? Cin : Cout;
+    const int cH = Hs + 2 * ph - 2, cW = Ws + 2 * pw - 2;
+    const int iH = dgrad ? cH : Hs, iW = dgrad ? cW : Ws, oH = dgrad ? Hs : cH, oW = dgrad ? Ws : cW;
+    if (cH < 2 || cW < 2 || (Kin % CK2) || Kin < 32 || Kout < 64) return 0;
+    const int tiles_x = (oW + 2 * TCOLS - 1) / (2 * TCOLS), tiles_y = (oH + 2 * TROWS - 1) / (2 * TROWS);
+    if ((double)oW * oH < 0.7 * (double)tiles_x * 2 * TCOLS * tiles_y * 2 * TROWS) return 0;
+    const long long mbs = (Kout + BM - 1) / BM;
+    if ((long long)B * Kin * iH * iW >= (1ll << 29) || (long long)Kin * iH * iW >= (1ll << 26) ||
+        (long long)B * Kout * oH * oW >= (1ll << 30))
+        return 0;
+    const size_t u3bytes = (size_t)mbs * 8 * (Kin / CK2) * 18 * 1024 + 18 * 1024;
+    return u3bytes < (1ull << 31) ? u3bytes : 0;
+#else
+    return 0;
+#endif
+}
+
+int mogan_wino_prep_group(int n, const float* const* w, void* const* prep, const int* Cout, const int* Cin, const int* dgrad,
+                          hipStream_t st) {
+#if MOGAN_X6
+    if (n < 0 || (n > 0 && (!w || !prep || !Cout || !Cin || !dgrad))) return MOGAN_ERR_SHAPE;
+    for (int i0 = 0; i0 < n; i0 += WPG_MAX) {
+        WinoPrepGroup g{}; unsigned tot = 0;
+        g.n = std::min(WPG_MAX, n - i0);
+        for (int i = 0; i < g.n; ++i) {
+            const int k = i0 + i;
+            const int Kin = dgrad[k] ? Cout[k] : Cin[k], Kout = dgrad[k] ? Cin[k] : Cout[k];
+            if (!w[k] || !prep[k] || (Kin % CK2) || Kin < 32 || Kout < 64 || (((uintptr_t)prep[k]) & 15)) return MOGAN_ERR_SHAPE;
+            const int nunit = ((Kout + BM - 1) / BM) * 3 * (Kin / CK2);
+            g.w[i] = w[k]; g.u3[i] = (uint4*)prep[k]; g.Cout[i] = Cout[k]; g.Cin[i] = Cin[k]; g.flip[i] = dgrad[k] ? 1 : 0;
+            tot += (unsigned)((nunit + 3) / 4);
+            g.end[i] = tot;
+        }
+        hipLaunchKernelGGL(wino3_weight_group_kernel, dim3(tot), dim3(256), 0, st, g);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+#else
+    return MOGAN_ERR_SHAPE;
+#endif
 }

@@ -39,6 +39,10 @@ SIGNATURES = {
     "mogan_affine_relu_bwd_out": [P, P, P, P, I, I, I, P],
     "mogan_conv2d_dgrad": [P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_wgrad": [P, P, P] + [I] * 12 + [P, Z, P],
+    "mogan_wino_prep_bytes": [I] * 12,
+    "mogan_wino_prep_group": [I, P, P, P, P, P, P],
+    "mogan_conv2d_fwd_wp": [P, P, P, P] + [I] * 11 + [P, Z, P],
+    "mogan_conv2d_dgrad_wp": [P, P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_pk_conv_eligible": [I] * 11,
     "mogan_pk_weight_bytes": [I] * 6,
     "mogan_pk_weight_pack": [P, P] + [I] * 8 + [P],
@@ -150,7 +154,8 @@ class TailArgs(ctypes.Structure):               # MoganTailArgs
                 ("panel", P), ("CGp", I), ("cg0", I), ("B", I), ("n", I), ("H", I), ("W", I)]
 
 
-_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z}
+_RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z,
+            "mogan_wino_prep_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
 _lib = None

@@ -333,6 +333,10 @@ class WeightPacks:
         self.cell = version_cell if version_cell is not None else [0]
         self.slots = {}
         self.elig = {}
+        # prepared Winograd filter images (round 6; include/mogan_hip.h "Prepared filter images"): wino[dgrad] = [buffer, version,
+        # global epoch, event, stream, prepared inside a capture]; wbytes[(dgrad, geometry)] = image size, 0 = not a Winograd layer
+        self.wino = {}
+        self.wbytes = {}
 
     def _pack(self, dgrad, slot):
         Cout, Cin, KH, KW = self.w.shape
@@ -364,6 +368,33 @@ class WeightPacks:
         for dgrad, slot in self.slots.items():
             self._pack(dgrad, slot)
 
+    # -- Winograd images -------------------------------------------------------------------------------------------------
+    def wino_stale(self):
+        """(dgrad, slot) of every image in use that is older than the weight"""
+        return [(d, sl) for d, sl in self.wino.items() if sl[1] != self.cell[0] or sl[2] != _PK_GLOBAL[0]]
+
+    def _wino_mark(self, sl, ev, st, cap):
+        sl[1], sl[2], sl[3], sl[4], sl[5] = self.cell[0], _PK_GLOBAL[0], ev, st, cap
+
+    def wino_pointer(self, dgrad, B, Hs, Ws, stride, ph, pw, up):
+        """device pointer of this weight's prepared filter image for the direction, current and ordered before a use on the
+        current stream -- or None: the convolution does not take the Winograd kernels (or the library is a native-fp32 build)"""
+        key = (dgrad, B, Hs, Ws, stride, ph, pw, up)
+        nb = self.wbytes.get(key)
+        if nb is None:
+            Cout, Cin, KH, KW = self.w.shape
+            nb = self.wbytes[key] = int(lib.load().mogan_wino_prep_bytes(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, dgrad))
+        if not nb:
+            return None
+        sl = self.wino.get(dgrad)
+        if sl is None or sl[0].numel() < nb:
+            sl = self.wino[dgrad] = [torch.empty(nb, dtype=torch.uint8, device=self.w.device), -1, -1, None, None, False]
+        if sl[1] != self.cell[0] or sl[2] != _PK_GLOBAL[0]:
+            wino_prep([(self, dgrad, sl)])
+        elif sl[4] != stream_ptr() and (sl[5] or not lib._capturing()):
+            torch.cuda.current_stream().wait_event(sl[3])
+        return sl[0].data_ptr()
+
     def _fresh(self, key, slot):
         """make the copy in `slot` current for a use on the current stream"""
         if slot[1] != self.cell[0] or slot[2] != _PK_GLOBAL[0]:
@@ -393,6 +424,50 @@ class WeightPacks:
         return self._fresh(dgrad, slot)
 
 
+def wino_prep(items):
+    """(WeightPacks, dgrad, slot) triples -> their Winograd filter images rebuilt in ONE launch (mogan_wino_prep_group) on the
+    current stream"""
+    import ctypes
+    n = len(items)
+    if not n:
+        return
+    VP, CI = ctypes.c_void_p * n, ctypes.c_int * n
+    ws = VP(*[it[0].w.data_ptr() for it in items])
+    ps = VP(*[it[2][0].data_ptr() for it in items])
+    co = CI(*[int(it[0].w.shape[0]) for it in items])
+    ci = CI(*[int(it[0].w.shape[1]) for it in items])
+    dg = CI(*[int(it[1]) for it in items])
+    st = stream_ptr()
+    call("mogan_wino_prep_group", n, ctypes.cast(ws, ctypes.c_void_p), ctypes.cast(ps, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p),
+         ctypes.cast(ci, ctypes.c_void_p), ctypes.cast(dg, ctypes.c_void_p), st)
+    ev = torch.cuda.Event()
+    ev.record()
+    cap = bool(lib._capturing())
+    for pk, _, sl in items:
+        pk._wino_mark(sl, ev, st, cap)
+    PK_STATS["wino_preps"] = PK_STATS.get("wino_preps", 0) + 1
+
+
+def repack_all(packs):
+    """Every derived weight image of a bucket brought up to date on the current stream (the owner changed the weights): the
+    packed panels pack by pack, the Winograd filter images of all of them in one launch."""
+    items = []
+    for pk in packs:
+        pk.repack()
+        items += [(pk, d, sl) for d, sl in pk.wino.items()]
+    wino_prep(items)
+
+
+def _wino_prep_ptr(w, dgrad, B, Hs, Ws, stride, ph, pw, up):
+    pk = getattr(w, "_mogan_pk", None)
+    if pk is None or not WINO_PREP:
+        return None
+    return pk.wino_pointer(dgrad, B, Hs, Ws, stride, ph, pw, up)
+
+
+WINO_PREP = True      # (module attribute: False = every Winograd convolution transforms its filters per call, as without an owner)
+
+
 def attach_packs(w, version_cell=None):
     pk = getattr(w, "_mogan_pk", None)
     if pk is None:
@@ -400,7 +475,7 @@ def attach_packs(w, version_cell=None):
     elif version_cell is not None and pk.cell is not version_cell:
         # a new owner (a second FlatAdam over the same network): its version counter rules from now on
         pk.cell = version_cell
-        for slot in pk.slots.values():
+        for slot in list(pk.slots.values()) + list(pk.wino.values()):
             slot[1] = -1
     return pk
 
@@ -433,6 +508,11 @@ def conv2d_forward(x, w, stride, ph, pw, up):
     OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, up)
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     wsp, wsn = workspace(x.device)
+    wprep = _wino_prep_ptr(w, 0, B, Hs, Ws, stride, ph, pw, up) if KH == 3 and KW == 3 and stride == 1 else None
+    if wprep is not None:        # the owner's prepared Winograd filter image of this weight version (no transform launch here)
+        call("mogan_conv2d_fwd_wp", ptr(x), ptr(w), wprep, ptr(y), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
+             wsp, wsn, stream_ptr())
+        return y
     call("mogan_conv2d_fwd", ptr(x), ptr(w), ptr(y), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
          wsp, wsn, stream_ptr())
     return y
@@ -453,8 +533,13 @@ def conv2d_dgrad(dy, w, x_shape, stride, ph, pw, up):
         call("mogan_upconv3x3_dgrad", ptr(dy), ptr(w), ptr(dx), B, Cin, Hs, Ws, Cout, wsp, wsn, stream_ptr())
         return dx
     du = torch.empty((B, Cin, Hs << up, Ws << up), dtype=torch.float32, device=dy.device)
-    call("mogan_conv2d_dgrad", ptr(dy), ptr(w), ptr(du), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
-         wsp, wsn, stream_ptr())
+    wprep = _wino_prep_ptr(w, 1, B, Hs, Ws, stride, ph, pw, up) if KH == 3 and KW == 3 and stride == 1 else None
+    if wprep is not None:
+        call("mogan_conv2d_dgrad_wp", ptr(dy), ptr(w), wprep, ptr(du), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
+             wsp, wsn, stream_ptr())
+    else:
+        call("mogan_conv2d_dgrad", ptr(dy), ptr(w), ptr(du), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
+             wsp, wsn, stream_ptr())
     if not up:
         return du
     dx = torch.empty((B, Cin, Hs, Ws), dtype=torch.float32, device=dy.device)

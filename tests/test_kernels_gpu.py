@@ -867,6 +867,79 @@ def test_packed_weight_convolution(case, force):
         ops.pk_debug_force(0, -1, 0)
 
 
+@pytest.mark.parametrize("case", [(2, 96, 16, 32, 192), (3, 64, 12, 64, 96), (2, 32, 20, 96, 160), (1, 48, 9, 11, 64)])
+def test_winograd_prepared_filter_images(case):
+    """Round 6 (include/mogan_hip.h "Prepared filter images"): a weight with an owner (ops.attach_packs) keeps its Winograd filter
+    images -- one per direction, built by mogan_wino_prep_group -- and its convolutions go through mogan_conv2d_fwd_wp /
+    mogan_conv2d_dgrad_wp; without an owner the same convolution transforms the filters per call.  Both must give the SAME
+    bits (same kernels, same image), a changed weight must be re-prepared by its owner (lazily at the next use after touch(),
+    all images of a bucket in one launch after step()), and a geometry the Winograd kernels decline gets no image."""
+    B, Cin, H, W, Cout = case
+    x = T("wpx%s" % (case,), (B, Cin, H, W)).to(DEV)
+    w0 = T("wpw%s" % (case,), (Cout, Cin, 3, 3), 0.2).to(DEV)
+    g = T("wpg%s" % (case,), (B, Cout, H, W)).to(DEV)
+    y_ref, dx_ref = ops.conv2d_forward(x, w0, 1, 1, 1, 0), ops.conv2d_dgrad(g, w0, x.shape, 1, 1, 1, 0)   # no owner: per-call transform
+    w = w0.clone()
+    pk = ops.attach_packs(w)
+    before = ops.PK_STATS.get("wino_preps", 0)
+    y, dx = ops.conv2d_forward(x, w, 1, 1, 1, 0), ops.conv2d_dgrad(g, w, x.shape, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    filled = H * W >= 0.7 * (-(-H // 4) * 4) * (-(-W // 32) * 32)
+    takes = [bool(lib.load().mogan_wino_prep_bytes(B, Cin, H, W, Cout, 3, 3, 1, 1, 1, 0, d)) for d in (0, 1)]
+    assert takes[0] == (filled and Cin % 16 == 0 and Cin >= 32 and Cout >= 64)
+    assert takes[1] == (filled and Cout % 16 == 0 and Cout >= 32 and Cin >= 64)
+    ntk = int(takes[0]) + int(takes[1])
+    assert sorted(pk.wino) == [d for d in (0, 1) if takes[d]] and ops.PK_STATS.get("wino_preps", 0) == before + ntk
+    assert torch.equal(y, y_ref) and torch.equal(dx, dx_ref)
+    y_again = ops.conv2d_forward(x, w, 1, 1, 1, 0)                 # a current image is not rebuilt
+    assert ops.PK_STATS.get("wino_preps", 0) == before + ntk and torch.equal(y_again, y_ref)
+    takes = ntk > 0
+    with torch.no_grad():
+        w.mul_(-0.5)
+    pk.cell[0] += 1                                               # FlatAdam.touch(): rebuilt at the next use
+    y2 = ops.conv2d_forward(x, w, 1, 1, 1, 0)
+    assert torch.equal(y2, ops.conv2d_forward(x, w0 * -0.5, 1, 1, 1, 0))
+    with torch.no_grad():
+        w.mul_(-3.0)
+    pk.cell[0] += 1
+    n0 = ops.PK_STATS.get("wino_preps", 0)
+    ops.repack_all([pk])                                          # FlatAdam.step(): every image in use, one launch
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + (1 if takes else 0)
+    y3, dx3 = ops.conv2d_forward(x, w, 1, 1, 1, 0), ops.conv2d_dgrad(g, w, x.shape, 1, 1, 1, 0)
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + (1 if takes else 0)
+    assert torch.equal(y3, ops.conv2d_forward(x, w0 * 1.5, 1, 1, 1, 0)) and torch.equal(dx3, ops.conv2d_dgrad(g, w0 * 1.5, x.shape, 1, 1, 1, 0))
+    _check(y3, 1.5 * F.conv2d(x.double().cpu(), w0.double().cpu(), None, 1, 1), what="fwd against fp64")
+
+
+def test_winograd_prepared_images_of_many_weights_in_one_call():
+    """mogan_wino_prep_group with more members than one launch holds (32): 20 weights of four shapes, both directions = 40 images"""
+    shapes = [(192, 96), (96, 96), (64, 32), (160, 48)]
+    ws, pks = [], []
+    x = {ci: T("wgx%d" % ci, (2, ci, 8, 32)).to(DEV) for ci in (96, 32, 48)}
+    for i in range(20):
+        co, ci = shapes[i % 4]
+        w = T("wgw%d" % i, (co, ci, 3, 3), 0.2).to(DEV)
+        ws.append(w)
+        pks.append(ops.attach_packs(w.clone()))
+    for pk in pks:                                               # allocate the slots (lazily prepared, one by one)
+        ci = pk.w.shape[1]
+        ops.conv2d_forward(x[ci], pk.w, 1, 1, 1, 0)
+        ops.conv2d_dgrad(torch.zeros(2, pk.w.shape[0], 8, 32, device=DEV), pk.w, x[ci].shape, 1, 1, 1, 0)
+    with torch.no_grad():
+        for pk in pks:
+            pk.w.mul_(2.0)
+            pk.cell[0] += 1
+    n0 = ops.PK_STATS.get("wino_preps", 0)
+    ops.repack_all(pks)
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + 1
+    for w, pk in zip(ws, pks):
+        ci = w.shape[1]
+        assert torch.equal(ops.conv2d_forward(x[ci], pk.w, 1, 1, 1, 0), ops.conv2d_forward(x[ci], w * 2.0, 1, 1, 1, 0))
+        gy = T("wgg%d" % w.shape[0], (2, w.shape[0], 8, 32)).to(DEV)
+        assert torch.equal(ops.conv2d_dgrad(gy, pk.w, x[ci].shape, 1, 1, 1, 0), ops.conv2d_dgrad(gy, w * 2.0, x[ci].shape, 1, 1, 1, 0))
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + 1
+
+
 PK_WGRAD_CASES = PK_CASES + [
     (4, 20, 9, 7, 50, 3, 2, 1),        # nothing aligned: Cin, Cout, the map and K = 4*5*4 = 80 output pixels (padded to 96)
     (33, 16, 4, 4, 40, 4, 1, 0),       # 1x1 outputs: K = 33

@@ -15,8 +15,9 @@ if [ "$DATASET" = "coco-attngan" ]; then
         HIP_VISIBLE_DEVICES="$GPU" python main.py --cfg cfg/coco_train.yml --gpu "$GPU" "${@:3}"
     fi
 elif [ "$DATASET" = "mnist" ] || [ "$DATASET" = "clevr" ] || [ "$DATASET" = "coco-stackgan-1" ] || [ "$DATASET" = "coco-stackgan-2" ]; then
-    # the StackGAN-style trees: same step on the same kernels, single process; their real-data Datasets are not built
-    # (SURVEY.md section 8(f)), so pass  --synthetic N  after the GPU id:  sh train.sh clevr 0 --synthetic 4096
+    # the StackGAN-style trees: same step on the same kernels, single process.  Real data: the trees' own TextDatasets
+    # (stackgan/datasets.py, round 5) read cfg.DATA_DIR; without the data sets pass  --synthetic N  after the GPU id:
+    #     sh train.sh clevr 0 --synthetic 4096
     case "$DATASET" in
         mnist)           MOD=multi_mnist; CFG=mnist_train.yml;   echo "Starting training on the Multi-MNIST data set." ;;
         clevr)           MOD=clevr;       CFG=clevr_train.yml;   echo "Starting training on the CLEVR data set." ;;

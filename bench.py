@@ -186,7 +186,9 @@ def roofline_leg(engine, run_step, steps=2):
             name = "gemm_kernel<%s,%s>" % (MODES[int(m)], TILES[int(c)])
         elif int(m) == 6:
             name = "wino_wgrad_kernel" if int(c) == 1 else "dconv_wgrad_kernel"
-        elif int(c) == 1:       # fused Winograd F(2x2,3x3): flops = the 16/36 of the direct multiplies it executes
+        elif int(c) == 3:       # fused Winograd F(2x2,3x3), 16 waves per block (round 6): flops = the 16/36 of the direct multiplies it executes
+            name = "wino5_fwd_kernel<%s>" % MODES[int(m)][6:]
+        elif int(c) == 1:       # the 8-wave form (ragged tile grids, fused affine epilogue: the frozen encoder's stem)
             name = "wino3_fwd_kernel<%s>" % MODES[int(m)][6:]
         elif int(c) == 2:       # the pre-split direct kernel (csrc/mogan_dconv2.hip, round 5)
             name = "dconv2_fwd_kernel<%s>" % MODES[int(m)][6:]
@@ -470,10 +472,27 @@ def main():
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d (plain `python bench.py --gpus N` launches its own ranks)" % (
         world, args.gpus)
 
+    # wall clock per phase of this run -> stderr and `phase_s` of the line (the driver's bench run took 491 s
+    # around a 0.73 s timed region).  On the builder's boxes the whole default run is 102 s: initialisation 2 s (the orthogonal
+    # init of D_NET256's largest layer is 1.1 s), warm-up + timed region 4 s, roofline leg 0.2 s, CPU oracle + parity 94 s
+    # (profiles/r06_ab.txt); what a run spends beyond that is outside this process (first import of torch on a fresh box) or the
+    # host's CPU leg -- the line says which
+    phase_s, _t_phase = {}, [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        phase_s[name] = round(phase_s.get(name, 0.0) + now - _t_phase[0], 2)
+        _t_phase[0] = now
+        if rank == 0:
+            print("[bench] %-28s %7.1f s" % (name, phase_s[name]), file=sys.stderr, flush=True)
+
+    lap("import + device + process group")
     set_coco_train_defaults()
     B = args.batch
     cfg.TRAIN.BATCH_SIZE = B
     text_encoder, image_encoder, netG, netsD = build_networks(device=device, seed=1234)   # identical replicas
+    torch.cuda.synchronize()
+    lap("build_networks (init)")
     use_graph = (world == 1) and args.graph and not args.no_graph
     dist_on = world > 1 or force_dist
     batch, bt_cpu = make_device_batch(B, seed=rank, device=device)
@@ -546,7 +565,9 @@ def main():
             os.environ["MOGAN_BRANCH_GRAPHS_DP"] = "1" if mode == "branch_graphs" else "0"
         engine = TrainEngine(text_encoder, image_encoder, netG, netsD, distributed=dist_on, use_graph=use_graph and not force_dist)
         run_step = make_runner(engine)
+        lap("engine construction")
         elapsed, host_elapsed, logs, comm = timed_region(engine, run_step)
+        lap("warm-up + timed region")
         results[mode] = dict(elapsed=elapsed, host_elapsed=host_elapsed, logs=logs, comm=comm,
                              launch="hipGraph" if engine.use_graph else "%s, %d streams + wgrad side streams" % (
                                  "generator eager + discriminator branches as hipGraphs" if engine.branch_graphs else "eager",
@@ -584,6 +605,7 @@ def main():
         rows, eager_ms = roofline_leg(engine, run_step)
         if world > 1:
             dist.barrier()
+        lap("roofline leg")
     if rank == 0 and rows is not None:
         fams = {}
         for r in rows:                                   # kernel families = the three MFMA kernels of csrc/
@@ -630,10 +652,12 @@ def main():
                                                               budget_s=max(150.0, 45.0 * (1 + args.cpu_steps)))
         out["cpu_baseline"]["sample"] += "; --cpu-steps %d%s" % (args.cpu_steps, "" if args.cpu_steps >= 5 else
                                                                " (the default run's bounded sample; --cpu-steps 5 = BASELINE.md's five)")
+        lap("cpu_baseline + parity")
     if world > 1 or force_dist:
         dist.destroy_process_group()
     if os.environ.get("MOGAN_CHAIN_EVENTS") and rank == 0:       # diagnostic: where the main stream (generator chain) spends the step
         out["chain_ms"] = engine.chain_report()
+    out["phase_s"] = phase_s
     if rank == 0:                      # the JSON line is the last thing on stdout (RCCL prints its banner there too, through C stdio:
         sys.stdout.flush()             # flush that buffer first, or the banner lands behind the line at exit)
         try:

@@ -860,6 +860,7 @@ int mogan_wino_try(const float* in, const float* w, const void* prep, float* out
         hipLaunchKernelGGL(wino3_weight_kernel, dim3((unsigned)((nunit + 3) / 4)), dim3(256), 0, st, w, (uint4*)ws, Cout, Cin, dgrad, nunit);
     if (MOGAN_WINO5 && ep_scale == nullptr && (oH % (2 * TROWS)) == 0 && (oW % (2 * TCOLS)) == 0 && (Kout % BM) == 0) {
         const long long nt5 = (long long)B * tiles_x * tiles_y * mbs;
+        mogan_prof_relabel(3);                              // (bench.py roofline leg: this launch is wino5_fwd_kernel's)
         hipLaunchKernelGGL(wino5_fwd_kernel, dim3((unsigned)std::min<long long>(nt5, ncu)), dim3(1024), 0, st, in, U, out,
                            Kin, iH, iW, Kout, oH, oW, pad, tiles_x, tiles_y, (int)nt5, (unsigned)(4ull * B * Kin * iH * iW),
                            (unsigned)u3bytes);

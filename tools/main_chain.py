@@ -1,4 +1,4 @@
-"""Kernels of the MAIN stream (the generator's chain: the stream that runs wino_fwd_kernel) in one steady-state step of a rocprofv3
+"""Kernels of the MAIN stream (the generator's chain: the stream that runs wino5_fwd_kernel) in one steady-state step of a rocprofv3
 kernel trace, by name: launches and time, split at the longest idle gap (the window in which the stream waits for the side branches)
 into the forward and the backward part.  python tools/main_chain.py <kernel_trace.csv> [step]"""
 import collections
@@ -13,7 +13,7 @@ adam = [x for x in ev if "adam_kernel" in x[2]]
 ends = [adam[i][1] for i in range(3, len(adam), 4)]
 t0, t1 = ends[which - 1], ends[which]
 win = [x for x in ev if t0 <= x[0] < t1]
-main = collections.Counter(x[3] for x in win if "wino3_fwd" in x[2]).most_common(1)[0][0]
+main = collections.Counter(x[3] for x in win if "wino5_fwd" in x[2]).most_common(1)[0][0]     # (round 6: wino5_fwd_kernel; wino3 is the encoder stem's)
 ms = [x for x in win if x[3] == main]
 gap, cut = max((ms[i + 1][0] - ms[i][1], i) for i in range(len(ms) - 1))
 

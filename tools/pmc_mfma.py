@@ -3,7 +3,7 @@ python tools/pmc_mfma.py <counter_collection.csv> <kernel_trace.csv> <out.json>"
 import csv, json, re, sys, collections
 cc, kt, out = sys.argv[1:4]
 FAM = ("pgemm_group_kernel", "pgemm_kernel", "gemm_group_kernel", "gemm_kernel", "dconv2_fwd_kernel", "dconv_fwd_kernel",
-       "dconv_wgrad_kernel", "wino3_fwd_kernel", "wino_wgrad_kernel")      # (longer names first: "gemm_kernel" is a substring of three)
+       "dconv_wgrad_kernel", "wino3_fwd_kernel", "wino5_fwd_kernel", "wino_wgrad_kernel")      # (longer names first: "gemm_kernel" is a substring of three)
 def fam(name):
     for f in FAM:
         if f in name:

@@ -19,7 +19,7 @@ import sys
 from collections import defaultdict
 
 KEEP = ("gemm_kernel", "pgemm_kernel", "pgemm_group_kernel", "dconv_fwd_kernel", "dconv2_fwd_kernel", "dconv_wgrad_kernel",
-        "wino3_fwd_kernel", "wino_wgrad_kernel")
+        "wino3_fwd_kernel", "wino5_fwd_kernel", "wino_wgrad_kernel")
 
 
 def short(name):
@@ -28,7 +28,7 @@ def short(name):
     m = re.search(r"(pgemm_group_kernel|pgemm_kernel|gemm_kernel|dconv2_fwd_kernel|dconv_fwd_kernel|dconv_wgrad_kernel|wino3_fwd_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2))
-    for k in ("wino3_fwd_kernel", "wino_wgrad_kernel"):
+    for k in ("wino3_fwd_kernel", "wino5_fwd_kernel", "wino_wgrad_kernel"):
         if k in name:
             return k + "<>"
     return None

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything under profiles/<round>_* that is measured (run on the GPU box; copy gpurun_out/<round>_* to profiles/ afterwards)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; RN=${ROUND:-r05}; export ROUND=$RN; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; RN=${ROUND:-r06}; export ROUND=$RN; cd $R
 ROUND=$RN bash tools/refresh_profiles.sh
 MOGAN_LAYERS_CSV=$O/${RN}_layers_single_stream.csv python bench.py --no-cpu-baseline > /dev/null 2>&1
 bash tools/pmc_mfma.sh

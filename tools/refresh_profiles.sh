@@ -2,7 +2,7 @@
 # Regenerates the judged artefacts under gpurun_out/ on the GPU box (copy them to profiles/ afterwards):
 #   <round>_pmc_traffic.json, ${RN}_bench_kernel_stats{,_multistream}.csv, ${RN}_bench_n1.json.log, ${RN}_family_bench_n1.jsonl
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-RN=${ROUND:-r05}
+RN=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp
 E="MOGAN_FAST_INIT=1 MOGAN_STREAMS=0 MOGAN_WGRAD_STREAM=0 MOGAN_GRAPH_ENCODER=0"
 B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"

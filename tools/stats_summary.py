@@ -3,7 +3,7 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 13.0
 skip = ('rocsolver', 'rocblas', 'Cijk', 'larf', 'trmm')
-mf = ('pgemm_kernel', 'pgemm_group_kernel', 'gemm_kernel', 'gemm_group_kernel', 'dconv_fwd', 'dconv2_fwd', 'dconv_wgrad', 'wino3_fwd', 'wino_wgrad_kernel')
+mf = ('pgemm_kernel', 'pgemm_group_kernel', 'gemm_kernel', 'gemm_group_kernel', 'dconv_fwd', 'dconv2_fwd', 'dconv_wgrad', 'wino3_fwd', 'wino5_fwd', 'wino_wgrad_kernel', 'stem_k4s2')
 out = []
 for r in rows:
     n = r['Name']

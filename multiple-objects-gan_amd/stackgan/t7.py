@@ -33,9 +33,17 @@ class _Reader(object):
             raise EOFError("truncated t7 file")
         return struct.unpack("<" + fmt, b)
 
+    def _bytes(self, n):
+        if n < 0:
+            raise ValueError("t7: negative length %d" % n)
+        b = self.f.read(n)
+        if len(b) != n:
+            raise EOFError("truncated t7 file")
+        return b
+
     def _string(self):
         (n,) = self._raw("i")
-        return self.f.read(n)
+        return self._bytes(n)
 
     def obj(self):
         (tag,) = self._raw("i")
@@ -54,7 +62,8 @@ class _Reader(object):
                 return self.memo[idx]
             (n,) = self._raw("i")
             t = Table()
-            self.memo[idx] = t
+            self.memo[idx] = t            # (a table that refers to ITSELF keeps this Table object inside; the caller gets the
+            #                               list form below -- cycles do not occur in the files this reader is for, val_captions.t7)
             for _ in range(n):
                 k = self.obj()
                 t[k] = self.obj()
@@ -73,7 +82,7 @@ class _Reader(object):
             if kind.endswith("Storage"):
                 (n,) = self._raw("q")
                 dt = np.dtype(_DT[kind[:-7]])
-                a = np.frombuffer(self.f.read(n * dt.itemsize), dtype=dt).copy()
+                a = np.frombuffer(self._bytes(n * dt.itemsize), dtype=dt).copy()
             elif kind.endswith("Tensor"):
                 (nd,) = self._raw("i")
                 size = self._raw("%dq" % nd) if nd else ()

@@ -772,6 +772,9 @@ struct PkCfg { int tm, tn; };
 static const PkCfg kPk[] = {{1, 2}, {1, 4}, {2, 2}};
 enum { NPK = 3 };
 static int g_pk_cfg = -1, g_pk_split = 0;
+#ifndef PK_OCC12
+#define PK_OCC12 3            // waves per SIMD of the 128 x 64 tile (lab: 4 with -DPK_NSET=2)
+#endif
 #ifndef PK_G64_OCC
 #define PK_G64_OCC 2
 #endif
@@ -822,7 +825,7 @@ static int run_pk(PkP& p, void* ws, size_t ws_bytes, int prof_mode, hipStream_t 
     switch (best) {
         case 1: launch_pk<1, 4, 2>((unsigned)blocks, st, p); break;
         case 2: launch_pk<2, 2, 2>((unsigned)blocks, st, p); break;
-        default: launch_pk<1, 2, 3>((unsigned)blocks, st, p); break;
+        default: launch_pk<1, 2, PK_OCC12>((unsigned)blocks, st, p); break;
     }
     mogan_prof_end(1, st);
     if (p.nsplit > 1 && !keep_slabs) mogan_splitk_reduce_dense((const float*)ws, p.C, c_numel, p.nsplit, p.accumulate, st);

@@ -459,9 +459,9 @@ def create_engine_streams(n_discriminators=3, touch=True):
 
 
 class TrainEngine:
-    G_GRAPH_VARIANTS = 4       # generator forward graphs kept per engine, one per shape of the text tensors (see _g_graph_for)
-
     """Device-side state of one rank: networks, flat optimizers, DP communicator, optional hipGraph."""
+
+    G_GRAPH_VARIANTS = 4       # generator forward graphs kept per engine, one per shape of the text tensors (see _g_graph_for)
 
     def __init__(self, text_encoder, image_encoder, netG, netsD, distributed=False, use_graph=False, branch_graphs=None):
         self.text_encoder, self.image_encoder, self.netG, self.netsD = text_encoder, image_encoder, netG, netsD

@@ -1,5 +1,5 @@
 """mogan_stem.hip (conv4x4 s2 p1 from 3 channels + LeakyReLU) against fp64 torch, and its time beside the implicit-GEMM kernel
-(MOGAN_STEM=0)."""
+(round 5: MOGAN_STEM=0; the switch is gone since round 6, the comparison stays on record in profiles/r05_ab.txt)."""
 import os, sys, torch
 import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

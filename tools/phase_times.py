@@ -1,6 +1,5 @@
-"""Device-synchronised wall time per phase of the eager train step (MOGAN_PHASE_TIMES=1; serialises the phases)."""
+"""Device-synchronised wall time per phase of the eager train step (TrainEngine.phase_times = True; serialises the phases)."""
 import os, sys, torch
-os.environ["MOGAN_PHASE_TIMES"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mogan_loader; mogan_loader.load()
@@ -11,6 +10,7 @@ set_coco_train_defaults()
 dev = torch.device("cuda", 0)
 te, ie, G, Ds = build_networks(device=dev, seed=1234)
 eng = TrainEngine(te, ie, G, Ds, use_graph=False)
+eng.phase_times = True
 batch, _ = bench.make_device_batch(16, 0, dev)
 def step():
     b = dict(batch); b["z"] = torch.randn(16, 100, device=dev); b["eps"] = torch.randn(16, 100, device=dev)

@@ -424,6 +424,9 @@ struct WGradP {
 // WIDE (3x3 s1 p1, no fused upsample, W % 4 == 0): the halo rows are fetched as aligned 16-byte quads covering the
 // columns [ox0-4, ox0+CW+4) -- 10 loads per row instead of 34 dword loads; every quad is entirely inside or outside
 // the image.  LDS column c of a row then holds image column ox0-4+c.
+#ifndef DCONV_WG_XCD
+#define DCONV_WG_XCD 1
+#endif
 #ifndef DCONV_WG_OCC
 #define DCONV_WG_OCC 2
 #endif
@@ -463,7 +466,13 @@ __global__ __launch_bounds__(256, DCONV_WG_OCC) void dconv_wgrad_kernel(const WG
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, sp = blockIdx.z;
+    // (the blocks of one pixel-tile range -- all (ci, co) blocks read the same dY / x tiles -- on one XCD: mma_xcd_block)
+#if DCONV_WG_XCD
+    unsigned bx_, by_, bz_; mma_xcd_block(bx_, by_, bz_);
+#else
+    const unsigned bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+#endif
+    const int n0 = bx_ * BN, m0 = by_ * BM, sp = bz_;
     const int ci_first = n0 / KHW;
     const int t_beg = sp * p.tps, t_end = min(p.ntiles, t_beg + p.tps);
     const int HsWs = p.Hs * p.Ws;

@@ -61,6 +61,21 @@ __device__ __forceinline__ mma_f32x16 x6_mfma(const X6Frag& a, const X6Frag& b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[x6_ia(term)], b.p[x6_ib(term)], acc, 0, 0, 0);
 }
 
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (own L2 each, 4 MB) by their linear index L; this maps L to
+// a logical index such that XCD k runs a CONTIGUOUS range of the logical sequence, in order: blocks that are neighbours in the logical
+// order (share an operand slice) sit on one XCD at the same time, and the slice is one L2 miss for all of them.
+__device__ __forceinline__ unsigned mma_xcd_order(unsigned L, unsigned total) {
+    const unsigned k = L & 7u, j = L >> 3, q = total >> 3, r = total & 7u;
+    return k * q + (k < r ? k : r) + j;
+}
+// the logical (x, y, z) of a block of a 3-D grid under that order, x fastest
+__device__ __forceinline__ void mma_xcd_block(unsigned& bx, unsigned& by, unsigned& bz) {
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned V = mma_xcd_order(L, gridDim.x * gridDim.y * gridDim.z);
+    bx = V % gridDim.x; V /= gridDim.x;
+    by = V % gridDim.y; bz = V / gridDim.y;
+}
+
 // acc[ta][tb] += sum over the 16 k-values (8 per lane half) of a[ta][.] * b[tb][.]
 template <int TM, int TN>
 __device__ __forceinline__ void mma_k16(const float (&a)[TM][8], const float (&b)[TN][8], mma_f32x16 (&acc)[TM][TN]) {

@@ -20,6 +20,15 @@
 #ifndef MOGAN_WINO5
 #define MOGAN_WINO5 1
 #endif
+#ifndef WGRAD_XCD
+#define WGRAD_XCD 1
+#endif
+#ifndef W5_XCD
+#define W5_XCD 1
+#endif
+#ifndef W5_NT
+#define W5_NT 1
+#endif
 
 namespace {
 
@@ -469,11 +478,25 @@ __global__ __launch_bounds__(1024) void wino5_fwd_kernel(const float* __restrict
             for (int a = 0; a < 3; ++a) acc[a] = x6_mfma(fa[a], fb, term, acc[a]);
     };
 
+    // Which items a block takes, in which order.  The L2 of an XCD (4 MB, 32 CUs) turns over every ~25 us under this kernel (78 KB of
+    // halo + 49 KB of output per CU and item): a halo row fetched for one tile is gone before the vertically adjacent tile -- two items
+    // later on the same CU -- asks for it, and every item pays its whole halo in 128-byte lines (measured: 3x the input bytes).  So the 32
+    // blocks of an XCD (workgroups are dealt round-robin: XCD = blockIdx & 7) work on 32 ADJACENT tiles at the same time -- round r,
+    // XCD k: spatial tiles (8 r + k) * 32 .. + 31 = 8 tile rows x 4 tile columns of one image -- so that a shared halo row is one L2 miss
+    // for all its readers; the channel blocks of a tile stay innermost.  (Other grids: a contiguous range per block.)
     const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
-    int tile = blockIdx.x * per;
-    const int tile_end = min(ntile, tile + per);
-    if (tile < tile_end) { plan(tile); load_x(0); }
-    for (; tile < tile_end; ++tile) {
+    const int nsp = ntile / mbs;
+    const bool super = W5_XCD && (gridDim.x & 7u) == 0 && nsp % (int)gridDim.x == 0;
+    const int bq = blockIdx.x & 7, bj = blockIdx.x >> 3, pxcd = gridDim.x >> 3;
+    auto item_tile = [&](int it) {                          // it-th item of this block -> combined index spatial * mbs + channel block
+        if (!super) return (int)blockIdx.x * per + it;
+        const int r = it / mbs, mb = it - r * mbs;
+        return (((r * 8 + bq) * pxcd + bj) * mbs + mb);
+    };
+    const int nit = super ? per : max(0, min(ntile, ((int)blockIdx.x + 1) * per) - (int)blockIdx.x * per);
+    int it = 0, tile = item_tile(0);
+    if (it < nit) { plan(tile); load_x(0); }
+    for (; it < nit; ++it) {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -498,7 +521,7 @@ __global__ __launch_bounds__(1024) void wino5_fwd_kernel(const float* __restrict
             __syncthreads();
         }
         const int cm0 = m0, cimg = img, coy0 = oy0, cox0 = ox0;
-        if (tile + 1 < tile_end) { plan(tile + 1); load_x(0); }
+        if (it + 1 < nit) { tile = item_tile(it + 1); plan(tile); load_x(0); }
         // ---- output transform, one 32-channel block (a) of all 16 positions per pass: Ts[position][channel 32][tile 32]
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -522,10 +545,15 @@ __global__ __launch_bounds__(1024) void wino5_fwd_kernel(const float* __restrict
                 }
                 const int oy = coy0 + 2 * (tp >> 3), ox = cox0 + 4 * (tp & 7);
                 float* o = Y + ((size_t)(cimg * Cout + cm0 + a * 32 + co) * OH + oy) * OW + ox;
-                *(float4*)o = make_float4(t0[0].x + t0[1].x + t0[2].x, t0[1].x - t0[2].x - t0[3].x,
-                                          t0[0].y + t0[1].y + t0[2].y, t0[1].y - t0[2].y - t0[3].y);
-                *(float4*)(o + OW) = make_float4(t1[0].x + t1[1].x + t1[2].x, t1[1].x - t1[2].x - t1[3].x,
-                                                 t1[0].y + t1[1].y + t1[2].y, t1[1].y - t1[2].y - t1[3].y);
+                const f32x4 y0 = {t0[0].x + t0[1].x + t0[2].x, t0[1].x - t0[2].x - t0[3].x, t0[0].y + t0[1].y + t0[2].y, t0[1].y - t0[2].y - t0[3].y};
+                const f32x4 y1 = {t1[0].x + t1[1].x + t1[2].x, t1[1].x - t1[2].x - t1[3].x, t1[0].y + t1[1].y + t1[2].y, t1[1].y - t1[2].y - t1[3].y};
+#if W5_NT       // the output is written once and not read again by this kernel: keep it from displacing the halos / filters in L2
+                __builtin_nontemporal_store(y0, (f32x4*)o);
+                __builtin_nontemporal_store(y1, (f32x4*)(o + OW));
+#else
+                *(f32x4*)o = y0;
+                *(f32x4*)(o + OW) = y1;
+#endif
             }
         }
     }
@@ -551,7 +579,13 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float Vs[2 * VSZ];
     __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    const int n0 = blockIdx.x * WBN, m0 = blockIdx.y * BM, sp = blockIdx.z;
+    // (the blocks of one K range -- all (ci, co) blocks read the same dY / x chunks -- on one XCD: mma_xcd_block)
+#if WGRAD_XCD
+    unsigned bx_, by_, bz_; mma_xcd_block(bx_, by_, bz_);
+#else
+    const unsigned bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+#endif
+    const int n0 = bx_ * WBN, m0 = by_ * BM, sp = bz_;
     const int k_beg = sp * cps, k_end = min(nchunk, k_beg + cps);
     const int plane = H * W;
     const int cgs = W / (2 * WCT), trs = H / 2;             // chunks per tile row, tile rows per image

@@ -40,7 +40,8 @@ def _worker(rank, world, port, q):
         flat.zero_grad()
         net(x).pow(2).mean().backward()                                   # mean-reduced loss, like BCE/KL
         assert allreduce_flat(flat.g) is None
-        q.put((rank, (flat.g / world).clone(), [o for o in flat.offsets]))
+        # numpy, not torch tensors: a tensor crosses the queue as a shared fd the exiting worker may close first
+        q.put((rank, (flat.g / world).numpy().copy(), [o for o in flat.offsets]))
     finally:
         dist.destroy_process_group()
 
@@ -54,6 +55,7 @@ def test_flat_bucket_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(g), o) for r, g, o in res]
     [p.join(30) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     # single process on the concatenated batch = mean of the shard gradients
@@ -110,7 +112,7 @@ def _gb_worker(rank, world, port, q):
         gh = torch.cat([p.grad.reshape(-1) for p in head.parameters()])
         dist.all_reduce(gb)
         dist.all_reduce(gh)                                         # what the flat-bucket exchange does: sum, then / world
-        q.put((rank, float(loss), gb / world, gh / world))
+        q.put((rank, float(loss), (gb / world).numpy().copy(), (gh / world).numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -126,6 +128,7 @@ def test_global_batch_loss_mode_world2():
     procs = [ctx.Process(target=_gb_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, l, torch.from_numpy(a), torch.from_numpy(b)) for r, l, a, b in res]
     [p.join(30) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     backbone, head = _toy()

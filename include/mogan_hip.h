@@ -192,6 +192,16 @@ int mogan_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci
 size_t mogan_wino_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up, int dgrad);
 int mogan_wino_prep_group(int n, const float* const* w, void* const* prep, const int* Cout, const int* Cin, const int* dgrad,
                           hipStream_t stream);
+/* The same for whichever kernel a convolution's geometry takes (round 6, third session): besides the Winograd image of a 3x3 s1 p1
+ * convolution, the pre-split filter image of dconv2_fwd_kernel for the discriminators' 4x4 s2 p1 convolutions
+ * (code/coco/attngan/model.py:575-613: forward over the space-to-depth image, data gradient by parity classes; csrc/mogan_dconv2.hip),
+ * which mogan_conv2d_fwd / _dgrad otherwise rebuild per call (44 prep launches per train step for weights that change once).
+ *   mogan_conv_prep_bytes   as mogan_wino_prep_bytes for any geometry: the size of the image mogan_conv2d_fwd_wp / _dgrad_wp expect as
+ *                           wprep for it (found by a dry run of the same dispatch), 0 = none
+ *   mogan_conv_prep_group   as mogan_wino_prep_group with the filter size KH[i] (3 or 4) per member: one launch per kind and 32 members */
+size_t mogan_conv_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up, int dgrad);
+int mogan_conv_prep_group(int n, const float* const* w, void* const* prep, const int* Cout, const int* Cin, const int* KH,
+                          const int* dgrad, hipStream_t stream);
 int mogan_conv2d_fwd_wp(const float* x, const float* w, const void* wprep, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH,
                         int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t stream);
 int mogan_conv2d_dgrad_wp(const float* dy, const float* w, const void* wprep, float* dx, int B, int Cin, int Hs, int Ws, int Cout,

@@ -48,6 +48,7 @@ struct DConvP {
     int accumulate;
     unsigned x_bytes, w_bytes;
     const void* Wp; unsigned wp_bytes;       // split-bf16 build: the filters as bf16 pieces in fragment order (dconv_wprep_kernel)
+    const void* d2prep; size_t* d2query;     // host side only: handed on to mogan_dconv2_fwd_try (mogan_internal.h)
 };
 
 #if MOGAN_X6
@@ -762,17 +763,18 @@ static int launch_fwd(DConvP& p, void* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (S == 1) {           // round 5: the pre-split form (mogan_dconv2.hip) where its tile grid fits
         if (p.up == 0) {
             const int rc2 = mogan_dconv2_fwd_try(p.X, p.Wt, 0, p.Y, p.B, p.Cin, p.Cout, p.H, p.W, p.OH, p.OW, KH, KW, p.pt, p.pl, p.yH,
-                                                 p.yW, p.ys, p.npar, p.accumulate, ws, ws_bytes, st);
+                                                 p.yW, p.ys, p.npar, p.accumulate, ws, ws_bytes, st, nullptr, p.d2query);
             if (rc2 != 0) return rc2 < 0 ? rc2 : 0;
         }
     }
     if constexpr (S == 2 && KH == 4 && KW == 4) {     // 4x4 s2 p1: the same kernel over the space-to-depth image of the input
         if (p.up == 0 && p.pt == 1 && p.pl == 1 && p.npar == 1 && p.ys == 1 && !p.accumulate) {
             const int rc2 = mogan_dconv2_fwd_try(p.X, p.Wt, 3, p.Y, p.B, p.Cin, p.Cout, p.H, p.W, p.OH, p.OW, 4, 4, 1, 1, p.yH, p.yW, 1, 1,
-                                                 0, ws, ws_bytes, st);
+                                                 0, ws, ws_bytes, st, p.d2prep, p.d2query);
             if (rc2 != 0) return rc2 < 0 ? rc2 : 0;
         }
     }
+    if (p.d2query) return MOGAN_ERR_WS;                  // dry run of the dispatch (mogan_conv_prep_bytes): nothing is launched
     // tile config: 96-wide M when it pads less
     const bool m96 = cdiv(p.Cout, 96) * 96 < cdiv(p.Cout, 128) * 128;
     const int bm = m96 ? 96 : 128;
@@ -882,7 +884,8 @@ static int launch_wgrad(WGradP& p, void* ws, size_t ws_bytes, hipStream_t st) {
 // ---- internal entry points (hidden visibility: not part of the C ABI) ---------------------------------------
 // return 1 = handled, 0 = not eligible (caller falls back to the implicit-GEMM kernel), <0 = error
 int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW,
-                        int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st, const void* d2prep,
+                        size_t* d2query) {
     const int H = Hs << up, W = Ws << up;
     const int OH = (H + 2 * ph - KH) / stride + 1, OW = (W + 2 * pw - KW) / stride + 1;
     const bool k33 = KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1;
@@ -896,6 +899,7 @@ int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin
     p.X = x; p.Wt = w; p.Y = y; p.B = B; p.Cin = Cin; p.Cout = Cout; p.Hs = Hs; p.Ws = Ws; p.H = H; p.W = W; p.up = up;
     p.OH = OH; p.OW = OW; p.pt = ph; p.pl = pw; p.yH = OH; p.yW = OW; p.ys = 1; p.y0 = 0; p.x0 = 0; p.accumulate = 0; p.npar = 1;
     p.x_bytes = 4u * B * Cin * Hs * Ws; p.w_bytes = 4u * Cout * Cin * KH * KW;
+    p.d2prep = d2prep; p.d2query = d2query;
     // 4x4 s2: round 1 (native fp32 MFMA) took it only at >= 64-pixel rows (124 vs 98 TF against the implicit GEMM at 64x64 output,
     // 98 vs 98 at 32x32, 90 vs 98 at 16x16: more M-blocks re-reading the same halo tile); with the pre-split filters of the
     // split-bf16 build it wins down to 16-pixel rows in the step (339.2 / 337.1 vs 337.8 / 335.6 img/s; MOGAN_DCONV_K44_MINOW)
@@ -910,7 +914,8 @@ int mogan_dconv_fwd_try(const float* x, const float* w, float* y, int B, int Cin
 
 // data gradient of the same two conv families; dx is (B,Cin,H,W) in the conv-input domain
 int mogan_dconv_dgrad_try(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, int KH,
-                          int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st) {
+                          int KW, int stride, int ph, int pw, int up, void* ws, size_t ws_bytes, hipStream_t st, const void* d2prep,
+                          size_t* d2query) {
     const int H = Hs << up, W = Ws << up;
     const int OH = (H + 2 * ph - KH) / stride + 1, OW = (W + 2 * pw - KW) / stride + 1;
     const bool k33 = KH == 3 && KW == 3 && stride == 1 && ph == 1 && pw == 1;
@@ -926,10 +931,12 @@ int mogan_dconv_dgrad_try(const float* dy, const float* w, float* dx, int B, int
         (long long)B * Cin * H * W >= (1ll << 30)) return 0;
     {   // round 5: the pre-split form takes the ORIGINAL filters (its prep kernel indexes them flipped / by parity class)
         const int rc2 = k33 ? mogan_dconv2_fwd_try(dy, w, 1, dx, B, Cout, Cin, OH, OW, H, W, 3, 3, KH - 1 - ph, KW - 1 - pw, H, W, 1, 1,
-                                                   0, ws, ws_bytes, st)
-                            : mogan_dconv2_fwd_try(dy, w, 2, dx, B, Cout, Cin, OH, OW, gH, gW, 2, 2, 0, 0, H, W, 2, 4, 0, ws, ws_bytes, st);
+                                                   0, ws, ws_bytes, st, nullptr, d2query)
+                            : mogan_dconv2_fwd_try(dy, w, 2, dx, B, Cout, Cin, OH, OW, gH, gW, 2, 2, 0, 0, H, W, 2, 4, 0, ws, ws_bytes, st,
+                                                   d2prep, d2query);
         if (rc2 != 0) return rc2;
     }
+    if (d2query) return 0;                               // dry run of the dispatch (mogan_conv_prep_bytes): nothing is launched
     float* wt = (float*)ws;                                          // transformed weights live at the head of ws
     void* ws2 = (char*)ws + ((wbytes + 255) & ~(size_t)255);
     const size_t ws2_bytes = ws_bytes - ((wbytes + 255) & ~(size_t)255);

@@ -111,6 +111,46 @@ __global__ __launch_bounds__(256) void dconv2_wprep_kernel(const float* __restri
     for (int pl = 0; pl < 3; ++pl) wp[base + pl * 2] = __builtin_bit_cast(uint4, f.p[pl]);
 }
 
+// The same for up to D2G_MAX weights in one launch (mogan_dconv2_prep_group: the owner of the weights rebuilds the images of a
+// bucket behind its optimizer step instead of one prep launch per convolution call)
+constexpr int D2G_MAX = 32;
+struct D2PrepGroup { const float* w[D2G_MAX]; uint4* wp[D2G_MAX]; int rows[D2G_MAX], Cin[D2G_MAX], NS[D2G_MAX], wmode[D2G_MAX], Cout1[D2G_MAX];
+                     unsigned end[D2G_MAX]; long long total[D2G_MAX]; int n; };
+
+__device__ __forceinline__ void dconv2_wprep_item(const float* __restrict__ w, uint4* __restrict__ wp, int rows, int Cin, int KHW, int NS,
+                                                  int wmode, int Cout1, long long t) {
+    const int half = (int)(t & 1); long long r = t >> 1;
+    const int tap = (int)(r % KHW); r /= KHW;
+    const int sub = (int)(r % NS); r /= NS;
+    const int row = (int)(r % rows); const int stage = (int)(r / rows);
+    const int c0 = (stage * NS + sub) * 16 + half * 8;
+    float v[8];
+    if (wmode == 3) {             // Cout1 = Ci of w
+        const int kh = 2 * (tap >> 1) + sub, kw = 2 * (tap & 1) + half;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[((size_t)row * Cout1 + stage * 8 + i) * 16 + kh * 4 + kw];
+    } else {                      // wmode 2: Cout1 = Ci of w (rows = 4 * Ci), Cin = Co of w
+        const int par = row / Cout1, ci = row - par * Cout1, py = par >> 1, px = par & 1;
+        const int kh = ((py + 1) & 1) + 2 * (1 - (tap >> 1)), kw = ((px + 1) & 1) + 2 * (1 - (tap & 1));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[((size_t)(c0 + i) * Cout1 + ci) * 16 + kh * 4 + kw];
+    }
+    const X6Frag f = x6_split8(v);
+    const size_t base = ((size_t)stage * rows + row) * (size_t)(NS * KHW * 6) + (size_t)(sub * KHW + tap) * 6 + half;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wp[base + pl * 2] = __builtin_bit_cast(uint4, f.p[pl]);
+}
+
+__global__ __launch_bounds__(256) void dconv2_wprep_group_kernel(const D2PrepGroup g) {
+    int m = 0;
+#pragma unroll 1
+    for (int i = 0; i < g.n - 1; ++i) if (blockIdx.x >= g.end[i]) m = i + 1;
+    const unsigned start = m ? g.end[m - 1] : 0u;
+    const long long t = (long long)(blockIdx.x - start) * 256 + threadIdx.x;
+    if (t >= g.total[m]) return;
+    dconv2_wprep_item(g.w[m], g.wp[m], g.rows[m], g.Cin[m], 4, g.NS[m], g.wmode[m], g.Cout1[m], t);
+}
+
 // CW = columns of the spatial tile (32: 8 rows x 32 columns, 16: 16 x 16 -- the maps with 16-pixel rows); S2D = the 2 x 2 filter
 // runs over the space-to-depth image of a stride-2 convolution's padded input: "pixel" (y, x) of sub-chunk dy, lane half dx is
 // X[c][2 y + dy - 1][2 x + dx - 1], a stage = 8 channels of X (NS = 2, KH = KW = 2)
@@ -343,8 +383,57 @@ static int launch2(D2P& p, hipStream_t st) {
     return p.tiles_cw == 32 ? launch2g<KH, KW, TM, NS, 32, false>(p, st) : launch2g<KH, KW, TM, NS, 16, false>(p, st);
 }
 
+// tile rows (tm) and sub-chunks per stage (ns) of a launch: functions of the channels and the form alone (not of the map size), so
+// that a filter image can be prepared ahead of the call.  Cin / Cout as the kernel sees them (s2d: Cin = 4 x the tensor's channels)
+static inline void d2_tile(bool s2d, bool k22, int Cin, int Cout, int& tm, int& ns) {
+    tm = 4; long long best = cdiv2(Cout, 128) * 128;
+    if (s2d) { tm = 3; best = cdiv2(Cout, 96) * 96; }
+    else if (cdiv2(Cout, 96) * 96 < best) { best = cdiv2(Cout, 96) * 96; tm = 3; }
+    if (cdiv2(Cout, 64) * 64 < best) { best = cdiv2(Cout, 64) * 64; tm = 2; }
+    ns = s2d ? 2 : (k22 && tm <= 3 && Cin % 32 == 0) ? 2 : 1;
+}
+
 }  // namespace
 #endif  // MOGAN_X6
+
+// Filter images of n 4x4 s2 p1 weights w[i] (Cout[i], Cin[i], 4, 4) for dconv2_fwd_kernel: dgrad[i] = 0 the forward form (2x2 filter
+// over the space-to-depth image), 1 the data-gradient form (four parity classes).  The layout parameters are the ones
+// mogan_dconv2_fwd_try derives from the same channels (d2_tile), so an image fits every map size of that weight.
+int mogan_dconv2_prep_group(int n, const float* const* w, void* const* prep, const int* Cout, const int* Cin, const int* dgrad,
+                            hipStream_t st) {
+#if MOGAN_X6
+    for (int i0 = 0; i0 < n; i0 += D2G_MAX) {
+        D2PrepGroup g{};
+        g.n = std::min(D2G_MAX, n - i0);
+        unsigned end = 0;
+        for (int j = 0; j < g.n; ++j) {
+            const int i = i0 + j;
+            if (!w[i] || !prep[i] || Cout[i] <= 0 || Cin[i] <= 0 || (((uintptr_t)prep[i]) & 15)) return MOGAN_ERR_SHAPE;
+            int tm, ns;
+            long long rows; int kin, cout1, wmode;
+            if (!dgrad[i]) {          // forward: rows = Cout, kernel channels 4 Cin (s2d), Cout1 = Ci of w
+                if (Cin[i] % 8) return MOGAN_ERR_SHAPE;
+                d2_tile(true, true, 4 * Cin[i], Cout[i], tm, ns);
+                rows = Cout[i]; kin = 4 * Cin[i]; cout1 = Cin[i]; wmode = 3;
+            } else {                  // data gradient: the convolution runs Co -> Ci per parity class: rows = 4 Ci, channels Co
+                if (Cout[i] % 16) return MOGAN_ERR_SHAPE;
+                d2_tile(false, true, Cout[i], Cin[i], tm, ns);
+                rows = 4ll * Cin[i]; kin = Cout[i]; cout1 = Cin[i]; wmode = 2;
+            }
+            const int nst = kin / (16 * ns);
+            g.w[j] = w[i]; g.wp[j] = (uint4*)prep[i]; g.rows[j] = (int)rows; g.Cin[j] = kin; g.NS[j] = ns; g.wmode[j] = wmode; g.Cout1[j] = cout1;
+            g.total[j] = (long long)nst * rows * ns * 4 * 2;
+            const long long blocks = (g.total[j] + 255) / 256;
+            if (blocks <= 0 || (long long)end + blocks > 0x7fffffffLL) return MOGAN_ERR_SHAPE;
+            end += (unsigned)blocks; g.end[j] = end;
+        }
+        hipLaunchKernelGGL(dconv2_wprep_group_kernel, dim3(end), dim3(256), 0, st, g);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+#else
+    return n > 0 ? MOGAN_ERR_SHAPE : 0;
+#endif
+}
 
 // ---- internal entry point (hidden): 1 = handled, 0 = not eligible (the caller takes dconv_fwd_kernel), < 0 = error ---------------
 // X (B, Cin, H, W); the filters of the convolution to run come out of w as wmode says (dconv2_wprep_kernel: 0 = w is
@@ -354,7 +443,7 @@ static int launch2(D2P& p, hipStream_t st) {
 // stride ys into planes yH x yW.
 int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, int B, int Cin, int Cout, int H, int W, int OH, int OW,
                          int KH, int KW, int pt, int pl, int yH, int yW, int ys, int npar, int accumulate, void* ws,
-                         size_t ws_bytes, hipStream_t st) {
+                         size_t ws_bytes, hipStream_t st, const void* prep_in, size_t* query) {
 #if MOGAN_X6
     // MOGAN_DCONV2: 0 = off, 1 = 8 x 32 tiles of stride-1 filters only (the first form of this kernel), 2 (default) = also the
     // 16 x 16 tiles and the space-to-depth forward of the 4x4 s2 convolutions
@@ -376,29 +465,29 @@ int mogan_dconv2_fwd_try(const float* X, const float* w, int wmode, float* Y, in
     if (!(k33 || k22) || (OW % cw) || (OH % tr) || (Cin % 16) || Cout < 64 || B <= 0) return 0;
     if ((long long)B * CinX * H * W >= (1ll << 29) || (long long)B * Cout * yH * yW >= (1ll << 30)) return 0;
     const int KHW = KH * KW;
-    // BM: least padded rows of 64 / 96 / 128, the larger tile on a tie (space-to-depth form: 64 / 96, its stage is two sub-chunks)
-    int tm = 4; long long best = cdiv2(Cout, 128) * 128;
-    if (s2d) { tm = 3; best = cdiv2(Cout, 96) * 96; }
-    else if (cdiv2(Cout, 96) * 96 < best) { best = cdiv2(Cout, 96) * 96; tm = 3; }
-    if (cdiv2(Cout, 64) * 64 < best) { best = cdiv2(Cout, 64) * 64; tm = 2; }
+    // BM: least padded rows of 64 / 96 / 128, the larger tile on a tie (space-to-depth form: 64 / 96, its stage is two sub-chunks);
     // stage = NS x 16 channels: the 2 x 2 filters take two sub-chunks per stage (8 groups between barriers) where LDS allows
-    const int ns = s2d ? 2 : (k22 && tm <= 3 && Cin % 32 == 0) ? 2 : 1;
+    int tm, ns; d2_tile(s2d, k22, Cin, Cout, tm, ns);
     const int nst = Cin / (16 * ns);
     const long long rows = (long long)npar * Cout;
     const size_t wpb = (size_t)nst * rows * ns * KHW * 6 * 16;
-    if (!ws || ws_bytes < wpb + 256 || wpb >= (1ull << 31)) return 0;
-    {
+    if (wpb >= (1ull << 31)) return 0;
+    const bool owned = wmode == 2 || wmode == 3;          // the forms whose image the weight's owner may hold (4x4 s2 p1)
+    if (query) { *query = owned ? wpb : 0; return 1; }   // dry run of the dispatch (mogan_conv_prep_bytes)
+    const void* prep = owned ? prep_in : nullptr;
+    if (!prep) {
+        if (!ws || ws_bytes < wpb + 256) return 0;
         const long long total = (long long)nst * rows * ns * KHW * 2;
         hipLaunchKernelGGL(dconv2_wprep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (uint4*)ws, (int)rows, Cin,
                            KHW, ns, wmode, s2d ? CinX : Cout, total);
     }
     D2P p{};
-    p.X = X; p.Wp = ws; p.Y = Y; p.B = B; p.Cin = Cin; p.CinX = CinX; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pt = pt; p.pl = pl;
+    p.X = X; p.Wp = prep ? prep : ws; p.Y = Y; p.B = B; p.Cin = Cin; p.CinX = CinX; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pt = pt; p.pl = pl;
     p.yH = yH; p.yW = yW; p.ys = ys; p.npar = npar; p.accumulate = accumulate;
     p.tiles_cw = cw; p.tiles_x = OW / cw; p.tiles_y = OH / tr;
     p.x_bytes = 4u * (unsigned)B * CinX * H * W; p.wp_bytes = (unsigned)wpb;
-    const size_t adv = (wpb + 255) & ~(size_t)255;
-    char* ws2 = (char*)ws + adv; size_t ws2_bytes = ws_bytes - adv;
+    const size_t adv = prep ? 0 : ((wpb + 255) & ~(size_t)255);
+    char* ws2 = (char*)ws + adv; size_t ws2_bytes = ws ? ws_bytes - adv : 0;
     p.ntiles = B * p.tiles_x * p.tiles_y;
     const long long groups = cdiv2(Cout, tm * 32) * npar;              // (channel block, parity class) pairs: each walks all spatial tiles
     const long long tiles = (long long)p.ntiles * groups;

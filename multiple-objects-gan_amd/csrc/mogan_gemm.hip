@@ -1100,7 +1100,9 @@ int mogan_conv2d_fwd_wp(const float* x, const float* w, const void* wprep, float
     }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(4, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cout, B * p.OH * p.OW, Cin * KH * KW, stream);
-        rc = mogan_dconv_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+        // (the image of a 4x4 s2 convolution is dconv2_fwd_kernel's: mogan_conv_prep_bytes)
+        rc = mogan_dconv_fwd_try(x, w, y, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream,
+                                 (KH == 4 && KW == 4 && stride == 2) ? wprep : nullptr);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
@@ -1284,7 +1286,8 @@ int mogan_conv2d_dgrad_wp(const float* dy, const float* w, const void* wprep, fl
     }
     if (mogan_use_dconv && g_force_cfg < 0) {
         mogan_prof_begin(5, 0, 2.0 * Cout * (double)B * p.OH * p.OW * Cin * KH * KW, Cin, B * p.H * p.W, Cout * KH * KW, stream);
-        rc = mogan_dconv_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream);
+        rc = mogan_dconv_dgrad_try(dy, w, dx, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, ws, ws_bytes, stream,
+                                   (KH == 4 && KW == 4 && stride == 2) ? wprep : nullptr);
         mogan_prof_end(rc == 1, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
@@ -1295,6 +1298,42 @@ int mogan_conv2d_dgrad_wp(const float* dy, const float* w, const void* wprep, fl
     p.N = B * Hc * Wc;   // class (0,0) has the most columns
     dense_io(p, CONV_DGRAD);
     return run_gemm(CONV_DGRAD, p, stride * stride, (long long)B * Cin * p.H * p.W, ws, ws_bytes, stream);
+}
+
+// ---- prepared filter images, any kind (include/mogan_hip.h "Prepared filter images") ------------------------------------------
+// Which image mogan_conv2d_fwd_wp / _dgrad_wp take for a geometry follows the dispatch above: 3x3 s1 p1 -> the Winograd kernels'
+// (mogan_wino_prep_bytes), 4x4 s2 p1 -> dconv2_fwd_kernel's, found by a dry run of that branch of the dispatch.
+size_t mogan_conv_prep_bytes(int B, int Cin, int Hs, int Ws, int Cout, int KH, int KW, int stride, int ph, int pw, int up, int dgrad) {
+    if (KH == 3 && KW == 3) return mogan_wino_prep_bytes(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, dgrad);
+    if (!(KH == 4 && KW == 4 && stride == 2 && ph == 1 && pw == 1 && up == 0) || B <= 0 || Cin <= 0 || Cout <= 0 || Hs <= 0 || Ws <= 0)
+        return 0;
+    if (!mogan_use_dconv || g_force_cfg >= 0) return 0;
+    // (the stages ahead of the direct kernels -- <= 4 channels on one side, the 3-channel first layer -- never meet a geometry the
+    // direct kernels accept: those need >= 8 / >= 64 channels on the two sides)
+    float* const fake = (float*)(uintptr_t)256;           // never dereferenced: the dry run launches nothing
+    size_t bytes = 0;
+    const int rc = dgrad ? mogan_dconv_dgrad_try(fake, fake, fake, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, fake, (size_t)1 << 40, nullptr,
+                                                 nullptr, &bytes)
+                         : mogan_dconv_fwd_try(fake, fake, fake, B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, fake, (size_t)1 << 40, nullptr,
+                                               nullptr, &bytes);
+    return rc == 1 ? bytes : 0;
+}
+
+int mogan_conv_prep_group(int n, const float* const* w, void* const* prep, const int* Cout, const int* Cin, const int* KH,
+                          const int* dgrad, hipStream_t st) {
+    if (n < 0 || (n > 0 && (!w || !prep || !Cout || !Cin || !KH || !dgrad))) return MOGAN_ERR_SHAPE;
+    // the members of each kind keep their order; one grouped launch per kind (and per 32 members)
+    std::vector<const float*> ws_[2]; std::vector<void*> ps_[2]; std::vector<int> co_[2], ci_[2], dg_[2];
+    for (int i = 0; i < n; ++i) {
+        if (KH[i] != 3 && KH[i] != 4) return MOGAN_ERR_SHAPE;
+        const int k = KH[i] == 4;
+        ws_[k].push_back(w[i]); ps_[k].push_back(prep[i]); co_[k].push_back(Cout[i]); ci_[k].push_back(Cin[i]); dg_[k].push_back(dgrad[i]);
+    }
+    int rc = 0;
+    if (!ws_[0].empty()) rc = mogan_wino_prep_group((int)ws_[0].size(), ws_[0].data(), ps_[0].data(), co_[0].data(), ci_[0].data(), dg_[0].data(), st);
+    if (!rc && !ws_[1].empty())
+        rc = mogan_dconv2_prep_group((int)ws_[1].size(), ws_[1].data(), ps_[1].data(), co_[1].data(), ci_[1].data(), dg_[1].data(), st);
+    return rc;
 }
 
 // Data gradient with channel-slice addressing and a fused ReLU backward: dy is a slice of a tensor with batch stride

@@ -41,6 +41,8 @@ SIGNATURES = {
     "mogan_conv2d_wgrad": [P, P, P] + [I] * 12 + [P, Z, P],
     "mogan_wino_prep_bytes": [I] * 12,
     "mogan_wino_prep_group": [I, P, P, P, P, P, P],
+    "mogan_conv_prep_bytes": [I] * 12,
+    "mogan_conv_prep_group": [I, P, P, P, P, P, P, P],
     "mogan_conv2d_fwd_wp": [P, P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_conv2d_dgrad_wp": [P, P, P, P] + [I] * 11 + [P, Z, P],
     "mogan_pk_conv_eligible": [I] * 11,
@@ -155,7 +157,7 @@ class TailArgs(ctypes.Structure):               # MoganTailArgs
 
 
 _RESTYPE = {"mogan_bn_ws_bytes": Z, "mogan_upconv3x3_ws_bytes": Z, "mogan_pk_weight_bytes": Z, "mogan_pk_panel_bytes": Z,
-            "mogan_wino_prep_bytes": Z}
+            "mogan_wino_prep_bytes": Z, "mogan_conv_prep_bytes": Z}
 _ERRORS = {-1: "MOGAN_ERR_SHAPE", -2: "MOGAN_ERR_LAUNCH", -3: "MOGAN_ERR_WS"}
 
 _lib = None

@@ -378,12 +378,13 @@ class WeightPacks:
 
     def wino_pointer(self, dgrad, B, Hs, Ws, stride, ph, pw, up):
         """device pointer of this weight's prepared filter image for the direction, current and ordered before a use on the
-        current stream -- or None: the convolution does not take the Winograd kernels (or the library is a native-fp32 build)"""
+        current stream -- or None: the convolution takes a kernel without one (or the library is a native-fp32 build).  The kind
+        of image follows the filter size: the Winograd kernels' for 3x3 s1, dconv2_fwd_kernel's for 4x4 s2 (mogan_conv_prep_bytes)"""
         key = (dgrad, B, Hs, Ws, stride, ph, pw, up)
         nb = self.wbytes.get(key)
         if nb is None:
             Cout, Cin, KH, KW = self.w.shape
-            nb = self.wbytes[key] = int(lib.load().mogan_wino_prep_bytes(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, dgrad))
+            nb = self.wbytes[key] = int(lib.load().mogan_conv_prep_bytes(B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up, dgrad))
         if not nb:
             return None
         sl = self.wino.get(dgrad)
@@ -425,8 +426,8 @@ class WeightPacks:
 
 
 def wino_prep(items):
-    """(WeightPacks, dgrad, slot) triples -> their Winograd filter images rebuilt in ONE launch (mogan_wino_prep_group) on the
-    current stream"""
+    """(WeightPacks, dgrad, slot) triples -> their prepared filter images rebuilt on the current stream in one launch per kind
+    (mogan_conv_prep_group: the Winograd images of the 3x3 weights, dconv2's images of the 4x4 s2 weights)"""
     import ctypes
     n = len(items)
     if not n:
@@ -436,10 +437,11 @@ def wino_prep(items):
     ps = VP(*[it[2][0].data_ptr() for it in items])
     co = CI(*[int(it[0].w.shape[0]) for it in items])
     ci = CI(*[int(it[0].w.shape[1]) for it in items])
+    kh = CI(*[int(it[0].w.shape[2]) for it in items])
     dg = CI(*[int(it[1]) for it in items])
     st = stream_ptr()
-    call("mogan_wino_prep_group", n, ctypes.cast(ws, ctypes.c_void_p), ctypes.cast(ps, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p),
-         ctypes.cast(ci, ctypes.c_void_p), ctypes.cast(dg, ctypes.c_void_p), st)
+    call("mogan_conv_prep_group", n, ctypes.cast(ws, ctypes.c_void_p), ctypes.cast(ps, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p),
+         ctypes.cast(ci, ctypes.c_void_p), ctypes.cast(kh, ctypes.c_void_p), ctypes.cast(dg, ctypes.c_void_p), st)
     ev = torch.cuda.Event()
     ev.record()
     cap = bool(lib._capturing())
@@ -465,7 +467,15 @@ def _wino_prep_ptr(w, dgrad, B, Hs, Ws, stride, ph, pw, up):
     return pk.wino_pointer(dgrad, B, Hs, Ws, stride, ph, pw, up)
 
 
-WINO_PREP = True      # (module attribute: False = every Winograd convolution transforms its filters per call, as without an owner)
+WINO_PREP = True      # (module attribute: False = every convolution prepares its filters per call, as without an owner)
+
+
+D2_PREP = True        # (module attribute: False = the 4x4 s2 convolutions prepare dconv2's filter image per call)
+
+
+def _prep_kind(KH, KW, stride, up):
+    """filter sizes that may have a prepared image: 3x3 s1 (Winograd) and 4x4 s2 (dconv2_fwd_kernel)"""
+    return (KH == 3 and KW == 3 and stride == 1) or (D2_PREP and KH == 4 and KW == 4 and stride == 2 and not up)
 
 
 def attach_packs(w, version_cell=None):
@@ -508,7 +518,7 @@ def conv2d_forward(x, w, stride, ph, pw, up):
     OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, up)
     y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     wsp, wsn = workspace(x.device)
-    wprep = _wino_prep_ptr(w, 0, B, Hs, Ws, stride, ph, pw, up) if KH == 3 and KW == 3 and stride == 1 else None
+    wprep = _wino_prep_ptr(w, 0, B, Hs, Ws, stride, ph, pw, up) if _prep_kind(KH, KW, stride, up) else None
     if wprep is not None:        # the owner's prepared Winograd filter image of this weight version (no transform launch here)
         call("mogan_conv2d_fwd_wp", ptr(x), ptr(w), wprep, ptr(y), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
              wsp, wsn, stream_ptr())
@@ -533,7 +543,7 @@ def conv2d_dgrad(dy, w, x_shape, stride, ph, pw, up):
         call("mogan_upconv3x3_dgrad", ptr(dy), ptr(w), ptr(dx), B, Cin, Hs, Ws, Cout, wsp, wsn, stream_ptr())
         return dx
     du = torch.empty((B, Cin, Hs << up, Ws << up), dtype=torch.float32, device=dy.device)
-    wprep = _wino_prep_ptr(w, 1, B, Hs, Ws, stride, ph, pw, up) if KH == 3 and KW == 3 and stride == 1 else None
+    wprep = _wino_prep_ptr(w, 1, B, Hs, Ws, stride, ph, pw, up) if _prep_kind(KH, KW, stride, up) else None
     if wprep is not None:
         call("mogan_conv2d_dgrad_wp", ptr(dy), ptr(w), wprep, ptr(du), B, Cin, Hs, Ws, Cout, KH, KW, stride, ph, pw, up,
              wsp, wsn, stream_ptr())

@@ -940,6 +940,86 @@ def test_winograd_prepared_images_of_many_weights_in_one_call():
     assert ops.PK_STATS.get("wino_preps", 0) == n0 + 1
 
 
+@pytest.mark.parametrize("case", [(2, 96, 64, 192), (3, 64, 32, 96), (2, 192, 32, 384), (2, 96, 16, 96), (2, 40, 64, 72), (1, 64, 8, 64)])
+def test_dconv2_prepared_filter_images(case):
+    """Round 6, third session (include/mogan_hip.h mogan_conv_prep_bytes / _group): the 4x4 s2 p1 convolutions of the discriminators
+    run on dconv2_fwd_kernel (forward over the space-to-depth image, data gradient by parity classes) with pre-split filter images
+    that mogan_conv2d_fwd / _dgrad rebuild per call.  A weight with an owner keeps one image per direction instead (the same
+    mechanism as the Winograd images): same bits as the per-call form, re-prepared by the owner after a change, both images of many
+    weights in one launch per kind, and no image where the dispatch does not take that kernel."""
+    B, Cin, H, Cout = case
+    x = T("d2x%s" % (case,), (B, Cin, H, H)).to(DEV)
+    w0 = T("d2w%s" % (case,), (Cout, Cin, 4, 4), 0.2).to(DEV)
+    g = T("d2g%s" % (case,), (B, Cout, H // 2, H // 2)).to(DEV)
+    y_ref, dx_ref = ops.conv2d_forward(x, w0, 2, 1, 1, 0), ops.conv2d_dgrad(g, w0, x.shape, 2, 1, 1, 0)     # no owner: per-call prep
+    nb = [int(lib.load().mogan_conv_prep_bytes(B, Cin, H, H, Cout, 4, 4, 2, 1, 1, 0, d)) for d in (0, 1)]
+    if lib.load().mogan_mfma_form() == 1:                      # the native-fp32 build has no pre-split filter images
+        assert nb == [0, 0]
+    else:
+        # the forward takes dconv2 from 16-pixel output rows and 64 output channels on, the data gradient from 16-pixel parity grids
+        assert bool(nb[0]) == (H // 2 >= 16 and Cin % 8 == 0 and Cout >= 64), nb
+        assert bool(nb[1]) == (H // 2 >= 16 and Cout % 16 == 0 and Cin >= 64), nb
+    w = w0.clone()
+    pk = ops.attach_packs(w)
+    before = ops.PK_STATS.get("wino_preps", 0)
+    y, dx = ops.conv2d_forward(x, w, 2, 1, 1, 0), ops.conv2d_dgrad(g, w, x.shape, 2, 1, 1, 0)
+    torch.cuda.synchronize()
+    ntk = int(bool(nb[0])) + int(bool(nb[1]))
+    assert sorted(pk.wino) == [d for d in (0, 1) if nb[d]] and ops.PK_STATS.get("wino_preps", 0) == before + ntk
+    assert all(pk.wino[d][0].numel() >= nb[d] for d in pk.wino)
+    assert torch.equal(y, y_ref) and torch.equal(dx, dx_ref)
+    assert torch.equal(ops.conv2d_forward(x, w, 2, 1, 1, 0), y_ref) and ops.PK_STATS.get("wino_preps", 0) == before + ntk
+    with torch.no_grad():
+        w.mul_(-0.5)
+    pk.cell[0] += 1                                               # FlatAdam.touch(): rebuilt at the next use
+    assert torch.equal(ops.conv2d_forward(x, w, 2, 1, 1, 0), ops.conv2d_forward(x, w0 * -0.5, 2, 1, 1, 0))
+    with torch.no_grad():
+        w.mul_(-3.0)
+    pk.cell[0] += 1
+    n0 = ops.PK_STATS.get("wino_preps", 0)
+    ops.repack_all([pk])                                          # FlatAdam.step(): every image in use, one launch
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + (1 if ntk else 0)
+    y3, dx3 = ops.conv2d_forward(x, w, 2, 1, 1, 0), ops.conv2d_dgrad(g, w, x.shape, 2, 1, 1, 0)
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + (1 if ntk else 0)
+    assert torch.equal(y3, ops.conv2d_forward(x, w0 * 1.5, 2, 1, 1, 0)) and torch.equal(dx3, ops.conv2d_dgrad(g, w0 * 1.5, x.shape, 2, 1, 1, 0))
+    _check(y3, 1.5 * F.conv2d(x.double().cpu(), w0.double().cpu(), None, 2, 1), what="fwd against fp64")
+
+
+def test_prepared_images_of_both_kinds_in_one_call():
+    """ops.repack_all over a bucket with 3x3 (Winograd) and 4x4 s2 (dconv2) weights: one mogan_conv_prep_group call, 36 + 36 images"""
+    if lib.load().mogan_mfma_form() == 1:
+        pytest.skip("the native-fp32 build has no prepared images")
+    pks, refs, xs = [], [], {}
+    for i in range(36):
+        k = 3 if i % 2 == 0 else 4
+        co, ci = [(192, 96), (96, 96), (128, 64)][i % 3]
+        w = T("bkw%d" % i, (co, ci, k, k), 0.2).to(DEV)
+        refs.append(w)
+        pks.append(ops.attach_packs(w.clone()))
+        xs[ci] = T("bkx%d" % ci, (2, ci, 32, 32)).to(DEV)
+
+    def run(wt):
+        co, ci, k = wt.shape[0], wt.shape[1], wt.shape[2]
+        s = 1 if k == 3 else 2
+        gy = T("bkg%d_%d" % (co, k), (2, co, 32 // s, 32 // s)).to(DEV)
+        return ops.conv2d_forward(xs[ci], wt, s, 1, 1, 0), ops.conv2d_dgrad(gy, wt, xs[ci].shape, s, 1, 1, 0)
+
+    for pk in pks:
+        run(pk.w)                                                # allocate the slots
+    assert all(sorted(pk.wino) == [0, 1] for pk in pks)
+    with torch.no_grad():
+        for pk in pks:
+            pk.w.mul_(2.0)
+            pk.cell[0] += 1
+    n0 = ops.PK_STATS.get("wino_preps", 0)
+    ops.repack_all(pks)
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + 1
+    for w, pk in zip(refs, pks):
+        a, b = run(pk.w), run(w * 2.0)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert ops.PK_STATS.get("wino_preps", 0) == n0 + 1
+
+
 PK_WGRAD_CASES = PK_CASES + [
     (4, 20, 9, 7, 50, 3, 2, 1),        # nothing aligned: Cin, Cout, the map and K = 4*5*4 = 80 output pixels (padded to 96)
     (33, 16, 4, 4, 40, 4, 1, 0),       # 1x1 outputs: K = 33

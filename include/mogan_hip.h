@@ -321,6 +321,13 @@ int mogan_panel_tail_group(int n, const MoganTailArgs* args, hipStream_t stream)
  * dgrad returns dx at the SOURCE resolution (B,Cin,Hs,Ws) (no mogan_down2_sum).  The workspace must hold
  * mogan_upconv3x3_ws_bytes(Cout,Cin) for K (dK in wgrad) in front of the split-K scratch of the inner conv. */
 size_t mogan_upconv3x3_ws_bytes(int Cout, int Cin);
+/* K (Cin, Cout, 4, 4) of w alone: a caller that owns w keeps K per weight version (and, with mogan_conv_prep_*, the filter image of
+ * the kernel that runs the virtual 4x4 s2 convolution) and then calls mogan_conv2d_dgrad_wp(x, K, image, y, B, Cout, 2 Hs, 2 Ws, Cin,
+ * 4, 4, 2, 1, 1, 0, ...) for the forward / mogan_conv2d_fwd_wp(dy, K, image, dx, ...) for the data gradient -- the calls
+ * mogan_upconv3x3_fwd / _dgrad make after building K per call (same results) */
+int mogan_upconv3x3_k4(const float* w, float* k4, int Cout, int Cin, hipStream_t stream);
+/* the K of n weights in one launch (what an owner calls behind its optimizer step) */
+int mogan_upconv3x3_k4_group(int n, const float* const* w, float* const* k4, const int* Cout, const int* Cin, hipStream_t stream);
 int mogan_upconv3x3_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, void* ws,
                         size_t ws_bytes, hipStream_t stream);
 int mogan_upconv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Hs, int Ws, int Cout, void* ws,

@@ -1439,6 +1439,32 @@ __global__ __launch_bounds__(256) void upconv_k4_grad_kernel(const float* __rest
     }
 }
 
+// K of up to 32 weights in one launch (mogan_upconv3x3_k4_group)
+constexpr int UKG_MAX = 32;
+struct UpK4Group { const float* w[UKG_MAX]; float* k4[UKG_MAX]; int Cout[UKG_MAX], Cin[UKG_MAX]; unsigned end[UKG_MAX]; int n; };
+__global__ __launch_bounds__(256) void upconv_k4_group_kernel(const UpK4Group g) {
+    int m = 0;
+#pragma unroll 1
+    for (int i = 0; i < g.n - 1; ++i) if (blockIdx.x >= g.end[i]) m = i + 1;
+    const unsigned start = m ? g.end[m - 1] : 0u;
+    const int Cout = g.Cout[m], Cin = g.Cin[m];
+    const long long i = (long long)(blockIdx.x - start) * 256 + threadIdx.x;        // one thread per (ci, co)
+    if (i >= (long long)Cout * Cin) return;
+    const int ci = (int)(i / Cout), co = (int)(i - (long long)ci * Cout);
+    const float* s = g.w[m] + ((size_t)co * Cin + ci) * 9;
+    float f[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) f[a][b] = s[a * 3 + b];
+    float r[4][3];                                                        // (the arithmetic of upconv_k4_kernel, term by term)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { r[0][b] = f[2][b]; r[1][b] = f[1][b] + f[2][b]; r[2][b] = f[0][b] + f[1][b]; r[3][b] = f[0][b]; }
+    float* d = g.k4[m] + i * 16;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { d[a * 4 + 0] = r[a][2]; d[a * 4 + 1] = r[a][1] + r[a][2]; d[a * 4 + 2] = r[a][0] + r[a][1]; d[a * 4 + 3] = r[a][0]; }
+}
+
 inline size_t upconv_k_bytes(int Cout, int Cin) { return (((size_t)Cout * Cin * 16 * sizeof(float)) + 255) & ~(size_t)255; }
 
 int upconv_make_k(const float* w, void* ws, size_t ws_bytes, int Cout, int Cin, hipStream_t st) {
@@ -1450,6 +1476,33 @@ int upconv_make_k(const float* w, void* ws, size_t ws_bytes, int Cout, int Cin, 
 }  // namespace
 
 size_t mogan_upconv3x3_ws_bytes(int Cout, int Cin) { return upconv_k_bytes(Cout, Cin); }
+
+// K = T w T^t alone, into the caller's buffer (Cin, Cout, 4, 4): an owner of w keeps K (and the filter image of the kernel that runs
+// the virtual convolution, mogan_conv_prep_*) per weight version and calls mogan_conv2d_dgrad_wp / mogan_conv2d_fwd_wp on K itself
+// -- what mogan_upconv3x3_fwd / _dgrad do after building K at the head of the workspace, per call
+int mogan_upconv3x3_k4(const float* w, float* k4, int Cout, int Cin, hipStream_t stream) {
+    if (!w || !k4 || Cout <= 0 || Cin <= 0) return MOGAN_ERR_SHAPE;
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(upconv_k4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, k4, Cout, Cin);
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
+
+int mogan_upconv3x3_k4_group(int n, const float* const* w, float* const* k4, const int* Cout, const int* Cin, hipStream_t stream) {
+    if (n < 0 || (n > 0 && (!w || !k4 || !Cout || !Cin))) return MOGAN_ERR_SHAPE;
+    for (int i0 = 0; i0 < n; i0 += UKG_MAX) {
+        UpK4Group g{};
+        g.n = std::min(UKG_MAX, n - i0);
+        unsigned end = 0;
+        for (int j = 0; j < g.n; ++j) {
+            const int i = i0 + j;
+            if (!w[i] || !k4[i] || Cout[i] <= 0 || Cin[i] <= 0) return MOGAN_ERR_SHAPE;
+            g.w[j] = w[i]; g.k4[j] = k4[i]; g.Cout[j] = Cout[i]; g.Cin[j] = Cin[i];
+            end += (unsigned)(((long long)Cout[i] * Cin[i] + 255) / 256); g.end[j] = end;
+        }
+        hipLaunchKernelGGL(upconv_k4_group_kernel, dim3(end), dim3(256), 0, stream, g);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : MOGAN_ERR_LAUNCH;
+}
 
 int mogan_upconv3x3_fwd(const float* x, const float* w, float* y, int B, int Cin, int Hs, int Ws, int Cout, void* ws,
                         size_t ws_bytes, hipStream_t stream) {

@@ -337,6 +337,11 @@ class WeightPacks:
         # global epoch, event, stream, prepared inside a capture]; wbytes[(dgrad, geometry)] = image size, 0 = not a Winograd layer
         self.wino = {}
         self.wbytes = {}
+        # upsample + conv3x3 as the transposed 4x4 s2 convolution (mogan_upconv3x3_*): the virtual filters K = T w T^t of this weight
+        # version, [buffer (Cin, Cout, 4, 4), version, global epoch, event, stream, built inside a capture], and a child WeightPacks
+        # over K (same version cell) that holds the filter images of the kernels running the virtual convolution
+        self.k4 = None
+        self.k4pk = None
 
     def _pack(self, dgrad, slot):
         Cout, Cin, KH, KW = self.w.shape
@@ -396,6 +401,36 @@ class WeightPacks:
             torch.cuda.current_stream().wait_event(sl[3])
         return sl[0].data_ptr()
 
+    # -- K of the up-convolution --------------------------------------------------------------------------------------------
+    def k4_stale(self):
+        return self.k4 is not None and (self.k4[1] != self.cell[0] or self.k4[2] != _PK_GLOBAL[0])
+
+    def k4_build(self):
+        """K = T w T^t of the current weight on the current stream (one launch)"""
+        Cout, Cin = int(self.w.shape[0]), int(self.w.shape[1])
+        st = stream_ptr()
+        call("mogan_upconv3x3_k4", ptr(self.w), self.k4[0].data_ptr(), Cout, Cin, st)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.k4[1], self.k4[2], self.k4[3], self.k4[4], self.k4[5] = self.cell[0], _PK_GLOBAL[0], ev, st, bool(lib._capturing())
+        PK_STATS["k4_builds"] = PK_STATS.get("k4_builds", 0) + 1
+
+    def upconv_pointers(self, dgrad, B, Hs, Ws):
+        """(K pointer, filter-image pointer or None) for the up-convolution of an (B, Cin, Hs, Ws) input with this 3x3 weight:
+        direction 0 (forward) runs the DATA GRADIENT of the virtual 4x4 s2 convolution C4 (in = Cout, out = Cin) on 2Hs x 2Ws,
+        direction 1 its forward.  Both current and ordered before a use on the current stream."""
+        Cout, Cin = int(self.w.shape[0]), int(self.w.shape[1])
+        if self.k4 is None:
+            k = torch.empty((Cin, Cout, 4, 4), dtype=torch.float32, device=self.w.device)
+            self.k4 = [k, -1, -1, None, None, False]
+            self.k4pk = WeightPacks(k, self.cell)
+        if self.k4_stale():
+            self.k4_build()
+        elif self.k4[4] != stream_ptr() and (self.k4[5] or not lib._capturing()):
+            torch.cuda.current_stream().wait_event(self.k4[3])
+        img = self.k4pk.wino_pointer(0 if dgrad else 1, B, 2 * Hs, 2 * Ws, 2, 1, 1, 0) if D2_PREP else None
+        return self.k4[0].data_ptr(), img
+
     def _fresh(self, key, slot):
         """make the copy in `slot` current for a use on the current stream"""
         if slot[1] != self.cell[0] or slot[2] != _PK_GLOBAL[0]:
@@ -450,13 +485,39 @@ def wino_prep(items):
     PK_STATS["wino_preps"] = PK_STATS.get("wino_preps", 0) + 1
 
 
+def k4_build_group(pks):
+    """K = T w T^t of every pack in `pks` on the current stream in one launch (mogan_upconv3x3_k4_group)"""
+    import ctypes
+    n = len(pks)
+    if not n:
+        return
+    VP, CI = ctypes.c_void_p * n, ctypes.c_int * n
+    ws = VP(*[pk.w.data_ptr() for pk in pks])
+    ks = VP(*[pk.k4[0].data_ptr() for pk in pks])
+    co = CI(*[int(pk.w.shape[0]) for pk in pks])
+    ci = CI(*[int(pk.w.shape[1]) for pk in pks])
+    st = stream_ptr()
+    call("mogan_upconv3x3_k4_group", n, ctypes.cast(ws, ctypes.c_void_p), ctypes.cast(ks, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p),
+         ctypes.cast(ci, ctypes.c_void_p), st)
+    ev = torch.cuda.Event()
+    ev.record()
+    cap = bool(lib._capturing())
+    for pk in pks:
+        pk.k4[1], pk.k4[2], pk.k4[3], pk.k4[4], pk.k4[5] = pk.cell[0], _PK_GLOBAL[0], ev, st, cap
+    PK_STATS["k4_builds"] = PK_STATS.get("k4_builds", 0) + 1
+
+
 def repack_all(packs):
     """Every derived weight image of a bucket brought up to date on the current stream (the owner changed the weights): the
     packed panels pack by pack, the Winograd filter images of all of them in one launch."""
-    items = []
+    items, k4s = [], []
     for pk in packs:
         pk.repack()
         items += [(pk, d, sl) for d, sl in pk.wino.items()]
+        if pk.k4 is not None:                  # the virtual filters of an up-convolution, then the images built from them
+            k4s.append(pk)
+            items += [(pk.k4pk, d, sl) for d, sl in pk.k4pk.wino.items()]
+    k4_build_group(k4s)
     wino_prep(items)
 
 
@@ -471,6 +532,7 @@ WINO_PREP = True      # (module attribute: False = every convolution prepares it
 
 
 D2_PREP = True        # (module attribute: False = the 4x4 s2 convolutions prepare dconv2's filter image per call)
+UPCONV_OWNED = True   # (module attribute: False = the up-convolutions build K = T w T^t per call, mogan_upconv3x3_fwd / _dgrad)
 
 
 def _prep_kind(KH, KW, stride, up):
@@ -487,6 +549,11 @@ def attach_packs(w, version_cell=None):
         pk.cell = version_cell
         for slot in list(pk.slots.values()) + list(pk.wino.values()):
             slot[1] = -1
+        if pk.k4 is not None:
+            pk.k4[1] = -1
+            pk.k4pk.cell = version_cell
+            for slot in pk.k4pk.wino.values():
+                slot[1] = -1
     return pk
 
 
@@ -513,6 +580,11 @@ def conv2d_forward(x, w, stride, ph, pw, up):
     if _is_upconv(w.shape, stride, ph, pw, up):
         y = torch.empty((B, Cout, 2 * Hs, 2 * Ws), dtype=torch.float32, device=x.device)
         wsp, wsn = workspace(x.device)
+        pk = getattr(w, "_mogan_pk", None)
+        if pk is not None and WINO_PREP and UPCONV_OWNED:     # the owner's K = T w T^t (and filter image) of this weight version
+            k4, img = pk.upconv_pointers(0, B, Hs, Ws)
+            call("mogan_conv2d_dgrad_wp", ptr(x), k4, img, ptr(y), B, Cout, 2 * Hs, 2 * Ws, Cin, 4, 4, 2, 1, 1, 0, wsp, wsn, stream_ptr())
+            return y
         call("mogan_upconv3x3_fwd", ptr(x), ptr(w), ptr(y), B, Cin, Hs, Ws, Cout, wsp, wsn, stream_ptr())
         return y
     OH, OW = conv_out_hw(Hs, Ws, KH, KW, stride, ph, pw, up)
@@ -540,6 +612,11 @@ def conv2d_dgrad(dy, w, x_shape, stride, ph, pw, up):
         return dx
     if _is_upconv(w.shape, stride, ph, pw, up):          # the gradient comes out at the source resolution
         dx = torch.empty((B, Cin, Hs, Ws), dtype=torch.float32, device=dy.device)
+        pk = getattr(w, "_mogan_pk", None)
+        if pk is not None and WINO_PREP and UPCONV_OWNED:
+            k4, img = pk.upconv_pointers(1, B, Hs, Ws)
+            call("mogan_conv2d_fwd_wp", ptr(dy), k4, img, ptr(dx), B, Cout, 2 * Hs, 2 * Ws, Cin, 4, 4, 2, 1, 1, 0, wsp, wsn, stream_ptr())
+            return dx
         call("mogan_upconv3x3_dgrad", ptr(dy), ptr(w), ptr(dx), B, Cin, Hs, Ws, Cout, wsp, wsn, stream_ptr())
         return dx
     du = torch.empty((B, Cin, Hs << up, Ws << up), dtype=torch.float32, device=dy.device)

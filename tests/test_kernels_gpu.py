@@ -985,6 +985,45 @@ def test_dconv2_prepared_filter_images(case):
     _check(y3, 1.5 * F.conv2d(x.double().cpu(), w0.double().cpu(), None, 2, 1), what="fwd against fp64")
 
 
+@pytest.mark.parametrize("case", [(2, 96, 32, 96), (2, 192, 16, 96), (3, 64, 8, 128), (2, 48, 64, 24), (1, 20, 5, 12)])
+def test_upconv_filters_kept_by_the_owner(case):
+    """nearest-x2 upsample + conv3x3 runs as the transposed 4x4 s2 convolution with the virtual filters K = T w T^t
+    (mogan_upconv3x3_*, which build K -- and, where dconv2_fwd_kernel takes the virtual convolution, its filter image -- per call).
+    A weight with an owner keeps K and the images per weight version (mogan_upconv3x3_k4 + mogan_conv_prep_group behind the optimizer
+    step) and calls mogan_conv2d_dgrad_wp / _fwd_wp on K: the same bits, no per-call transform launches."""
+    B, Cin, H, Cout = case
+    x = T("ukx%s" % (case,), (B, Cin, H, H)).to(DEV)
+    w0 = T("ukw%s" % (case,), (Cout, Cin, 3, 3), 0.2).to(DEV)
+    g = T("ukg%s" % (case,), (B, Cout, 2 * H, 2 * H)).to(DEV)
+    assert ops.UPCONV4
+    y_ref, dx_ref = ops.conv2d_forward(x, w0, 1, 1, 1, 1), ops.conv2d_dgrad(g, w0, x.shape, 1, 1, 1, 1)     # no owner: K per call
+    w = w0.clone()
+    pk = ops.attach_packs(w)
+    k0 = ops.PK_STATS.get("k4_builds", 0)
+    y, dx = ops.conv2d_forward(x, w, 1, 1, 1, 1), ops.conv2d_dgrad(g, w, x.shape, 1, 1, 1, 1)
+    torch.cuda.synchronize()
+    assert ops.PK_STATS.get("k4_builds", 0) == k0 + 1 and pk.k4 is not None        # one K for both directions
+    assert torch.equal(y, y_ref) and torch.equal(dx, dx_ref)
+    _check(y, F.conv2d(F.interpolate(x.double().cpu(), scale_factor=2, mode="nearest"), w0.double().cpu(), None, 1, 1), what="fwd against fp64")
+    n0 = ops.PK_STATS.get("wino_preps", 0)
+    assert torch.equal(ops.conv2d_forward(x, w, 1, 1, 1, 1), y_ref)               # current K and images are not rebuilt
+    assert ops.PK_STATS.get("k4_builds", 0) == k0 + 1 and ops.PK_STATS.get("wino_preps", 0) == n0
+    with torch.no_grad():
+        w.mul_(-0.5)
+    pk.cell[0] += 1                                               # FlatAdam.touch(): rebuilt at the next use
+    assert torch.equal(ops.conv2d_dgrad(g, w, x.shape, 1, 1, 1, 1), ops.conv2d_dgrad(g, w0 * -0.5, x.shape, 1, 1, 1, 1))
+    assert ops.PK_STATS.get("k4_builds", 0) == k0 + 2
+    with torch.no_grad():
+        w.mul_(-3.0)
+    pk.cell[0] += 1
+    ops.repack_all([pk])                                          # FlatAdam.step()
+    k1, n1 = ops.PK_STATS.get("k4_builds", 0), ops.PK_STATS.get("wino_preps", 0)
+    assert k1 == k0 + 3
+    y3, dx3 = ops.conv2d_forward(x, w, 1, 1, 1, 1), ops.conv2d_dgrad(g, w, x.shape, 1, 1, 1, 1)
+    assert ops.PK_STATS.get("k4_builds", 0) == k1 and ops.PK_STATS.get("wino_preps", 0) == n1
+    assert torch.equal(y3, ops.conv2d_forward(x, w0 * 1.5, 1, 1, 1, 1)) and torch.equal(dx3, ops.conv2d_dgrad(g, w0 * 1.5, x.shape, 1, 1, 1, 1))
+
+
 def test_prepared_images_of_both_kinds_in_one_call():
     """ops.repack_all over a bucket with 3x3 (Winograd) and 4x4 s2 (dconv2) weights: one mogan_conv_prep_group call, 36 + 36 images"""
     if lib.load().mogan_mfma_form() == 1:

@@ -588,6 +588,18 @@ int mogan_adam_step(float* p, const float* g, float* m, float* v, float* ema, lo
                     float beta2, float eps, int step, float* dev_state, int eps_mode, float grad_scale,
                     float ema_decay, hipStream_t stream);
 
+/* ---- text encoder (round 6, third session; csrc/mogan_lstm.hip): nn.Embedding + one-layer bidirectional nn.LSTM over packed
+ * captions in eval mode, without gradients -- RNN_ENCODER.forward, code/coco/attngan/model.py:183-204 (pack_padded_sequence,
+ * self.rnn, pad_packed_sequence, the transposes) -- as ONE launch instead of the 119 of the stock module (MIOpen).
+ *   captions (B, T) int64 token ids (clamped to [0, V)), lens[B] on the HOST (sorted or not; 0 <= lens[i] <= Tmax <= T, Tmax <= 32),
+ *   emb (V, E) (E % 4 == 0, E <= 320), per direction d = 0 forward / 1 reverse: w_ih[d] (4H, E), w_hh[d] (4H, H), b_ih[d], b_hh[d]
+ *   (4H) in PyTorch's gate order i, f, g, o (16-byte aligned weights), H = 128, B <= 64; h0 / c0 (2, B, H) or NULL (zeros);
+ *   words (B, 2H, Tmax): the hidden states, zero for t >= lens[b]; sent (B, 2H): the final states (forward | reverse). */
+int mogan_lstm_encoder_fwd(const long long* captions, const int* lens, const float* emb, const float* const* w_ih,
+                           const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, const float* h0,
+                           const float* c0, float* words, float* sent, int B, int T, int Tmax, int V, int E, int H,
+                           hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

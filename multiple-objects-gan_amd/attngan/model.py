@@ -119,8 +119,10 @@ class BBOX_NET(nn.Module):
 
 # --------------------------------------------------------------------------- text / image encoders
 class RNN_ENCODER(nn.Module):
-    """model.py:120-204.  Frozen front-end that runs once per step without gradients; kept on the
-    stock nn.Embedding/nn.LSTM (MIOpen) -- SURVEY.md §8(a) row 21, not a HIP-kernel target."""
+    """model.py:120-204.  Frozen front-end that runs once per step without gradients.  The parameters live in the stock
+    nn.Embedding / nn.LSTM modules (state_dict keys of the reference); in eval mode on the device the forward is ONE launch
+    (csrc/mogan_lstm.hip: 119 launches and 0.8 ms of host time per call on MIOpen's LSTM), anything else -- training mode,
+    gradients, a GRU, other sizes -- takes the stock modules."""
 
     def __init__(self, ntoken, ninput=300, drop_prob=0.5, nhidden=128, nlayers=1, bidirectional=True):
         super(RNN_ENCODER, self).__init__()
@@ -145,9 +147,17 @@ class RNN_ENCODER(nn.Module):
             return (weight.new_zeros(shape), weight.new_zeros(shape))
         return weight.new_zeros(shape)
 
+    FUSED = True      # eval mode on the device: embedding + bi-LSTM as one launch (hip/ops.lstm_encoder_forward)
+
     def forward(self, captions, cap_lens, hidden, mask=None):
-        emb = self.drop(self.encoder(captions))
         lens = cap_lens.data.tolist() if torch.is_tensor(cap_lens) else list(cap_lens)
+        if (self.FUSED and captions.is_cuda and not self.training and not torch.is_grad_enabled() and self.rnn_type == 'LSTM'
+                and self.nlayers == 1 and self.bidirectional):
+            from ..hip import ops
+            out = ops.lstm_encoder_forward(captions, lens, self.encoder.weight, self.rnn, hidden[0], hidden[1])
+            if out is not None:                     # (B, 2H, T_max) = the reference's output.transpose(1, 2), and (B, 2H)
+                return out
+        emb = self.drop(self.encoder(captions))
         emb = pack_padded_sequence(emb, lens, batch_first=True)
         output, hidden = self.rnn(emb, hidden)
         output = pad_packed_sequence(output, batch_first=True)[0]

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mogan_deep_conv_bn_act_bwd": [P] * 9 + [I, P] + [I] * 10 + [I, F, I, P, Z, P],
     "mogan_upconv3x3_ws_bytes": [I, I],
     "mogan_upconv3x3_fwd": [P, P, P, I, I, I, I, I, P, Z, P],
+    "mogan_lstm_encoder_fwd": [P] * 11 + [I] * 6 + [P],
     "mogan_upconv3x3_k4": [P, P, I, I, P],
     "mogan_upconv3x3_k4_group": [I, P, P, P, P, P],
     "mogan_upconv3x3_dgrad": [P, P, P, I, I, I, I, I, P, Z, P],

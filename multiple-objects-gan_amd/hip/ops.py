@@ -1855,3 +1855,39 @@ def adam_step(p, g, m, v, ema, lr, beta1, beta2, eps, step=0, dev_state=None, ep
     """In-place fused Adam (+EMA) over flat fp32 buckets (trainer.py:137-148,341-342)."""
     call("mogan_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), lr, beta1, beta2, eps, step,
          ptr(dev_state), eps_mode, grad_scale, ema_decay, stream_ptr())
+
+
+# ------------------------------------------------------------------------------- text encoder (csrc/mogan_lstm.hip)
+def lstm_encoder_forward(captions, lens, emb_weight, rnn, h0=None, c0=None):
+    """Embedding + one-layer bidirectional LSTM over packed captions, eval mode, no gradient, as ONE launch
+    (mogan_lstm_encoder_fwd); `rnn` is the nn.LSTM whose parameters are used.  Returns (words (B, 2H, Tmax), sent (B, 2H)) or
+    None where the kernel does not cover the module (then the caller keeps the stock path)."""
+    import ctypes
+    H = rnn.hidden_size
+    if (not isinstance(rnn, torch.nn.LSTM) or rnn.num_layers != 1 or not rnn.bidirectional or not rnn.batch_first or H != 128
+            or not rnn.bias or getattr(rnn, "proj_size", 0)):
+        return None
+    B, T = captions.shape
+    V, E = emb_weight.shape
+    lens = [int(v) for v in lens]
+    Tmax = max(lens) if lens else 0
+    if B > 64 or Tmax < 1 or Tmax > 32 or Tmax > T or E > 320 or E % 4 or min(lens) < 0 or captions.dtype != torch.int64:
+        return None
+    ws = [rnn.weight_ih_l0, rnn.weight_ih_l0_reverse, rnn.weight_hh_l0, rnn.weight_hh_l0_reverse,
+          rnn.bias_ih_l0, rnn.bias_ih_l0_reverse, rnn.bias_hh_l0, rnn.bias_hh_l0_reverse]
+    if any(w.dtype != torch.float32 or not w.is_contiguous() or w.data_ptr() % 16 for w in ws) or not emb_weight.is_contiguous():
+        return None
+    dev = captions.device
+    cap = captions if captions.is_contiguous() else captions.contiguous()
+    words = torch.empty((B, 2 * H, Tmax), dtype=torch.float32, device=dev)
+    sent = torch.empty((B, 2 * H), dtype=torch.float32, device=dev)
+    P2 = ctypes.c_void_p * 2
+    arr = [P2(ws[2 * i].data_ptr(), ws[2 * i + 1].data_ptr()) for i in range(4)]
+    lens_c = (ctypes.c_int * B)(*lens)
+    h0p = ptr(_c(h0)) if h0 is not None else None
+    c0p = ptr(_c(c0)) if c0 is not None else None
+    call("mogan_lstm_encoder_fwd", cap.data_ptr(), ctypes.cast(lens_c, ctypes.c_void_p), emb_weight.data_ptr(),
+         ctypes.cast(arr[0], ctypes.c_void_p), ctypes.cast(arr[1], ctypes.c_void_p), ctypes.cast(arr[2], ctypes.c_void_p),
+         ctypes.cast(arr[3], ctypes.c_void_p), h0p, c0p, words.data_ptr(), sent.data_ptr(), B, T, Tmax, V, E, H, stream_ptr())
+    PK_STATS["lstm_fused"] = PK_STATS.get("lstm_fused", 0) + 1
+    return words, sent

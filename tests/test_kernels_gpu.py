@@ -1436,3 +1436,48 @@ def test_panel_tail_box_filter():
     ref = torch.relu(F.avg_pool2d(slabs.double().cpu().sum(0), 3, 1, 1) * sc.double().cpu().view(1, -1, 1, 1)
                      + sh.double().cpu().view(1, -1, 1, 1))
     assert max_abs(y.cpu().double(), ref) <= 2e-6
+
+
+@pytest.mark.parametrize("case", [(16, 12, [12, 12, 11, 10, 9, 9, 8, 8, 7, 7, 6, 6, 5, 5, 5, 5]), (6, 18, [15, 11, 9, 9, 6, 1]),
+                                  (1, 12, [12]), (3, 32, [32, 20, 2])])
+def test_text_encoder_as_one_launch(case):
+    """csrc/mogan_lstm.hip (mogan_lstm_encoder_fwd): RNN_ENCODER.forward in eval mode -- embedding, packed bidirectional LSTM,
+    unpacking, the transposes (model.py:183-204) -- as one launch against the stock nn.Embedding / nn.LSTM path of the same module
+    on the device (MIOpen) and against torch on the CPU in fp64: zero / non-zero initial state, T_max < T, a one-word caption."""
+    from mogan_amd.attngan import model
+    from mogan_amd.attngan.miscc.config import cfg
+    B, Tw, lens = case
+    cfg.RNN_TYPE = 'LSTM'
+    torch.manual_seed(5 + B)
+    enc = model.RNN_ENCODER(300, nhidden=256).to(DEV).eval()
+    cap = torch.zeros(B, Tw, dtype=torch.int64)
+    for i, n in enumerate(lens):
+        cap[i, :n] = torch.randint(1, 300, (n,))
+    cap = cap.to(DEV)
+    for zero_state in (True, False):
+        hid = enc.init_hidden(B)
+        if not zero_state:
+            hid = tuple(T("lstmh%d_%d" % (k, B), tuple(h.shape), 0.5).to(DEV) for k, h in enumerate(hid))
+        with torch.no_grad():
+            n0 = ops.PK_STATS.get("lstm_fused", 0)
+            w1, s1 = enc(cap, torch.tensor(lens), hid)
+            assert ops.PK_STATS.get("lstm_fused", 0) == n0 + 1
+            model.RNN_ENCODER.FUSED = False
+            try:
+                w0, s0 = enc(cap, torch.tensor(lens), hid)
+            finally:
+                model.RNN_ENCODER.FUSED = True
+            assert ops.PK_STATS.get("lstm_fused", 0) == n0 + 1
+            enc64 = model.RNN_ENCODER(300, nhidden=256).double().eval()
+            enc64.load_state_dict({k: v.double().cpu() for k, v in enc.state_dict().items()})
+            w64, s64 = enc64(cap.cpu(), torch.tensor(lens), tuple(h.double().cpu() for h in hid))
+        assert tuple(w1.shape) == tuple(w0.shape) == (B, 256, max(lens)) and tuple(s1.shape) == tuple(s0.shape) == (B, 256)
+        for got, ref in ((w1, w64), (s1, s64), (w0, w64), (s0, s64)):
+            assert float((got.double().cpu() - ref).abs().max()) <= 5e-6
+        assert float((w1 - w0).abs().max()) <= 5e-6 and float((s1 - s0).abs().max()) <= 5e-6
+        for i, n in enumerate(lens):                                   # exact zeros behind every caption's end
+            assert float(w1[i, :, n:].abs().max()) == 0.0 if n < max(lens) else True
+    with torch.enable_grad():                                          # gradients asked for: the stock modules
+        n0 = ops.PK_STATS.get("lstm_fused", 0)
+        enc(cap, torch.tensor(lens), enc.init_hidden(B))
+        assert ops.PK_STATS.get("lstm_fused", 0) == n0

@@ -18,7 +18,11 @@ i = sys.argv.index("--")
 for spec in sys.argv[1:i]:
     target, value = spec.split("=", 1)
     mod, name = target.split(":")
-    setattr(importlib.import_module(mod), name, ast.literal_eval(value))
+    obj = importlib.import_module(mod)
+    parts = name.split(".")                               # (module:Class.ATTR reaches a class attribute)
+    for part in parts[:-1]:
+        obj = getattr(obj, part)
+    setattr(obj, parts[-1], ast.literal_eval(value))
 script = sys.argv[i + 1]
 sys.argv = sys.argv[i + 1:]
 runpy.run_path(os.path.join(ROOT, script) if not os.path.isabs(script) else script, run_name="__main__")
